@@ -1,0 +1,308 @@
+"""ctypes binding of the CPU oracle (oracle/topopt_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_dp = C.POINTER(C.c_double)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("topopt_oracle.c", "mma_oracle.c", "Makefile")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        L = _LIB
+        L.orc_hash_u01.restype = C.c_double
+        L.orc_hash_u01.argtypes = [C.c_uint64, C.c_uint64]
+        L.orc_elem_lambda_bound.restype = C.c_double
+        L.orc_elem_lambda_bound.argtypes = [C.c_int, C.c_void_p]
+        L.orc_mg_create.restype = C.c_void_p
+        L.orc_mg_create.argtypes = [C.c_int] * 7 + [C.c_double] * 2
+        L.orc_mg_destroy.argtypes = [C.c_void_p]
+        L.orc_mg_assemble.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_mg_precond.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_mg_solve.restype = C.c_int
+        L.orc_mg_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int,
+                                   C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_mg_level_size.restype = C.c_long
+        L.orc_mg_level_size.argtypes = [C.c_void_p, C.c_int]
+        L.orc_mg_level_nnz.restype = C.c_long
+        L.orc_mg_level_nnz.argtypes = [C.c_void_p, C.c_int]
+        L.orc_mg_level_lambda.restype = C.c_double
+        L.orc_mg_level_lambda.argtypes = [C.c_void_p, C.c_int]
+        for f in ("orc_mg_level_apply", "orc_mg_prolong", "orc_mg_restrict"):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_mg_level_diag.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_mg_level_csr.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_mg_smooth.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.orc_filter_create.restype = C.c_void_p
+        L.orc_filter_create.argtypes = [C.c_int] * 3 + [C.c_double] * 4
+        L.orc_filter_destroy.argtypes = [C.c_void_p]
+        L.orc_filter_conn.argtypes = [C.c_void_p]
+        L.orc_filter_nnz.restype = C.c_long
+        L.orc_filter_nnz.argtypes = [C.c_void_p]
+        L.orc_filter_hs.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_filter_project.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double,
+                                         C.c_double]
+        L.orc_filter_gradient.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                          C.c_double, C.c_double]
+        L.orc_mnd.restype = C.c_double
+        L.orc_mnd.argtypes = [C.c_long, C.c_void_p]
+        L.orc_heaviside.argtypes = [C.c_long, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+        L.orc_heaviside_chain.argtypes = [C.c_long, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+        L.orc_pdef_create.restype = C.c_void_p
+        L.orc_pdef_create.argtypes = [C.c_int] * 3 + [C.c_double] * 4 + [C.c_int] * 3 + [C.c_double] * 2
+        L.orc_pdef_destroy.argtypes = [C.c_void_p]
+        L.orc_pdef_kf.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_pdef_apply.restype = C.c_int
+        L.orc_pdef_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p]
+        L.orc_pdef_last_rnorm.restype = C.c_double
+        L.orc_pdef_last_rnorm.argtypes = [C.c_void_p]
+        L.orc_pdef_clamp.restype = C.c_long
+        L.orc_pdef_clamp.argtypes = [C.c_long, C.c_void_p]
+        L.orc_simp.argtypes = [C.c_long, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p]
+        L.orc_synth_density.argtypes = [C.c_int] * 5 + [C.c_double, C.c_uint64, C.c_void_p]
+        L.orc_matfree_apply.argtypes = [C.c_int] * 4 + [C.c_void_p] * 5
+        L.orc_cantilever_bc.argtypes = [C.c_int] * 3 + [C.c_double] * 3 + [C.c_void_p] * 2
+        L.orc_compliance_sens.argtypes = ([C.c_int] * 3 + [C.c_void_p] * 3 + [C.c_double] * 4 + [C.c_void_p] * 4)
+        L.orc_hex8_ke.argtypes = [C.c_void_p] * 3 + [C.c_double, C.c_int, C.c_void_p]
+        L.orc_hex8_ke_box.argtypes = [C.c_double] * 4 + [C.c_void_p]
+        L.orc_pde_kf.argtypes = [C.c_double] * 4 + [C.c_void_p] * 2
+    return _LIB
+
+
+def _p(a):
+    if a is None:
+        return None
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def hex8_ke_box(dx, dy, dz, nu=0.3):
+    ke = np.zeros(576)
+    lib().orc_hex8_ke_box(dx, dy, dz, nu, _p(ke))
+    return ke
+
+
+def pde_kf(dx, dy, dz, R):
+    kf, tf = np.zeros(64), np.zeros(8)
+    lib().orc_pde_kf(dx, dy, dz, R, _p(kf), _p(tf))
+    return kf, tf
+
+
+def elem_lambda_bound(ke):
+    ed = int(round(np.sqrt(ke.size)))
+    ke = f64(ke)
+    return lib().orc_elem_lambda_bound(ed, _p(ke))
+
+
+def cantilever_bc(nx, ny, nz, h):
+    n = 3 * nx * ny * nz
+    N, R = np.zeros(n), np.zeros(n)
+    hx, hy, hz = (h, h, h) if np.isscalar(h) else h
+    lib().orc_cantilever_bc(nx, ny, nz, hx, hy, hz, _p(N), _p(R))
+    return N, R
+
+
+def simp(x, Emin=1e-9, Emax=1.0, penal=3.0):
+    x = f64(x)
+    E = np.zeros_like(x)
+    lib().orc_simp(x.size, _p(x), Emin, Emax, penal, _p(E))
+    return E
+
+
+def synth_density(ex, ey, ez, h, seed=12345, e0z=0, ez_glob=None):
+    x = np.zeros(ex * ey * ez)
+    lib().orc_synth_density(ex, ey, ez, e0z, ez_glob or ez, h, seed, _p(x))
+    return x
+
+
+def matfree_apply(nx, ny, nz, dof, KE, E, N, u):
+    u = f64(u)
+    y = np.zeros_like(u)
+    lib().orc_matfree_apply(nx, ny, nz, dof, _p(f64(KE)), _p(E), _p(N), _p(u), _p(y))
+    return y
+
+
+def compliance_sens(nx, ny, nz, KE, U, xPhys, Emin=1e-9, Emax=1.0, penal=3.0, volfrac=0.12):
+    nel = (nx - 1) * (ny - 1) * (nz - 1)
+    fx, gx = C.c_double(), C.c_double()
+    dfdx, dgdx = np.zeros(nel), np.zeros(nel)
+    lib().orc_compliance_sens(nx, ny, nz, _p(f64(KE)), _p(f64(U)), _p(f64(xPhys)), Emin, Emax, penal, volfrac,
+                              C.addressof(fx), C.addressof(gx), _p(dfdx), _p(dgdx))
+    return fx.value, gx.value, dfdx, dgdx
+
+
+class MG:
+    """CG + Galerkin multigrid on assembled CSR matrices (the oracle solver)."""
+
+    def __init__(self, nx, ny, nz, dof=3, nlv=3, nsmooth=4, ncoarse=30, cheb_lo=0.1, cheb_hi=1.1):
+        self.L = lib()
+        self.h = self.L.orc_mg_create(nx, ny, nz, dof, nlv, nsmooth, ncoarse, cheb_lo, cheb_hi)
+        if not self.h:
+            raise ValueError("mesh not coarsenable %d times" % (nlv - 1))
+        self.nlv, self.dof = nlv, dof
+        self.n = dof * nx * ny * nz
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_mg_destroy(self.h)
+            self.h = None
+
+    def assemble(self, KE, E=None, N=None):
+        self._keep = (f64(KE), None if E is None else f64(E), None if N is None else f64(N))
+        self.L.orc_mg_assemble(self.h, *[_p(a) for a in self._keep])
+
+    def size(self, l):
+        return self.L.orc_mg_level_size(self.h, l)
+
+    def lam(self, l):
+        return self.L.orc_mg_level_lambda(self.h, l)
+
+    def apply(self, l, u):
+        u = f64(u)
+        y = np.zeros_like(u)
+        self.L.orc_mg_level_apply(self.h, l, _p(u), _p(y))
+        return y
+
+    def diag(self, l):
+        d = np.zeros(self.size(l))
+        self.L.orc_mg_level_diag(self.h, l, _p(d))
+        return d
+
+    def csr(self, l):
+        import scipy.sparse as sp
+        n, nnz = self.size(l), self.L.orc_mg_level_nnz(self.h, l)
+        rp, ci, v = np.zeros(n + 1, dtype=np.int64), np.zeros(nnz, dtype=np.int32), np.zeros(nnz)
+        self.L.orc_mg_level_csr(self.h, l, rp.ctypes.data, ci.ctypes.data, _p(v))
+        return sp.csr_matrix((v, ci, rp), shape=(n, n))
+
+    def prolong(self, l, xc):
+        xc = f64(xc)
+        xf = np.zeros(self.size(l))
+        self.L.orc_mg_prolong(self.h, l, _p(xc), _p(xf))
+        return xf
+
+    def restrict(self, l, rf):
+        rf = f64(rf)
+        rc = np.zeros(self.size(l + 1))
+        self.L.orc_mg_restrict(self.h, l, _p(rf), _p(rc))
+        return rc
+
+    def smooth(self, l, b, x, k, zero_guess):
+        b, x = f64(b), f64(x).copy()
+        self.L.orc_mg_smooth(self.h, l, _p(b), _p(x), k, int(zero_guess))
+        return x
+
+    def precond(self, r):
+        r = f64(r)
+        z = np.zeros_like(r)
+        self.L.orc_mg_precond(self.h, _p(r), _p(z))
+        return z
+
+    def solve(self, b, x0=None, rtol=1e-5, atol=1e-50, dtol=1e5, maxit=200, use_pc=True):
+        b = f64(b)
+        x = np.zeros_like(b) if x0 is None else f64(x0).copy()
+        hist = np.zeros(maxit + 1)
+        rn = C.c_double()
+        its = self.L.orc_mg_solve(self.h, _p(b), _p(x), rtol, atol, dtol, maxit, int(use_pc), _p(hist),
+                                  C.addressof(rn))
+        return x, its, hist[: max(its, 0) + 1].copy()
+
+
+class Filter:
+    def __init__(self, nx, ny, nz, h, rmin):
+        self.L = lib()
+        hx, hy, hz = (h, h, h) if np.isscalar(h) else h
+        self.h = self.L.orc_filter_create(nx, ny, nz, hx, hy, hz, rmin)
+        self.nel = (nx - 1) * (ny - 1) * (nz - 1)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_filter_destroy(self.h)
+            self.h = None
+
+    @property
+    def conn(self):
+        return self.L.orc_filter_conn(self.h)
+
+    @property
+    def nnz(self):
+        return self.L.orc_filter_nnz(self.h)
+
+    def hs(self):
+        a = np.zeros(self.nel)
+        self.L.orc_filter_hs(self.h, _p(a))
+        return a
+
+    def project(self, ftype, x, proj=False, beta=0.1, eta=0.0):
+        x = f64(x)
+        xt, xp = np.zeros_like(x), np.zeros_like(x)
+        self.L.orc_filter_project(self.h, ftype, _p(x), _p(xt), _p(xp), int(proj), beta, eta)
+        return xt, xp
+
+    def gradient(self, ftype, x, xTilde, df, proj=False, beta=0.1, eta=0.0):
+        df = f64(df).copy()
+        self.L.orc_filter_gradient(self.h, ftype, _p(f64(x)), _p(f64(xTilde)), _p(df), int(proj), beta, eta)
+        return df
+
+
+class PDEFilter:
+    def __init__(self, nx, ny, nz, h, rmin, nlv=3, nsmooth=4, ncoarse=30, cheb_lo=0.1, cheb_hi=1.1):
+        self.L = lib()
+        hx, hy, hz = (h, h, h) if np.isscalar(h) else h
+        self.h = self.L.orc_pdef_create(nx, ny, nz, hx, hy, hz, rmin, nlv, nsmooth, ncoarse, cheb_lo, cheb_hi)
+        if not self.h:
+            raise ValueError("mesh not coarsenable")
+        self.nel = (nx - 1) * (ny - 1) * (nz - 1)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_pdef_destroy(self.h)
+            self.h = None
+
+    def apply(self, x, rtol=1e-8, maxit=60):
+        x = f64(x)
+        out = np.zeros(self.nel)
+        hist = np.zeros(maxit + 1)
+        its = self.L.orc_pdef_apply(self.h, _p(x), _p(out), rtol, maxit, _p(hist))
+        return out, its, hist[: max(its, 0) + 1].copy()
+
+
+def heaviside(xt, beta, eta):
+    xt = f64(xt)
+    y = np.zeros_like(xt)
+    lib().orc_heaviside(xt.size, _p(xt), beta, eta, _p(y))
+    return y
+
+
+def heaviside_chain(xt, beta, eta):
+    xt = f64(xt)
+    y = np.zeros_like(xt)
+    lib().orc_heaviside_chain(xt.size, _p(xt), beta, eta, _p(y))
+    return y
+
+
+def mnd(x):
+    x = f64(x)
+    return lib().orc_mnd(x.size, _p(x))

@@ -1,0 +1,88 @@
+"""Pins the oracle's element matrices against the reference's own arithmetic.
+
+tests/golden/ref_ke.bin / ref_kf.bin were produced by running the reference's
+Hex8Isoparametric (LinearElasticity.cc:841-998) and PDEFilterMatrix
+(PDEFilter.cc:472-576) in the build container (tests/golden/make_ref_vectors.sh).
+"""
+import os
+
+import numpy as np
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _ke_cases():
+    raw = np.fromfile(os.path.join(G, "ref_ke.bin"))
+    return raw.reshape(-1, 4 + 576)
+
+
+def test_ke_bit_exact_vs_reference(orc):
+    cases = _ke_cases()
+    assert len(cases) == 6
+    for row in cases:
+        dx, dy, dz, nu = row[:4]
+        ke = orc.hex8_ke_box(dx, dy, dz, nu)
+        assert np.array_equal(ke, row[4:]), "KE differs from the reference's bits for %s" % (row[:4],)
+
+
+def test_ke_known_answers(orc):
+    # unit cube, nu = 0.3
+    ke = orc.hex8_ke_box(1.0, 1.0, 1.0, 0.3)
+    assert ke[0] == 0.23504273504273507
+    assert ke[1] == 0.080128205128205107
+    assert ke[3] == -0.10683760683760686
+    K = ke.reshape(24, 24)
+    assert abs(np.trace(K) - 5.6410256410256423) < 1e-14
+    assert np.abs(K - K.T).max() < 1e-16          # symmetric to rounding only
+    assert np.abs(K.sum(axis=1)).max() < 1e-15    # rigid translation
+    # KE scales with h for cubes
+    h = 1.0 / 24
+    assert np.allclose(orc.hex8_ke_box(h, h, h, 0.3), ke * h, rtol=1e-13, atol=0)
+    # 10 distinct magnitudes
+    mags = np.unique(np.round(np.abs(K[np.abs(K) > 1e-12]), 10))
+    assert len(mags) == 10
+
+
+def test_ke_rigid_body_modes(orc):
+    h = 1.0 / 32
+    K = orc.hex8_ke_box(h, h, h, 0.3).reshape(24, 24)
+    X = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]]) * h
+    # rotations about z, y, x
+    for ax in range(3):
+        u = np.zeros((8, 3))
+        a, b = [(0, 1), (0, 2), (1, 2)][ax]
+        u[:, a], u[:, b] = -X[:, b], X[:, a]
+        assert np.abs(K @ u.ravel()).max() < 1e-15
+    w = np.linalg.eigvalsh(0.5 * (K + K.T))
+    assert (w > -1e-15).all() and (w > 1e-10).sum() == 18
+
+
+def test_kf_bit_exact_vs_reference(orc):
+    raw = np.fromfile(os.path.join(G, "ref_kf.bin")).reshape(-1, 4 + 64 + 8)
+    assert len(raw) == 12
+    for row in raw:
+        dx, dy, dz, rmin = row[:4]
+        kf, tf = orc.pde_kf(dx, dy, dz, rmin / 2.0 / np.sqrt(3))
+        assert np.array_equal(kf, row[4:68])
+        assert np.array_equal(tf, row[68:])
+
+
+def test_kf_known_answers(orc):
+    # h = 1/32, rmin = 0.08
+    h = 1.0 / 32
+    kf, tf = orc.pde_kf(h, h, h, 0.08 / 2.0 / np.sqrt(3))
+    assert kf[0] == 6.6858362268518521e-06
+    assert kf[1] == 5.6514033564814812e-07
+    assert kf[6] == -1.2476038049768519e-06
+    K = kf.reshape(8, 8)
+    assert np.allclose(K.sum(axis=1), h ** 3 / 8, rtol=1e-13)
+    assert np.array_equal(K, K.T)
+    assert (tf == 0.125).all()
+
+
+def test_lambda_bound(orc):
+    ke = orc.hex8_ke_box(1.0, 1.0, 1.0, 0.3)
+    K = ke.reshape(24, 24)
+    d = np.sqrt(np.diag(K))
+    ref = np.linalg.eigvalsh(0.5 * (K + K.T) / np.outer(d, d)).max()
+    assert abs(orc.elem_lambda_bound(ke) - ref) < 1e-12
