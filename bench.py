@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: one "step" = one design-iteration pass
+
+    FilterProject(x) -> SIMP "assembly" + Galerkin coarse operators -> CG/GMG solve
+    -> compliance + sensitivities -> Filter::Gradients
+
+on a synthetic cantilever; metric = DOF-updates/s = n_DOF / t_step.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, z-slabs, weak scaling)
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (ex, ey, ez_per_gpu, nlvls)   domain edge h = 1/ey
+    "cantilever128": (128, 128, 128, 4),   # BASELINE.json metric mesh: 128^3 elements, 6.44 M DOF
+    "c2": (128, 64, 64, 3),                # configs[1]
+    "c1": (48, 24, 24, 4),                 # configs[0]
+    "cube256": (256, 256, 256, 4),         # north-star SpMV target mesh
+    "tiny": (32, 16, 16, 3),
+}
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--workload", default="cantilever128", choices=sorted(WORKLOADS))
+    p.add_argument("--rtol", type=float, default=1e-5)
+    p.add_argument("--spmv-reps", type=int, default=50)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample", default="96x48x48")
+    return p.parse_args()
+
+
+def cpu_baseline(sample, rtol):
+    """The oracle (a port of the reference's assembled-CSR path, OpenMP) timed on
+    the host cores for one step of the same algorithm on a bounded sample mesh."""
+    from oracle import oracle as orc
+    ex, ey, ez = [int(v) for v in sample.split("x")]
+    nlv = 4
+    nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
+    cores = os.cpu_count() or 1
+    x = orc.synth_density(ex, ey, ez, h)
+    KE = orc.hex8_ke_box(h, h, h, 0.3)
+    N, R = orc.cantilever_bc(nx, ny, nz, h)
+    flt = orc.Filter(nx, ny, nz, h, 2.56 * h)
+    mg = orc.MG(nx, ny, nz, 3, nlv)
+    t0 = time.perf_counter()
+    xt, xp = flt.project(1, x)
+    mg.assemble(KE, orc.simp(xp), N)
+    U, its, hist = mg.solve(R * N, rtol=rtol)
+    fx, gx, df, dg = orc.compliance_sens(nx, ny, nz, KE, U, xp)
+    df = flt.gradient(1, x, xt, df)
+    dg = flt.gradient(1, x, xt, dg)
+    t = time.perf_counter() - t0
+    ndof = 3 * nx * ny * nz
+    return {"value": ndof / t, "unit": "DOF-updates/s", "cores": cores, "kind": "port",
+            "sample": "1 step on %s elements (%d DOF), %d levels, CG its %d, %.2f s; assembled CSR + Galerkin SpGEMM "
+                      "(the reference's data path), OpenMP on %d threads" % (sample, ndof, nlv, its, t, cores)}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    import topopt_in_petsc_amd as tp
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    ex, ey, ezg, nlv = WORKLOADS[a.workload]
+    ez = ezg * world  # weak scaling: fixed slab per GPU
+    nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
+    ndof = 3 * nx * ny * nz
+    grid = tp.Grid(nx, ny, nz, h, rank=rank, nranks=world)
+    le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=nlv, rtol=a.rtol))
+    flt = tp.Filter(grid, 1, 2.56 * h)
+    le.SetUpLoadAndBC()
+    x = grid.synth_density(12345)
+    xt, xp, df, dg = grid.elem_vec(), grid.elem_vec(), grid.elem_vec(), grid.elem_vec()
+    Emin, Emax, penal, volfrac = 1e-9, 1.0, 3.0, 0.12
+    info = {}
+
+    def step():
+        flt.FilterProject(x, xt, xp)                       # main.cc:98
+        le.U.zero_()                                       # cold start: every step does the full solve
+        fx, gx = le.ComputeObjectiveConstraintsSensitivities(df, dg, xp, Emin, Emax, penal, volfrac)  # main.cc:62
+        df.mul_(10.0 / fx)                                 # main.cc:68-73 (fscale)
+        flt.Gradients(x, xt, df, [dg])                     # main.cc:76
+        info.update(its=le.last_its, fx=fx, gx=gx, rel_res=le.last_rnorm / le.last_bnorm)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    le.pop_stats()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    alg_bytes, flops, launches = le.pop_stats()
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+    t_step = dt / max(a.steps, 1)
+
+    # ---- roofline of the dominant kernel: fine-level matrix-free hex8 SpMV ----
+    # algorithmic bytes: read u 24 B/node + E 8 B/element, write y 24 B/node
+    part = grid.part
+    n_nd_own, n_el_own = part.n_owned_nodes, part.n_own_elems
+    spmv_bytes = 48.0 * n_nd_own + 8.0 * n_el_own
+    u = le.grid.node_vec(3).normal_()
+    y = torch.zeros_like(u)
+    for _ in range(5):
+        le.MatMult(u, y)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(a.spmv_reps):
+        le.MatMult(u, y)
+    ev1.record()
+    torch.cuda.synchronize()
+    spmv_ms = ev0.elapsed_time(ev1) / a.spmv_reps
+    achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "k_node<3,MatfreeOp<3>,EPI_APPLY> (fine-level hex8 SpMV)",
+                "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                "alg_bytes_per_launch": spmv_bytes, "avg_launch_ms": spmv_ms,
+                "fp64_tflops": 1152.0 * n_el_own / (spmv_ms * 1e-3) / 1e12}
+
+    out = {
+        "metric": "DOF-updates/s per design iter (assembly+PCG+filter)",
+        "value": ndof / t_step, "unit": "DOF-updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": t_step * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%s: cantilever %dx%dx%d elements (%d DOF), z-slabs over %d GPU(s), rmin=2.56h density "
+                               "filter, CG + %d-level GMG (Chebyshev(4)-Jacobi, Galerkin), rtol %g, cold start, "
+                               "filtered synthetic density seed 12345" % (a.workload, ex, ey, ez, ndof, world, nlv, a.rtol),
+                   "n_dof": ndof, "cg_its": info.get("its"), "rel_residual": info.get("rel_res"), "fx": info.get("fx"),
+                   "parallelism": "zslab%d" % world, "kernel_launches_per_step": launches / max(a.steps, 1),
+                   "alg_GB_per_step": alg_bytes / max(a.steps, 1) / 1e9,
+                   "hot_path_alg_GBps": alg_bytes / dt / 1e9},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a.cpu_sample, a.rtol)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,180 @@
+/*
+ * topopt_amd.h -- C ABI of the MI355X-native hot path of TopOpt_in_PETSc.
+ *
+ * One shared library (libtopopt_amd.so, HIP, gfx950) replaces what the
+ * reference does per design iteration through PETSc:
+ *
+ *   stiffness "assembly"  -> tp_elasticity_assemble   (LinearElasticity.cc:487-549, :198-200)
+ *   KSPSolve (CG + PCMG)  -> tp_elasticity_solve      (LinearElasticity.cc:204, :617-746)
+ *   MatMult(K, u)         -> tp_elasticity_apply      (PETSc MatMult on the assembled K)
+ *   objective/sensitivity -> tp_elasticity_objective  (LinearElasticity.cc:363-445)
+ *   density filter        -> tp_filter_*              (Filter.cc:60-204, :290-463)
+ *   Helmholtz PDE filter  -> tp_pdefilter_*           (PDEFilter.cc:189-218, :243-417)
+ *
+ * Conventions (mirroring PetscErrorCode): every function returns int, 0 = OK,
+ * nonzero = error (TP_ERR_*; hipError_t values are passed through offset by
+ * TP_ERR_HIP).  No exceptions cross the boundary.  Scalars are double
+ * (PetscScalar), indices int (PetscInt, 32 bit) except sizes in bytes/long.
+ *
+ * Memory: every `double*` argument marked [dev] is a DEVICE pointer to plain
+ * contiguous doubles (no torch types).  Host code that only has host arrays
+ * (VecGetArray in the reference) uses tp_malloc / tp_memcpy_* below.
+ *
+ * Layout (identical to the reference's DMDA natural ordering,
+ * LinearElasticity.cc:819-826): node id = i + nx*(j + ny*k), dof = 3*node+c
+ * (u,v,w interlaced), element id = i + ex*(j + ey*k), x fastest.
+ *
+ * Partitioning: z-slabs.  Rank r of R owns element layers [r*ez/R, (r+1)*ez/R)
+ * and, like DMDA (a rank owns the elements whose upper corner node it owns,
+ * LinearElasticity.cc:802-814), the node planes (r*ez/R, (r+1)*ez/R]; rank 0
+ * also owns plane 0.  A rank's *local* node array stores planes
+ * r*ez/R .. (r+1)*ez/R+1 (one ghost plane either side where a neighbour
+ * exists); local element arrays store the own layers only.  With R = 1 local
+ * == global.  tp_grid_local_* report the local sizes.
+ *
+ * Threading: one host thread per context; all work is enqueued on the
+ * hipStream_t given at creation (pass the framework's current stream).
+ */
+#ifndef TOPOPT_AMD_H
+#define TOPOPT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TP_OK 0
+#define TP_ERR_ARG 1        /* bad argument / mesh not coarsenable (TopOpt.cc:183-201) */
+#define TP_ERR_STATE 2      /* call order violated (e.g. solve before assemble) */
+#define TP_ERR_DIVERGED 3   /* KSP_DIVERGED_DTOL analogue */
+#define TP_ERR_COMM 4       /* communication callback failed */
+#define TP_ERR_HIP 1000     /* TP_ERR_HIP + hipError_t */
+
+#define TP_MAX_LEVELS 10
+
+/* ---- communication hooks (z-slab halo + reductions) -------------------- */
+/* The library never links RCCL itself: the host framework (torch.distributed
+ * with the nccl(=RCCL) backend, or gloo in CPU/1-GPU tests) supplies two
+ * stream-ordered operations on four staging buffers it owns.               */
+typedef struct tp_comm {
+    void *user;
+    double *send_lo, *send_hi, *recv_lo, *recv_hi; /* [dev] staging, cap doubles each */
+    double *red;                                   /* [dev] >= 16 doubles, all-reduce scratch */
+    long cap;
+    /* send send_lo[0..n) to rank-1 and send_hi[0..n) to rank+1, receive recv_lo from
+     * rank-1 and recv_hi from rank+1 (absent neighbours are skipped). */
+    int (*exchange)(void *user, long n);
+    /* in-place sum over ranks of red[0..n) */
+    int (*allreduce_sum)(void *user, int n);
+} tp_comm;
+
+/* ---- grid / partition --------------------------------------------------- */
+typedef struct tp_grid_opts {
+    int nx, ny, nz;       /* GLOBAL node counts, TopOpt.cc:106-108 (-nx -ny -nz) */
+    double hx, hy, hz;    /* element edge lengths */
+    int rank, nranks;     /* z-slab partition */
+    int device;           /* HIP device ordinal */
+    void *stream;         /* hipStream_t; NULL = the null stream */
+    const tp_comm *comm;  /* NULL when nranks == 1 */
+} tp_grid_opts;
+
+typedef struct tp_grid tp_grid;
+int tp_grid_create(tp_grid **g, const tp_grid_opts *o);
+int tp_grid_destroy(tp_grid *g);
+long tp_grid_local_nodes(const tp_grid *g);     /* nodes in the local array incl. ghost planes */
+long tp_grid_local_elems(const tp_grid *g);     /* own elements */
+long tp_grid_owned_node_offset(const tp_grid *g); /* first owned node in the local array */
+long tp_grid_owned_nodes(const tp_grid *g);
+int tp_grid_node_z0(const tp_grid *g);          /* global z index of local node plane 0 */
+int tp_grid_elem_z0(const tp_grid *g);          /* global z index of local element layer 0 */
+
+/* ---- device memory helpers (for hosts without a GPU framework) ---------- */
+int tp_malloc(void **p, size_t bytes);
+int tp_free(void *p);
+int tp_memcpy_h2d(void *dst, const void *src, size_t bytes);
+int tp_memcpy_d2h(void *dst, const void *src, size_t bytes);
+int tp_sync(const tp_grid *g);
+
+/* ---- linear elasticity -------------------------------------------------- */
+typedef struct tp_solver_opts {
+    int nlvls;          /* MG levels, LinearElasticity.cc:23 (-nlvls, default 4) */
+    double nu;          /* Poisson ratio, :22 (-nu) */
+    double rtol, atol, dtol; /* KSPSetTolerances, :621-623 */
+    int max_it;         /* :625 */
+    int nsmooth;        /* smoother iterations per sweep, :635 */
+    int ncoarse;        /* coarse-solve iterations, :631 */
+    double cheb_lo, cheb_hi; /* Chebyshev window as fractions of the eigenvalue estimate */
+    int nlanczos;       /* Lanczos steps for the coarse-level estimates */
+} tp_solver_opts;
+void tp_solver_default_opts(tp_solver_opts *o);
+
+typedef struct tp_elasticity tp_elasticity;
+/* LinearElasticity::LinearElasticity + SetUpLoadAndBC (LinearElasticity.cc:12-180):
+ * computes KE (Hex8Isoparametric, :841-998).  N [dev, local nodes*3, 1 = free /
+ * 0 = clamped] and RHS [dev, local nodes*3] are the Dirichlet and load vectors;
+ * tp_elasticity_cantilever fills them with the reference's load case. */
+int tp_elasticity_create(tp_elasticity **e, tp_grid *g, const tp_solver_opts *o);
+int tp_elasticity_destroy(tp_elasticity *e);
+int tp_elasticity_get_ke(const tp_elasticity *e, double *ke_host_576);
+int tp_elasticity_cantilever(tp_elasticity *e, double *N, double *RHS);      /* :143-171 */
+int tp_elasticity_set_bc(tp_elasticity *e, const double *N);                /* N [dev] */
+/* AssembleStiffnessMatrix + KSPSetOperators/KSPSetUp (:487-549, :198-200):
+ * E = Emin + x^p (Emax-Emin), Galerkin coarse operators, Jacobi diagonals,
+ * Chebyshev windows.  xPhys [dev, own elements].  RHS is NOT modified here;
+ * tp_elasticity_solve multiplies the load by N as :542 does. */
+int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, double Emin, double Emax, double penal);
+/* MatMult with the operator  N K(x) N + (I - N).  u, y [dev, local nodes*3];
+ * ghost planes of u are refreshed internally, y is valid on owned planes. */
+int tp_elasticity_apply(tp_elasticity *e, const double *u, double *y);
+/* KSPSolve(ksp, RHS, U) with a warm start from U (:204, :647).  U, RHS [dev,
+ * local nodes*3].  its / rnorm as KSPGetIterationNumber / KSPGetResidualNorm
+ * (:212-213).  hist (host, may be NULL) receives ||b - A x_k|| for k = 0..its,
+ * at most hist_cap entries. */
+int tp_elasticity_solve(tp_elasticity *e, const double *RHS, double *U, int *its, double *rnorm, double *bnorm,
+                        double *hist, int hist_cap);
+/* ComputeObjectiveConstraintsSensitivities minus the solve (:377-437):
+ * fx = sum E_e u^T KE u, gx = sum x / n - volfrac, dfdx, dgdx = 1/n.
+ * U [dev, local nodes*3], xPhys, dfdx, dgdx [dev, own elements] (dgdx may be NULL). */
+int tp_elasticity_objective(tp_elasticity *e, const double *U, const double *xPhys, double Emin, double Emax,
+                            double penal, double volfrac, double *fx, double *gx, double *dfdx, double *dgdx);
+/* introspection for parity tests */
+int tp_elasticity_level_count(const tp_elasticity *e);
+long tp_elasticity_level_nodes(const tp_elasticity *e, int level);
+double tp_elasticity_level_lambda(const tp_elasticity *e, int level);
+int tp_elasticity_level_apply(tp_elasticity *e, int level, const double *u, double *y); /* [dev, level local dofs] */
+int tp_elasticity_level_diag(tp_elasticity *e, int level, double *d);
+int tp_elasticity_precond(tp_elasticity *e, const double *r, double *z); /* one V-cycle */
+int tp_elasticity_restrict(tp_elasticity *e, int level, const double *rf, double *rc);
+int tp_elasticity_prolong_add(tp_elasticity *e, int level, const double *xc, double *xf);
+/* bytes moved / flops of the last call, by the algorithmic model of DESIGN.md */
+int tp_elasticity_last_stats(const tp_elasticity *e, double *alg_bytes, double *flops, long *kernel_launches);
+
+/* ---- density / sensitivity filter (Filter.cc) --------------------------- */
+typedef struct tp_filter tp_filter;
+/* Filter::Filter + SetUp (Filter.cc:25-38, :290-463).  filterType 0 = sensitivity,
+ * 1 = density, 2 = PDE (Helmholtz), other = none; rmin is an absolute length. */
+int tp_filter_create(tp_filter **f, tp_grid *g, int filterType, double rmin, const tp_solver_opts *pde_opts);
+int tp_filter_destroy(tp_filter *f);
+int tp_filter_stencil_width(const tp_filter *f);        /* ElemConn, Filter.cc:326 */
+int tp_filter_get_hs(tp_filter *f, double *Hs);          /* [dev, own elements] */
+/* Filter::FilterProject (:60-117): x -> xTilde -> xPhys [dev, own elements] */
+int tp_filter_project(tp_filter *f, const double *x, double *xTilde, double *xPhys, int projectionFilter, double beta,
+                      double eta);
+/* Filter::Gradients (:120-204): dfdx and dgdx[0..m) filtered in place */
+int tp_filter_gradients(tp_filter *f, const double *x, const double *xTilde, double *dfdx, int m, double **dgdx,
+                        int projectionFilter, double beta, double eta);
+int tp_filter_mnd(tp_filter *f, const double *x, double *mnd);   /* GetMND, :206-225 */
+int tp_filter_last_pde_its(const tp_filter *f, int *its, double *rnorm);
+
+/* ---- streaming helpers used by the driver (main.cc:68-73, TopOpt.cc) ----- */
+int tp_vec_scale(tp_grid *g, double *x, double a, long n);
+int tp_vec_set(tp_grid *g, double *x, double a, long n);
+/* synthetic density of SURVEY.md 8(d), indexed by GLOBAL element id */
+int tp_synth_density(tp_grid *g, double *x, uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOPOPT_AMD_H */

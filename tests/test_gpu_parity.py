@@ -1,0 +1,192 @@
+"""GPU parity: the HIP hot path (through the C ABI) against the CPU oracle on
+the same seeded inputs.  Tolerances are stated per test; FP64 throughout."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def tp():
+    import topopt_in_petsc_amd as tp
+    tp.load_library()
+    assert torch.cuda.is_available()
+    return tp
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def make(tp, orc, ex, ey, ez, nlv, kind="synth", **kw):
+    nx, ny, nz = ex + 1, ey + 1, ez + 1
+    h = 1.0 / ey
+    grid = tp.Grid(nx, ny, nz, h)
+    le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=nlv, **kw))
+    le.SetUpLoadAndBC()
+    x = np.full(ex * ey * ez, 0.12) if kind == "uniform" else orc.synth_density(ex, ey, ez, h)
+    KE = orc.hex8_ke_box(h, h, h, 0.3)
+    N, R = orc.cantilever_bc(nx, ny, nz, h)
+    mg = orc.MG(nx, ny, nz, 3, nlv, kw.get("nsmooth", 4), kw.get("ncoarse", 30))
+    mg.assemble(KE, orc.simp(x), N)
+    le.AssembleStiffnessMatrix(dev(x), 1e-9, 1.0, 3.0)
+    return grid, le, mg, x, KE, N, R
+
+
+def test_ke_bits(tp):
+    raw = np.fromfile(os.path.join(G, "ref_ke.bin")).reshape(-1, 580)
+    for row in raw[[1, 2, 5]]:  # cubes h = 1/24, 1/32, 1/64 (nu 0.3)
+        ey = int(round(1 / row[1]))
+        grid = tp.Grid(2 * ey + 1, ey + 1, ey + 1, row[1])
+        le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=1))
+        assert np.array_equal(le.KE, row[4:]), "product KE differs from the reference's bits"
+
+
+def test_cantilever_vectors(tp, orc):
+    grid = tp.Grid(17, 9, 9, 0.125)
+    le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=2))
+    le.SetUpLoadAndBC()
+    N, R = orc.cantilever_bc(17, 9, 9, 0.125)
+    assert np.array_equal(host(le.N), N) and np.array_equal(host(le.RHS), R)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "synth"])
+def test_matrix_free_apply(tp, orc, kind):
+    grid, le, mg, x, KE, N, R = make(tp, orc, 16, 8, 8, 1, kind)
+    u = np.random.default_rng(0).standard_normal(mg.n)
+    y = host(le.MatMult(dev(u)))
+    yo = mg.apply(0, u)
+    assert rel(y, yo) <= 1e-13
+    cl = N == 0
+    assert np.array_equal(y[cl], u[cl])  # Dirichlet rows return u
+
+
+def test_galerkin_levels_transfers_and_bounds(tp, orc):
+    grid, le, mg, x, KE, N, R = make(tp, orc, 16, 8, 8, 3)
+    rng = np.random.default_rng(1)
+    assert le.level_count() == 3
+    for l in range(3):
+        n = 3 * le.level_nodes(l)
+        assert n == mg.size(l)
+        u = rng.standard_normal(n)
+        assert rel(host(le.level_apply(l, dev(u))), mg.apply(l, u)) <= 1e-13
+        assert rel(1.0 / host(le.level_dinv(l)), mg.diag(l)) <= 1e-13
+        assert le.level_lambda(l) == pytest.approx(mg.lam(l), rel=1e-10)
+    for l in range(2):
+        rf = rng.standard_normal(mg.size(l))
+        assert rel(host(le.restrict(l, dev(rf))), mg.restrict(l, rf)) <= 1e-14
+        xc = rng.standard_normal(mg.size(l + 1))
+        xf = rng.standard_normal(mg.size(l))
+        assert rel(host(le.prolong_add(l, dev(xc), dev(xf))), xf + mg.prolong(l, xc)) <= 1e-14
+
+
+def test_vcycle(tp, orc):
+    grid, le, mg, x, KE, N, R = make(tp, orc, 16, 8, 8, 3)
+    r = np.random.default_rng(2).standard_normal(mg.n)
+    assert rel(host(le.precond(dev(r))), mg.precond(r)) <= 1e-11
+
+
+@pytest.mark.parametrize("kind,nlv", [("uniform", 3), ("synth", 3), ("synth", 2)])
+def test_solve_residual_history(tp, orc, kind, nlv):
+    """KSP residual history and solution against the oracle running the same
+    algorithm (north star: 1e-10 relative)."""
+    grid, le, mg, x, KE, N, R = make(tp, orc, 16, 8, 8, nlv, kind, rtol=1e-10, max_it=300)
+    its = le.KSPSolve(hist_cap=400)
+    Uo, its_o, hist_o = mg.solve(R * N, rtol=1e-10, maxit=300)
+    assert its == its_o
+    h = le.last_hist
+    assert len(h) == len(hist_o)
+    assert np.abs(h / hist_o - 1).max() <= 1e-8, np.abs(h / hist_o - 1).max()
+    assert np.abs(h[:10] / hist_o[:10] - 1).max() <= 1e-10
+    assert rel(host(le.U), Uo) <= 1e-9
+    assert le.last_bnorm == pytest.approx(np.linalg.norm(R * N), rel=1e-14)
+    # warm start from the converged state (KSPSetInitialGuessNonzero): no iterations
+    assert le.KSPSolve() == 0
+
+
+def test_objective_and_sensitivities(tp, orc):
+    grid, le, mg, x, KE, N, R = make(tp, orc, 16, 8, 8, 3, rtol=1e-12, max_it=300)
+    le.KSPSolve()
+    U = host(le.U)
+    df, dg = grid.elem_vec(), grid.elem_vec()
+    fx, gx = le.Objective(dev(x), 1e-9, 1.0, 3.0, 0.12, df, dg)
+    fo, go, dfo, dgo = orc.compliance_sens(17, 9, 9, KE, U, x)
+    assert fx == pytest.approx(fo, rel=1e-13)
+    assert gx == pytest.approx(go, abs=1e-14)
+    assert rel(host(df), dfo) <= 1e-12
+    assert np.array_equal(host(dg), dgo)
+    # against the oracle's own converged state: 1e-10 (north star)
+    Uo, _, _ = mg.solve(R * N, rtol=1e-12, maxit=300)
+    fo2, _, dfo2, _ = orc.compliance_sens(17, 9, 9, KE, Uo, x)
+    assert fx == pytest.approx(fo2, rel=1e-10)
+    assert rel(host(df), dfo2) <= 1e-9
+
+
+@pytest.mark.parametrize("rfac", [1.5, 2.56, 3.2])
+def test_conv_filter(tp, orc, rfac):
+    ex, ey, ez = 12, 8, 8
+    h = 1.0 / ey
+    grid = tp.Grid(ex + 1, ey + 1, ez + 1, h)
+    of = orc.Filter(ex + 1, ey + 1, ez + 1, h, rfac * h)
+    rng = np.random.default_rng(3)
+    x = rng.random(ex * ey * ez) * 0.9 + 0.05
+    df0 = rng.standard_normal(x.size)
+    dg0 = np.full(x.size, 1.0 / x.size)
+    for ftype in (1, 0):
+        f = tp.Filter(grid, ftype, rfac * h)
+        assert f.ElemConn == of.conn
+        assert rel(host(f.Hs()), of.hs()) <= 1e-14
+        xt, xp = grid.elem_vec(), grid.elem_vec()
+        f.FilterProject(dev(x), xt, xp)
+        xto, xpo = of.project(ftype, x)
+        assert rel(host(xt), xto) <= 1e-14 and rel(host(xp), xpo) <= 1e-14
+        df, dg = dev(df0), dev(dg0)
+        f.Gradients(dev(x), xt, df, [dg])
+        assert rel(host(df), of.gradient(ftype, x, xto, df0)) <= 1e-13
+        dgo = of.gradient(ftype, x, xto, dg0) if ftype == 1 else dg0
+        assert rel(host(dg), dgo) <= 1e-13
+        assert f.GetMND(xp) == pytest.approx(orc.mnd(xpo), rel=1e-13)
+        # Heaviside projection + chain rule
+        f.FilterProject(dev(x), xt, xp, True, 4.0, 0.5)
+        xto, xpo = of.project(ftype, x, True, 4.0, 0.5)
+        assert rel(host(xp), xpo) <= 1e-13
+        df = dev(df0)
+        f.Gradients(dev(x), xt, df, [], True, 4.0, 0.5)
+        assert rel(host(df), of.gradient(ftype, x, xto, df0, True, 4.0, 0.5)) <= 1e-12
+
+
+def test_pde_filter(tp, orc):
+    ex, ey, ez = 16, 8, 8
+    h = 1.0 / ey
+    rmin = 2.56 * h
+    grid = tp.Grid(ex + 1, ey + 1, ez + 1, h)
+    po = tp.SolverOptions(nlvls=3, rtol=1e-8, dtol=1e3, max_it=60, nsmooth=2, ncoarse=10)
+    f = tp.Filter(grid, 2, rmin, po)
+    of = orc.PDEFilter(ex + 1, ey + 1, ez + 1, h, rmin, nlv=3, nsmooth=2, ncoarse=10)
+    x = np.random.default_rng(4).random(ex * ey * ez)
+    xt, xp = grid.elem_vec(), grid.elem_vec()
+    f.FilterProject(dev(x), xt, xp)
+    xo, its_o, hist_o = of.apply(x)
+    its, rn = f.last_pde_solve()
+    assert its == its_o
+    assert rn == pytest.approx(hist_o[-1], rel=1e-6)
+    assert rel(host(xt), np.clip(xo, 0, 1)) <= 1e-10
+    # gradients: same operator, no clamp (PDEFilter.cc:218)
+    df0 = np.random.default_rng(5).standard_normal(x.size)
+    df = dev(df0)
+    f.Gradients(dev(x), xt, df, [])
+    dfo, _, _ = of.apply(df0)
+    assert rel(host(df), dfo) <= 1e-9

@@ -1,0 +1,267 @@
+"""Host-side mirror of the reference's operator interface for the hot path.
+
+Class and method names follow the reference (LinearElasticity.h:21-109,
+Filter.h:34-92) so that tests read like the reference's call sites in main.cc;
+vectors are 1-D float64 torch tensors on the GPU standing in for PETSc Vecs
+(local slab layout, see include/topopt_amd.h).  Everything numerical happens in
+libtopopt_amd.so.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import lib as _lib
+from .comm import SlabComm
+from .partition import SlabPartition
+
+
+class TopOptError(RuntimeError):
+    def __init__(self, code, where):
+        names = {1: "TP_ERR_ARG", 2: "TP_ERR_STATE", 3: "TP_ERR_DIVERGED", 4: "TP_ERR_COMM"}
+        msg = names.get(code, "hipError %d" % (code - 1000) if code >= 1000 else str(code))
+        super().__init__("%s failed: %s" % (where, msg))
+        self.code = code
+
+
+def _chk(code, where):
+    if code != 0:
+        raise TopOptError(code, where)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.dtype == torch.float64 and t.is_contiguous() and t.is_cuda, "need a contiguous float64 GPU tensor"
+    return t.data_ptr()
+
+
+@dataclass
+class SolverOptions:
+    """LinearElasticity.cc:621-635 defaults; smoother = Chebyshev(nsmooth)/Jacobi."""
+    nlvls: int = 4
+    nu: float = 0.3
+    rtol: float = 1.0e-5
+    atol: float = 1.0e-50
+    dtol: float = 1.0e5
+    max_it: int = 200
+    nsmooth: int = 4
+    ncoarse: int = 30
+    cheb_lo: float = 0.1
+    cheb_hi: float = 1.1
+    nlanczos: int = 10
+
+    def c_struct(self):
+        return _lib.SolverOpts(self.nlvls, self.nu, self.rtol, self.atol, self.dtol, self.max_it, self.nsmooth,
+                               self.ncoarse, self.cheb_lo, self.cheb_hi, self.nlanczos)
+
+
+class Grid:
+    """The DMDA stand-in: global node counts, element size, z-slab partition."""
+
+    def __init__(self, nx, ny, nz, h, rank=0, nranks=1, device=None, group=None):
+        self.L = _lib.load_library()
+        if not torch.cuda.is_available():
+            raise RuntimeError("no GPU visible: the MI355X hot path has no CPU fallback")
+        self.part = SlabPartition(nx, ny, nz, rank, nranks)
+        self.h = (h, h, h) if isinstance(h, (int, float)) else tuple(h)
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.stream = torch.cuda.current_stream(self.device)
+        self.comm = None
+        comm_p = None
+        if nranks > 1:
+            self.comm = SlabComm(self.part, self.device, group)
+            comm_p = C.cast(C.pointer(self.comm.c_struct), C.c_void_p)
+        self._opts = _lib.GridOpts(nx, ny, nz, self.h[0], self.h[1], self.h[2], rank, nranks, self.device.index,
+                                   self.stream.cuda_stream, comm_p)
+        self.handle = C.c_void_p()
+        _chk(self.L.tp_grid_create(C.byref(self.handle), C.byref(self._opts)), "tp_grid_create")
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            self.L.tp_grid_destroy(self.handle)
+            self.handle = None
+
+    # sizes of the local arrays
+    @property
+    def n_local_nodes(self):
+        return self.L.tp_grid_local_nodes(self.handle)
+
+    @property
+    def n_own_elems(self):
+        return self.L.tp_grid_local_elems(self.handle)
+
+    def node_vec(self, dof=3):
+        return torch.zeros(self.n_local_nodes * dof, dtype=torch.float64, device=self.device)
+
+    def elem_vec(self, value=0.0):
+        return torch.full((self.n_own_elems,), value, dtype=torch.float64, device=self.device)
+
+    def synth_density(self, seed=12345):
+        x = self.elem_vec()
+        _chk(self.L.tp_synth_density(self.handle, _ptr(x), seed), "tp_synth_density")
+        return x
+
+    def sync(self):
+        _chk(self.L.tp_sync(self.handle), "tp_sync")
+
+
+class LinearElasticity:
+    """LinearElasticity (LinearElasticity.h:21-109) on the MI355X."""
+
+    def __init__(self, grid, opts=None):
+        self.grid, self.L = grid, grid.L
+        self.opts = opts or SolverOptions()
+        self.handle = C.c_void_p()
+        self._o = self.opts.c_struct()
+        _chk(self.L.tp_elasticity_create(C.byref(self.handle), grid.handle, C.byref(self._o)), "tp_elasticity_create")
+        self.U = grid.node_vec(3)       # state, persists across design iterations (warm start, :647)
+        self.RHS = grid.node_vec(3)
+        self.N = grid.node_vec(3)
+        self.last_its, self.last_rnorm, self.last_bnorm, self.last_hist = 0, 0.0, 0.0, None
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            self.L.tp_elasticity_destroy(self.handle)
+            self.handle = None
+
+    @property
+    def KE(self):
+        import numpy as np
+        ke = np.zeros(576)
+        _chk(self.L.tp_elasticity_get_ke(self.handle, ke.ctypes.data), "tp_elasticity_get_ke")
+        return ke
+
+    def SetUpLoadAndBC(self):
+        """cantilever load case, LinearElasticity.cc:143-171"""
+        _chk(self.L.tp_elasticity_cantilever(self.handle, _ptr(self.N), _ptr(self.RHS)), "tp_elasticity_cantilever")
+
+    def SetBC(self, N, RHS):
+        self.N.copy_(N)
+        self.RHS.copy_(RHS)
+        _chk(self.L.tp_elasticity_set_bc(self.handle, _ptr(self.N)), "tp_elasticity_set_bc")
+
+    def AssembleStiffnessMatrix(self, xPhys, Emin, Emax, penal):
+        _chk(self.L.tp_elasticity_assemble(self.handle, _ptr(xPhys), Emin, Emax, penal), "tp_elasticity_assemble")
+
+    def MatMult(self, u, y=None):
+        y = torch.zeros_like(u) if y is None else y
+        _chk(self.L.tp_elasticity_apply(self.handle, _ptr(u), _ptr(y)), "tp_elasticity_apply")
+        return y
+
+    def KSPSolve(self, hist_cap=0):
+        import numpy as np
+        its, rn, bn = C.c_int(), C.c_double(), C.c_double()
+        hist = np.zeros(max(hist_cap, 1))
+        rc = self.L.tp_elasticity_solve(self.handle, _ptr(self.RHS), _ptr(self.U), C.byref(its), C.byref(rn),
+                                        C.byref(bn), hist.ctypes.data if hist_cap else None, hist_cap)
+        self.last_its, self.last_rnorm, self.last_bnorm = its.value, rn.value, bn.value
+        self.last_hist = hist[: min(its.value + 1, hist_cap)] if hist_cap else None
+        _chk(rc, "tp_elasticity_solve")
+        return its.value
+
+    def SolveState(self, xPhys, Emin, Emax, penal, hist_cap=0):
+        """LinearElasticity.cc:182-223"""
+        self.AssembleStiffnessMatrix(xPhys, Emin, Emax, penal)
+        return self.KSPSolve(hist_cap)
+
+    def Objective(self, xPhys, Emin, Emax, penal, volfrac, dfdx=None, dgdx=None):
+        fx, gx = C.c_double(), C.c_double()
+        _chk(self.L.tp_elasticity_objective(self.handle, _ptr(self.U), _ptr(xPhys), Emin, Emax, penal, volfrac,
+                                            C.byref(fx), C.byref(gx), _ptr(dfdx), _ptr(dgdx)),
+             "tp_elasticity_objective")
+        return fx.value, gx.value
+
+    def ComputeObjectiveConstraintsSensitivities(self, dfdx, dgdx, xPhys, Emin, Emax, penal, volfrac, hist_cap=0):
+        """LinearElasticity.cc:363-445 -> (fx, gx)"""
+        self.SolveState(xPhys, Emin, Emax, penal, hist_cap)
+        return self.Objective(xPhys, Emin, Emax, penal, volfrac, dfdx, dgdx)
+
+    # ---- introspection used by the parity tests ----------------------------
+    def level_count(self):
+        return self.L.tp_elasticity_level_count(self.handle)
+
+    def level_nodes(self, l):
+        return self.L.tp_elasticity_level_nodes(self.handle, l)
+
+    def level_lambda(self, l):
+        return self.L.tp_elasticity_level_lambda(self.handle, l)
+
+    def level_vec(self, l):
+        return torch.zeros(3 * self.level_nodes(l), dtype=torch.float64, device=self.grid.device)
+
+    def level_apply(self, l, u):
+        y = torch.zeros_like(u)
+        _chk(self.L.tp_elasticity_level_apply(self.handle, l, _ptr(u), _ptr(y)), "tp_elasticity_level_apply")
+        return y
+
+    def level_dinv(self, l):
+        d = self.level_vec(l)
+        _chk(self.L.tp_elasticity_level_diag(self.handle, l, _ptr(d)), "tp_elasticity_level_diag")
+        return d
+
+    def precond(self, r):
+        z = torch.zeros_like(r)
+        _chk(self.L.tp_elasticity_precond(self.handle, _ptr(r), _ptr(z)), "tp_elasticity_precond")
+        return z
+
+    def restrict(self, l, rf):
+        rc = self.level_vec(l + 1)
+        _chk(self.L.tp_elasticity_restrict(self.handle, l, _ptr(rf), _ptr(rc)), "tp_elasticity_restrict")
+        return rc
+
+    def prolong_add(self, l, xc, xf):
+        _chk(self.L.tp_elasticity_prolong_add(self.handle, l, _ptr(xc), _ptr(xf)), "tp_elasticity_prolong_add")
+        return xf
+
+    def pop_stats(self):
+        b, f, n = C.c_double(), C.c_double(), C.c_long()
+        self.L.tp_elasticity_last_stats(self.handle, C.byref(b), C.byref(f), C.byref(n))
+        return b.value, f.value, n.value
+
+
+class Filter:
+    """Filter (Filter.h:34-92): filterType 0 sensitivity, 1 density, 2 PDE."""
+
+    def __init__(self, grid, filterType, rmin, pde_opts=None):
+        self.grid, self.L = grid, grid.L
+        self.filterType = filterType
+        self.handle = C.c_void_p()
+        po = pde_opts.c_struct() if pde_opts else None
+        _chk(self.L.tp_filter_create(C.byref(self.handle), grid.handle, filterType, rmin,
+                                     C.byref(po) if po else None), "tp_filter_create")
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            self.L.tp_filter_destroy(self.handle)
+            self.handle = None
+
+    @property
+    def ElemConn(self):
+        return self.L.tp_filter_stencil_width(self.handle)
+
+    def Hs(self):
+        hs = self.grid.elem_vec()
+        _chk(self.L.tp_filter_get_hs(self.handle, _ptr(hs)), "tp_filter_get_hs")
+        return hs
+
+    def FilterProject(self, x, xTilde, xPhys, projectionFilter=False, beta=0.1, eta=0.0):
+        """Filter.cc:60-117"""
+        _chk(self.L.tp_filter_project(self.handle, _ptr(x), _ptr(xTilde), _ptr(xPhys), int(projectionFilter), beta,
+                                      eta), "tp_filter_project")
+
+    def Gradients(self, x, xTilde, dfdx, dgdx, projectionFilter=False, beta=0.1, eta=0.0):
+        """Filter.cc:120-204; dgdx is a list of tensors (m constraints)"""
+        arr = (C.c_void_p * max(len(dgdx), 1))(*[_ptr(g) for g in dgdx])
+        _chk(self.L.tp_filter_gradients(self.handle, _ptr(x), _ptr(xTilde), _ptr(dfdx), len(dgdx), arr,
+                                        int(projectionFilter), beta, eta), "tp_filter_gradients")
+
+    def GetMND(self, x):
+        v = C.c_double()
+        _chk(self.L.tp_filter_mnd(self.handle, _ptr(x), C.byref(v)), "tp_filter_mnd")
+        return v.value
+
+    def last_pde_solve(self):
+        its, rn = C.c_int(), C.c_double()
+        self.L.tp_filter_last_pde_its(self.handle, C.byref(its), C.byref(rn))
+        return its.value, rn.value

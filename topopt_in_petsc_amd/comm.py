@@ -1,0 +1,123 @@
+"""z-slab neighbour exchange and scalar all-reduce through torch.distributed.
+
+One process per GPU.  With the `nccl` backend (= RCCL over xGMI on ROCm) the
+staging tensors are sent device-to-device; with `gloo` (CPU tests, or two ranks
+sharing one GPU in the 1-GPU parity test) they are staged through host memory.
+The HIP library calls back into `exchange` / `allreduce_sum`
+(include/topopt_amd.h: tp_comm); both are ordered on the current stream.
+
+The same class drives CPU tensors, which is what the world_size-2 gloo tests
+use to check the partition/halo logic without a GPU.
+"""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from . import lib as _lib
+
+
+class SlabComm:
+    def __init__(self, part, device, group=None, cap=None):
+        self.part = part
+        self.device = torch.device(device)
+        self.group = group
+        self.rank, self.nranks = part.rank, part.nranks
+        assert dist.is_initialized(), "torch.distributed must be initialised for nranks > 1"
+        self.backend = dist.get_backend(group)
+        # staging: large enough for one 3-dof node plane and a few filter layers
+        self.cap = int(cap or max(3 * part.plane, 4 * part.ex * part.ey))
+        mk = lambda n: torch.zeros(n, dtype=torch.float64, device=self.device)
+        self.send_lo, self.send_hi, self.recv_lo, self.recv_hi = mk(self.cap), mk(self.cap), mk(self.cap), mk(self.cap)
+        self.red = mk(16)
+        self.n_exchanges = 0
+        self.n_allreduces = 0
+        self.bytes_sent = 0
+        self._via_host = self.device.type == "cuda" and self.backend != "nccl"
+        # keep the callbacks alive for the lifetime of the object
+        self._ex_cb = _lib.EXCHANGE_FN(self._exchange_cb)
+        self._ar_cb = _lib.ALLREDUCE_FN(self._allreduce_cb)
+        p = lambda t: t.data_ptr()
+        self.c_struct = _lib.Comm(None, p(self.send_lo), p(self.send_hi), p(self.recv_lo), p(self.recv_hi),
+                                  p(self.red), self.cap, self._ex_cb, self._ar_cb)
+
+    # ---- python-level API (also used directly by the CPU tests) -----------
+    def exchange(self, n):
+        """send_lo[:n] -> rank-1, send_hi[:n] -> rank+1; recv_lo <- rank-1, recv_hi <- rank+1"""
+        lo, hi = self.rank - 1, self.rank + 1
+        has_lo, has_hi = lo >= 0, hi < self.nranks
+        if self._via_host:
+            s_lo, s_hi = self.send_lo[:n].cpu(), self.send_hi[:n].cpu()
+            r_lo, r_hi = torch.empty(n, dtype=torch.float64), torch.empty(n, dtype=torch.float64)
+        else:
+            s_lo, s_hi, r_lo, r_hi = self.send_lo[:n], self.send_hi[:n], self.recv_lo[:n], self.recv_hi[:n]
+        ops = []
+        if has_lo:
+            ops += [dist.P2POp(dist.isend, s_lo, self._g(lo), self.group), dist.P2POp(dist.irecv, r_lo, self._g(lo), self.group)]
+        if has_hi:
+            ops += [dist.P2POp(dist.isend, s_hi, self._g(hi), self.group), dist.P2POp(dist.irecv, r_hi, self._g(hi), self.group)]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        if self._via_host:
+            if has_lo:
+                self.recv_lo[:n].copy_(r_lo)
+            if has_hi:
+                self.recv_hi[:n].copy_(r_hi)
+        self.n_exchanges += 1
+        self.bytes_sent += 8 * n * (int(has_lo) + int(has_hi))
+
+    def allreduce_sum(self, n):
+        if self._via_host:
+            t = self.red[:n].cpu()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            self.red[:n].copy_(t)
+        else:
+            dist.all_reduce(self.red[:n], op=dist.ReduceOp.SUM, group=self.group)
+        self.n_allreduces += 1
+
+    def _g(self, r):
+        """group rank -> global rank"""
+        return r if self.group is None else dist.get_global_rank(self.group, r)
+
+    # ---- C callbacks --------------------------------------------------------
+    def _exchange_cb(self, _user, n):
+        try:
+            self.exchange(int(n))
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            print("SlabComm.exchange failed: %r" % (e,), flush=True)
+            return 1
+
+    def _allreduce_cb(self, _user, n):
+        try:
+            self.allreduce_sum(int(n))
+            return 0
+        except Exception as e:
+            print("SlabComm.allreduce_sum failed: %r" % (e,), flush=True)
+            return 1
+
+    # ---- host-side helpers on plain tensors (CPU or GPU) ----------------------
+    def halo_nodes(self, v, dof):
+        """refresh the ghost planes of a local node vector in place"""
+        p = self.part
+        pl = p.plane * dof
+        if self.nranks == 1:
+            return v
+        if p.has_lo:
+            self.send_lo[:pl].copy_(v[pl * p.own_lo: pl * (p.own_lo + 1)])
+        if p.has_hi:
+            self.send_hi[:pl].copy_(v[pl * p.own_hi: pl * (p.own_hi + 1)])
+        self.exchange(pl)
+        if p.has_lo:
+            v[:pl].copy_(self.recv_lo[:pl])
+        if p.has_hi:
+            v[pl * (p.nz_local - 1): pl * p.nz_local].copy_(self.recv_hi[:pl])
+        return v
+
+    def dot_owned(self, a, b, dof):
+        s = self.part.owned_slice(dof)
+        self.red[0] = torch.dot(a[s], b[s])
+        if self.nranks > 1:
+            self.allreduce_sum(1)
+        return float(self.red[0])

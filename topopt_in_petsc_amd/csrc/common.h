@@ -1,0 +1,151 @@
+// common.h -- shared definitions of the HIP hot path (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/topopt_amd.h"
+
+#define TP_HIP(x)                                              \
+    do {                                                       \
+        hipError_t e_ = (x);                                   \
+        if (e_ != hipSuccess) return TP_ERR_HIP + (int)e_;     \
+    } while (0)
+#define TP_TRY(x)              \
+    do {                       \
+        int r_ = (x);          \
+        if (r_) return r_;     \
+    } while (0)
+
+constexpr int WAVE = 64;     // CDNA wavefront
+constexpr int BLK  = 256;    // default workgroup: 4 waves, one per SIMD
+constexpr int MAX_RED_BLOCKS = 8192;
+
+// One multigrid level of the local z-slab.  Local node plane k <-> global plane
+// gz0 + k.  Element layer l spans node planes l, l+1.
+struct Geom {
+    int nx, ny, nzl;      // local node planes stored (own + ghosts)
+    int ex, ey;           // elements per row / column
+    int ez_own;           // own element layers [0, ez_own)
+    int ezl;              // element layers with data available locally (own + ghost above)
+    int own_lo, own_hi;   // owned node planes, inclusive
+    int gz0;              // global z index of local node plane 0
+    int nz_glob;          // global node planes on this level
+    int has_lo, has_hi;   // neighbour slabs
+    __host__ __device__ long plane() const { return (long)nx * ny; }
+    __host__ __device__ long nodes() const { return (long)nx * ny * nzl; }
+    __host__ __device__ long owned_nodes() const { return (long)nx * ny * (own_hi - own_lo + 1); }
+    __host__ __device__ long own_elems() const { return (long)ex * ey * ez_own; }
+    __host__ __device__ long elems_stored() const { return (long)ex * ey * ezl; }
+};
+
+// local corner offsets of the 8-node hexahedron, reference node order
+// (LinearElasticity.cc:819-826): counter-clockwise in the lower plane, then the upper.
+__device__ __constant__ int c_LX[8] = {0, 1, 1, 0, 0, 1, 1, 0};
+__device__ __constant__ int c_LY[8] = {0, 0, 1, 1, 0, 0, 1, 1};
+__device__ __constant__ int c_LZ[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+static const int h_LX[8] = {0, 1, 1, 0, 0, 1, 1, 0};
+static const int h_LY[8] = {0, 0, 1, 1, 0, 0, 1, 1};
+static const int h_LZ[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+// compile-time versions for fully unrolled loops
+__host__ __device__ constexpr int LXc(int a) { return (a == 1 || a == 2 || a == 5 || a == 6) ? 1 : 0; }
+__host__ __device__ constexpr int LYc(int a) { return (a == 2 || a == 3 || a == 6 || a == 7) ? 1 : 0; }
+__host__ __device__ constexpr int LZc(int a) { return a >= 4 ? 1 : 0; }
+// corner index from (lx,ly,lz)
+__host__ __device__ constexpr int corner_of(int lx, int ly, int lz) {
+    return lz * 4 + (ly ? (lx ? 2 : 3) : (lx ? 1 : 0));
+}
+
+// ---------------------------------------------------------------------------
+// deterministic reductions: wave shuffle -> LDS -> one partial per workgroup,
+// then a single-workgroup pass over the partials.  No atomics: run-to-run
+// bit-reproducible.
+// ---------------------------------------------------------------------------
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
+    return v;
+}
+
+// returns the block total in thread 0 (BLK threads)
+__device__ inline double block_sum(double v) {
+    __shared__ double s_part[BLK / WAVE];
+    v = wave_sum(v);
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    __syncthreads();  // protect s_part reuse across consecutive calls
+    if (lane == 0) s_part[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < BLK / WAVE; i++) t += s_part[i];
+    }
+    return t;
+}
+
+// partials laid out [value][block]; out[v] = sum_b partials[v*nblocks + b]
+template <int NV>
+__global__ __launch_bounds__(BLK) void k_reduce_final(const double *__restrict__ partials, int nblocks,
+                                                      double *__restrict__ out) {
+    for (int v = 0; v < NV; v++) {
+        double s = 0.0;
+        for (int b = threadIdx.x; b < nblocks; b += BLK) s += partials[(long)v * nblocks + b];
+        s = block_sum(s);
+        if (threadIdx.x == 0) out[v] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// BLAS-1 style kernels (grid-stride, coefficients read from device scalars so
+// that the Krylov loop needs no host round trip for them)
+// ---------------------------------------------------------------------------
+inline int grid_for(long n, int cap = 2048) {
+    long b = (n + BLK - 1) / BLK;
+    if (b < 1) b = 1;
+    return (int)(b > cap ? cap : b);
+}
+
+__global__ __launch_bounds__(BLK) void k_set(double *__restrict__ x, double a, long n) {
+    for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) x[i] = a;
+}
+__global__ __launch_bounds__(BLK) void k_scale(double *__restrict__ x, double a, long n) {
+    for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) x[i] *= a;
+}
+__global__ __launch_bounds__(BLK) void k_copy(double *__restrict__ y, const double *__restrict__ x, long n) {
+    for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) y[i] = x[i];
+}
+// y = a*x*z (pointwise), used by Lanczos scaling
+__global__ __launch_bounds__(BLK) void k_pw_mult(double *__restrict__ y, const double *__restrict__ x,
+                                                 const double *__restrict__ z, long n) {
+    for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) y[i] = x[i] * z[i];
+}
+// partial dot products: partials[0*nb+b] = sum a*b
+__global__ __launch_bounds__(BLK) void k_dot(const double *__restrict__ a, const double *__restrict__ b, long n,
+                                             double *__restrict__ partials) {
+    double s = 0.0;
+    for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) s += a[i] * b[i];
+    s = block_sum(s);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(BLK) void k_sum(const double *__restrict__ a, long n, double *__restrict__ partials) {
+    double s = 0.0;
+    for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) s += a[i];
+    s = block_sum(s);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// splitmix64 -> [0,1): the synthetic-field generator of SURVEY.md 8(d)
+__host__ __device__ inline double hash_u01(uint64_t idx, uint64_t seed) {
+    uint64_t z = (idx + 1u) * 0x9E3779B97F4A7C15ULL + seed;
+    z ^= z >> 30;
+    z *= 0xBF58476D1CE4E5B9ULL;
+    z ^= z >> 27;
+    z *= 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}

@@ -1,0 +1,116 @@
+// grid.h -- z-slab partition, halo exchange through the host framework's
+// collectives, deterministic reductions with device-resident results.
+#pragma once
+#include "common.h"
+
+struct tp_grid {
+    tp_grid_opts o;
+    hipStream_t stream;
+    tp_comm comm;
+    bool has_comm;
+    int ex, ey, ez_glob, ez_own;  // fine level element counts
+    int rank, nranks;
+    double *partials;   // [dev] MAX_RED_BLOCKS * 4
+    double *scal;       // [dev] 64 device scalars
+    double *h_scal;     // pinned host mirror
+    // accounting (algorithmic model)
+    double alg_bytes, flops;
+    long launches;
+};
+
+// geometry of multigrid level `l` of this rank's slab
+inline Geom make_geom(const tp_grid *g, int l) {
+    Geom q;
+    q.ex = g->ex >> l;
+    q.ey = g->ey >> l;
+    q.nx = q.ex + 1;
+    q.ny = q.ey + 1;
+    q.ez_own = g->ez_own >> l;
+    q.has_lo = g->rank > 0;
+    q.has_hi = g->rank < g->nranks - 1;
+    q.ezl = q.ez_own + q.has_hi;
+    q.nzl = q.ez_own + 1 + q.has_hi;
+    q.own_lo = q.has_lo ? 1 : 0;
+    q.own_hi = q.ez_own;
+    q.gz0 = g->rank * q.ez_own;
+    q.nz_glob = (g->ez_glob >> l) + 1;
+    return q;
+}
+
+inline void count_launch(tp_grid *g, double bytes = 0.0, double flops = 0.0) {
+    g->launches++;
+    g->alg_bytes += bytes;
+    g->flops += flops;
+}
+
+// out = scal[slot .. slot+NV): block partials -> one value each, then summed over ranks
+template <int NV>
+inline int finish_reduction(tp_grid *g, int nblocks, int slot) {
+    hipLaunchKernelGGL(k_reduce_final<NV>, dim3(1), dim3(BLK), 0, g->stream, g->partials, nblocks, g->scal + slot);
+    count_launch(g);
+    if (g->has_comm) {
+        TP_HIP(hipMemcpyAsync(g->comm.red, g->scal + slot, sizeof(double) * NV, hipMemcpyDeviceToDevice, g->stream));
+        if (g->comm.allreduce_sum(g->comm.user, NV)) return TP_ERR_COMM;
+        TP_HIP(hipMemcpyAsync(g->scal + slot, g->comm.red, sizeof(double) * NV, hipMemcpyDeviceToDevice, g->stream));
+    }
+    return TP_OK;
+}
+
+// blocking read of device scalars (the only host synchronisation of the Krylov loop)
+inline int read_scal(tp_grid *g, int slot, int n, double *out) {
+    TP_HIP(hipMemcpyAsync(g->h_scal, g->scal + slot, sizeof(double) * n, hipMemcpyDeviceToHost, g->stream));
+    TP_HIP(hipStreamSynchronize(g->stream));
+    for (int i = 0; i < n; i++) out[i] = g->h_scal[i];
+    return TP_OK;
+}
+
+inline int dot_to_slot(tp_grid *g, const double *a, const double *b, long n, int slot) {
+    int nb = grid_for(n, MAX_RED_BLOCKS);
+    hipLaunchKernelGGL(k_dot, dim3(nb), dim3(BLK), 0, g->stream, a, b, n, g->partials);
+    count_launch(g, 16.0 * n, 2.0 * n);
+    return finish_reduction<1>(g, nb, slot);
+}
+inline int sum_to_slot(tp_grid *g, const double *a, long n, int slot) {
+    int nb = grid_for(n, MAX_RED_BLOCKS);
+    hipLaunchKernelGGL(k_sum, dim3(nb), dim3(BLK), 0, g->stream, a, n, g->partials);
+    count_launch(g, 8.0 * n, 1.0 * n);
+    return finish_reduction<1>(g, nb, slot);
+}
+
+// Generic neighbour exchange of `rows` segments of `seg` doubles each (pitch in
+// doubles), through the framework-owned staging buffers:
+//   to_lo   -> rank-1 (arrives there as from_hi),  to_hi -> rank+1 (arrives as from_lo).
+// Any of the four pointers may be NULL.  Stream ordered.
+inline int exchange_segments(tp_grid *g, const double *to_lo, double *from_lo, const double *to_hi, double *from_hi,
+                             long seg, long rows, long pitch) {
+    if (!g->has_comm || seg <= 0 || rows <= 0) return TP_OK;
+    const tp_comm &c = g->comm;
+    long rows_per = c.cap / seg;
+    if (rows_per < 1) return TP_ERR_ARG;
+    for (long r0 = 0; r0 < rows; r0 += rows_per) {
+        long nr = rows - r0 < rows_per ? rows - r0 : rows_per;
+        if (to_lo && g->rank > 0)
+            TP_HIP(hipMemcpy2DAsync(c.send_lo, seg * 8, to_lo + r0 * pitch, pitch * 8, seg * 8, nr,
+                                    hipMemcpyDeviceToDevice, g->stream));
+        if (to_hi && g->rank < g->nranks - 1)
+            TP_HIP(hipMemcpy2DAsync(c.send_hi, seg * 8, to_hi + r0 * pitch, pitch * 8, seg * 8, nr,
+                                    hipMemcpyDeviceToDevice, g->stream));
+        if (c.exchange(c.user, seg * nr)) return TP_ERR_COMM;
+        if (from_lo && g->rank > 0)
+            TP_HIP(hipMemcpy2DAsync(from_lo + r0 * pitch, pitch * 8, c.recv_lo, seg * 8, seg * 8, nr,
+                                    hipMemcpyDeviceToDevice, g->stream));
+        if (from_hi && g->rank < g->nranks - 1)
+            TP_HIP(hipMemcpy2DAsync(from_hi + r0 * pitch, pitch * 8, c.recv_hi, seg * 8, seg * 8, nr,
+                                    hipMemcpyDeviceToDevice, g->stream));
+    }
+    return TP_OK;
+}
+
+// refresh the ghost node planes of a level vector (DMGlobalToLocalBegin/End,
+// LinearElasticity.cc:249-250): own bottom plane -> lower neighbour's top ghost,
+// own top plane -> upper neighbour's bottom ghost.
+inline int halo_nodes(tp_grid *g, const Geom &q, double *v, int dof) {
+    if (!g->has_comm) return TP_OK;
+    long pl = q.plane() * dof;
+    return exchange_segments(g, v + pl * q.own_lo, v /*plane 0*/, v + pl * q.own_hi, v + pl * (q.nzl - 1), pl, 1, pl);
+}

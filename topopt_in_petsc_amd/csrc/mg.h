@@ -1,0 +1,449 @@
+// mg.h -- CG preconditioned by a geometric-multigrid V-cycle with
+// Chebyshev-Jacobi smoothing, for DOF unknowns per node (3 = elasticity,
+// 1 = Helmholtz filter).  Replaces KSPSolve(KSPCG) + PCApply_MG + the level
+// KSPCHEBYSHEV/PCJACOBI smoothers the reference reaches through PETSc
+// (LinearElasticity.cc:617-746, PDEFilter.cc:269-417).
+#pragma once
+#include "galerkin.h"
+#include "grid.h"
+#include "operators.h"
+
+enum { LV_MATFREE = 0, LV_DIA = 1 };
+
+template <int DOF>
+struct Level {
+    Geom g;
+    int kind;
+    // matrix-free levels
+    const double *KE;       // [dev] (8 DOF)^2
+    const double *E;        // [dev] per stored element, or null
+    const uint8_t *mask;    // [dev] per node, or null
+    // stencil levels
+    double *S;              // [dev] 27*DOF diagonals x (DOF*nodes)
+    double *Kel;            // [dev] coarse element matrices (DOF = 3 Galerkin levels)
+    double *dinv;
+    double lam;             // estimate / bound of lambda_max(D^-1 A)
+    double *b, *x, *x2, *r, *d;
+    long ndof() const { return (long)DOF * g.nodes(); }
+    long own_off() const { return (long)DOF * g.plane() * g.own_lo; }
+    long own_n() const { return (long)DOF * g.owned_nodes(); }
+};
+
+// CG scalar slots in tp_grid::scal
+enum { S_BB = 0, S_RR = 1, S_PW = 2, S_RZ0 = 3, S_RZ1 = 4, S_TMP = 8 };
+
+__global__ __launch_bounds__(BLK) void k_cg_update_xr(double *__restrict__ x, double *__restrict__ r,
+                                                      const double *__restrict__ p, const double *__restrict__ w,
+                                                      const double *__restrict__ scal, int slot_rz, long off, long n,
+                                                      double *__restrict__ partials) {
+    const double alpha = scal[slot_rz] / scal[S_PW];
+    double s = 0.0;
+    for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
+        const long q = off + i;
+        x[q] = fma(alpha, p[q], x[q]);
+        const double rn = fma(-alpha, w[q], r[q]);
+        r[q] = rn;
+        s = fma(rn, rn, s);
+    }
+    s = block_sum(s);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+// p = z + (rz_new/rz_old) p   (first: p = z)
+__global__ __launch_bounds__(BLK) void k_cg_update_p(double *__restrict__ p, const double *__restrict__ z,
+                                                     const double *__restrict__ scal, int slot_new, int slot_old,
+                                                     int first, long off, long n) {
+    const double beta = first ? 0.0 : scal[slot_new] / scal[slot_old];
+    for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
+        const long q = off + i;
+        p[q] = first ? z[q] : fma(beta, p[q], z[q]);
+    }
+}
+// two dot products in one pass: partials[b] = a1.b1, partials[nb + b] = a2.b2
+__global__ __launch_bounds__(BLK) void k_dot2(const double *__restrict__ a1, const double *__restrict__ b1,
+                                              const double *__restrict__ a2, const double *__restrict__ b2, long off,
+                                              long n, double *__restrict__ partials) {
+    double s1 = 0.0, s2 = 0.0;
+    for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
+        s1 = fma(a1[off + i], b1[off + i], s1);
+        s2 = fma(a2[off + i], b2[off + i], s2);
+    }
+    s1 = block_sum(s1);
+    s2 = block_sum(s2);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = s1;
+        partials[gridDim.x + blockIdx.x] = s2;
+    }
+}
+
+// Lanczos helpers (owned range)
+template <int DOF>
+__global__ __launch_bounds__(BLK) void k_lanczos_init(Geom g, double *__restrict__ v, double *__restrict__ dis,
+                                                      const double *__restrict__ dinv) {
+    const long plane = g.plane();
+    const long t = blockIdx.x * (long)BLK + threadIdx.x;
+    if (t >= g.owned_nodes()) return;
+    const long n = t + plane * g.own_lo;
+    const uint64_t gn = (uint64_t)(n + plane * (long)g.gz0);  // global node id
+#pragma unroll
+    for (int c = 0; c < DOF; c++) {
+        v[n * DOF + c] = hash_u01(gn * DOF + c, 0x5eedULL) - 0.5;
+        dis[n * DOF + c] = sqrt(dinv[n * DOF + c]);
+    }
+}
+// w = dis*w - beta*vp ; partial w.v
+__global__ __launch_bounds__(BLK) void k_lanczos_a(double *__restrict__ w, const double *__restrict__ dis,
+                                                   const double *__restrict__ vp, const double *__restrict__ v,
+                                                   double beta, long off, long n, double *__restrict__ partials) {
+    double s = 0.0;
+    for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
+        const long q = off + i;
+        const double wn = dis[q] * w[q] - beta * vp[q];
+        w[q] = wn;
+        s = fma(wn, v[q], s);
+    }
+    s = block_sum(s);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+// w -= alpha v ; partial w.w
+__global__ __launch_bounds__(BLK) void k_lanczos_b(double *__restrict__ w, const double *__restrict__ v, double alpha,
+                                                   long off, long n, double *__restrict__ partials) {
+    double s = 0.0;
+    for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
+        const long q = off + i;
+        const double wn = w[q] - alpha * v[q];
+        w[q] = wn;
+        s = fma(wn, wn, s);
+    }
+    s = block_sum(s);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+// vp = v ; v = w / beta
+__global__ __launch_bounds__(BLK) void k_lanczos_c(double *__restrict__ vp, double *__restrict__ v,
+                                                   const double *__restrict__ w, double inv_beta, long off, long n) {
+    for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
+        const long q = off + i;
+        vp[q] = v[q];
+        v[q] = w[q] * inv_beta;
+    }
+}
+
+// largest eigenvalue of a symmetric tridiagonal matrix, Sturm bisection
+inline double tridiag_lmax(int m, const double *a, const double *b) {
+    double lo = a[0], hi = a[0];
+    for (int i = 0; i < m; i++) {
+        double rad = (i > 0 ? fabs(b[i - 1]) : 0.0) + (i < m - 1 ? fabs(b[i]) : 0.0);
+        lo = fmin(lo, a[i] - rad);
+        hi = fmax(hi, a[i] + rad);
+    }
+    for (int it = 0; it < 200; it++) {
+        double mid = 0.5 * (lo + hi);
+        if (mid == lo || mid == hi) break;
+        int cnt = 0;
+        double q = a[0] - mid;
+        if (q < 0) cnt++;
+        for (int i = 1; i < m; i++) {
+            double den = (fabs(q) < 1e-300) ? 1e-300 : q;
+            q = a[i] - mid - b[i - 1] * b[i - 1] / den;
+            if (q < 0) cnt++;
+        }
+        if (cnt >= m) hi = mid;
+        else lo = mid;
+    }
+    return 0.5 * (lo + hi);
+}
+
+// lambda_max(diag(KE)^-1 KE) by cyclic Jacobi rotations (n <= 24): the rigorous,
+// density-independent Chebyshev bound of the matrix-free level
+inline double elem_lambda_bound(int n, const double *KE) {
+    std::vector<double> S((size_t)n * n);
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) S[i * n + j] = 0.5 * (KE[i * n + j] + KE[j * n + i]) / sqrt(KE[i * n + i] * KE[j * n + j]);
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0.0;
+        for (int p = 0; p < n; p++)
+            for (int q = p + 1; q < n; q++) off += S[p * n + q] * S[p * n + q];
+        if (off < 1e-30) break;
+        for (int p = 0; p < n; p++)
+            for (int q = p + 1; q < n; q++) {
+                double apq = S[p * n + q];
+                if (fabs(apq) < 1e-300) continue;
+                double th = (S[q * n + q] - S[p * n + p]) / (2.0 * apq);
+                double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+                double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; k++) {
+                    double akp = S[k * n + p], akq = S[k * n + q];
+                    S[k * n + p] = c * akp - s * akq;
+                    S[k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; k++) {
+                    double apk = S[p * n + k], aqk = S[q * n + k];
+                    S[p * n + k] = c * apk - s * aqk;
+                    S[q * n + k] = s * apk + c * aqk;
+                }
+            }
+    }
+    double l = S[0];
+    for (int i = 1; i < n; i++) l = fmax(l, S[i * n + i]);
+    return l;
+}
+
+template <int DOF>
+struct MGSolver {
+    tp_grid *grid = nullptr;
+    int nlv = 0;
+    Level<DOF> lv[TP_MAX_LEVELS];
+    tp_solver_opts opt;
+    double *cg_r = nullptr, *cg_p = nullptr, *cg_w = nullptr;
+    bool ready = false;
+
+    int alloc_levels() {
+        for (int l = 0; l < nlv; l++) {
+            Level<DOF> &L = lv[l];
+            L.g = make_geom(grid, l);
+            size_t nb = sizeof(double) * (size_t)L.ndof();
+            for (double **p : {&L.b, &L.x, &L.x2, &L.r, &L.d, &L.dinv}) {
+                TP_HIP(hipMalloc((void **)p, nb));
+                TP_HIP(hipMemsetAsync(*p, 0, nb, grid->stream));
+            }
+        }
+        size_t nb = sizeof(double) * (size_t)lv[0].ndof();
+        for (double **p : {&cg_r, &cg_p, &cg_w}) {
+            TP_HIP(hipMalloc((void **)p, nb));
+            TP_HIP(hipMemsetAsync(*p, 0, nb, grid->stream));
+        }
+        return TP_OK;
+    }
+    void free_levels() {
+        for (int l = 0; l < nlv; l++) {
+            Level<DOF> &L = lv[l];
+            for (double *p : {L.b, L.x, L.x2, L.r, L.d, L.dinv, L.S, L.Kel}) (void)hipFree(p);
+        }
+        for (double *p : {cg_r, cg_p, cg_w}) (void)hipFree(p);
+    }
+
+    // ---- operator application with one of the epilogues -------------------
+    template <int EPI>
+    int op(int l, NodeArgs a) {
+        Level<DOF> &L = lv[l];
+        const long nown = L.g.owned_nodes();
+        const int nb = (int)((nown + BLK - 1) / BLK);
+        double bytes, flops;
+        if (L.kind == LV_MATFREE) {
+            MatfreeOp<DOF> o{L.KE, L.E, L.mask, L.g};
+            hipLaunchKernelGGL((k_node<DOF, MatfreeOp<DOF>, EPI>), dim3(nb), dim3(BLK), 0, grid->stream, o, a);
+            bytes = 16.0 * DOF * nown + (L.E ? 8.0 * L.g.own_elems() : 0.0);
+            flops = 2.0 * (8 * DOF) * (8 * DOF) * (double)L.g.own_elems();
+        } else {
+            DiaOp<DOF> o{L.S, L.ndof(), L.g};
+            hipLaunchKernelGGL((k_node<DOF, DiaOp<DOF>, EPI>), dim3(nb), dim3(BLK), 0, grid->stream, o, a);
+            bytes = (27.0 * DOF * DOF + 2.0 * DOF) * 8.0 * nown;
+            flops = 2.0 * 27 * DOF * DOF * (double)nown;
+        }
+        if (EPI == EPI_RESID) bytes += 8.0 * DOF * nown;
+        if (EPI == EPI_CHEB) bytes += 4.0 * 8.0 * DOF * nown;
+        count_launch(grid, bytes, flops);
+        return TP_OK;
+    }
+    int halo(int l, double *v) { return halo_nodes(grid, lv[l].g, v, DOF); }
+
+    // y = A_l u (ghost planes of u refreshed first)
+    int apply(int l, double *u, double *y) {
+        TP_TRY(halo(l, u));
+        NodeArgs a{};
+        a.x = u;
+        a.out = y;
+        return op<EPI_APPLY>(l, a);
+    }
+
+    // Chebyshev(k)-Jacobi; the iterate ping-pongs between L.x and L.x2, on exit L.x holds it
+    int smooth(int l, const double *b, int k, bool zero_guess) {
+        Level<DOF> &L = lv[l];
+        const double lmin = opt.cheb_lo * L.lam, lmax = opt.cheb_hi * L.lam;
+        const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+        double rho = 1.0 / sigma;
+        int it = 0;
+        if (zero_guess) {
+            hipLaunchKernelGGL(k_cheb_first, dim3(grid_for(L.own_n())), dim3(BLK), 0, grid->stream, L.x, L.d, b, L.dinv,
+                               1.0 / theta, L.own_off(), L.own_n());
+            count_launch(grid, 32.0 * L.own_n(), 2.0 * L.own_n());
+            it = 1;
+        }
+        for (; it < k; it++) {
+            NodeArgs a{};
+            a.x = L.x;
+            a.out = L.x2;
+            a.b = b;
+            a.d = L.d;
+            a.dinv = L.dinv;
+            if (it == 0) {
+                a.c1 = 0.0;
+                a.c2 = 1.0 / theta;
+            } else {
+                const double rn = 1.0 / (2.0 * sigma - rho);
+                a.c1 = rn * rho;
+                a.c2 = 2.0 * rn / delta;
+                rho = rn;
+            }
+            TP_TRY(halo(l, L.x));
+            TP_TRY(op<EPI_CHEB>(l, a));
+            std::swap(L.x, L.x2);
+        }
+        return TP_OK;
+    }
+
+    // PCMG multiplicative V-cycle with zero initial guesses; result in lv[l].x
+    int vcycle(int l, const double *b) {
+        Level<DOF> &L = lv[l];
+        if (l == nlv - 1) return smooth(l, b, opt.ncoarse, true);
+        TP_TRY(smooth(l, b, opt.nsmooth, true));
+        {
+            NodeArgs a{};
+            a.x = L.x;
+            a.out = L.r;
+            a.b = b;
+            TP_TRY(halo(l, L.x));
+            TP_TRY(op<EPI_RESID>(l, a));
+        }
+        Level<DOF> &C = lv[l + 1];
+        TP_TRY(halo(l, L.r));
+        hipLaunchKernelGGL((k_restrict<DOF>), dim3((int)((C.g.owned_nodes() + BLK - 1) / BLK)), dim3(BLK), 0,
+                           grid->stream, C.g, L.g, L.r, C.b);
+        count_launch(grid, 8.0 * DOF * (L.g.owned_nodes() + C.g.owned_nodes()), 2.0 * 27 * DOF * C.g.owned_nodes());
+        TP_TRY(vcycle(l + 1, C.b));
+        TP_TRY(halo(l + 1, C.x));
+        hipLaunchKernelGGL((k_prolong_add<DOF>), dim3((int)((L.g.owned_nodes() + BLK - 1) / BLK)), dim3(BLK), 0,
+                           grid->stream, C.g, L.g, C.x, L.x);
+        count_launch(grid, 8.0 * DOF * (2 * L.g.owned_nodes() + C.g.owned_nodes()), 2.0 * 8 * DOF * L.g.owned_nodes());
+        return smooth(l, b, opt.nsmooth, false);
+    }
+
+    // Jacobi diagonal + Chebyshev bound of a matrix-free level
+    int setup_matfree_level(int l, const double *h_KE) {
+        Level<DOF> &L = lv[l];
+        MatfreeOp<DOF> o{L.KE, L.E, L.mask, L.g};
+        hipLaunchKernelGGL((k_matfree_diag<DOF>), dim3((int)((L.g.owned_nodes() + BLK - 1) / BLK)), dim3(BLK), 0,
+                           grid->stream, o, L.dinv);
+        count_launch(grid, 8.0 * DOF * L.g.owned_nodes() + 8.0 * L.g.own_elems(), 16.0 * DOF * L.g.owned_nodes());
+        if (l == 0) {
+            double lb = elem_lambda_bound(8 * DOF, h_KE);
+            L.lam = lb > 1.0 ? lb : 1.0;
+        }
+        return TP_OK;
+    }
+
+    // largest Ritz value of `steps` Lanczos iterations on D^-1/2 A D^-1/2
+    int lanczos(int l, int steps, double *lam_out) {
+        Level<DOF> &L = lv[l];
+        double *v = L.b, *vp = L.r, *w = L.d, *t = L.x, *dis = L.x2;
+        const long off = L.own_off(), n = L.own_n();
+        const int nb = grid_for(n, MAX_RED_BLOCKS);
+        const int gn = (int)((L.g.owned_nodes() + BLK - 1) / BLK);
+        hipStream_t s = grid->stream;
+        TP_HIP(hipMemsetAsync(vp, 0, sizeof(double) * (size_t)L.ndof(), s));
+        hipLaunchKernelGGL((k_lanczos_init<DOF>), dim3(gn), dim3(BLK), 0, s, L.g, v, dis, L.dinv);
+        TP_TRY(dot_to_slot(grid, v + off, v + off, n, S_TMP));
+        double nv2;
+        TP_TRY(read_scal(grid, S_TMP, 1, &nv2));
+        hipLaunchKernelGGL(k_scale, dim3(grid_for(n)), dim3(BLK), 0, s, v + off, 1.0 / sqrt(nv2), n);
+        double al[64], be[64], beta = 0.0;
+        int m = 0;
+        if (steps > 64) steps = 64;
+        for (int j = 0; j < steps; j++) {
+            hipLaunchKernelGGL(k_pw_mult, dim3(grid_for(n)), dim3(BLK), 0, s, t + off, dis + off, v + off, n);
+            TP_TRY(apply(l, t, w));
+            hipLaunchKernelGGL(k_lanczos_a, dim3(nb), dim3(BLK), 0, s, w, dis, vp, v, beta, off, n, grid->partials);
+            TP_TRY(finish_reduction<1>(grid, nb, S_TMP));
+            double alpha;
+            TP_TRY(read_scal(grid, S_TMP, 1, &alpha));
+            hipLaunchKernelGGL(k_lanczos_b, dim3(nb), dim3(BLK), 0, s, w, v, alpha, off, n, grid->partials);
+            TP_TRY(finish_reduction<1>(grid, nb, S_TMP));
+            double b2;
+            TP_TRY(read_scal(grid, S_TMP, 1, &b2));
+            beta = sqrt(b2);
+            al[m] = alpha;
+            be[m] = beta;
+            m++;
+            if (beta < 1e-14 * fabs(alpha)) break;
+            hipLaunchKernelGGL(k_lanczos_c, dim3(grid_for(n)), dim3(BLK), 0, s, vp, v, w, 1.0 / beta, off, n);
+            grid->launches += 4;
+        }
+        *lam_out = tridiag_lmax(m, al, be);
+        return TP_OK;
+    }
+
+    // z = M r : one V-cycle.  Returns the pointer holding z (lv[0].x).
+    int precond(const double *r, double **z) {
+        TP_TRY(vcycle(0, r));
+        *z = lv[0].x;
+        return TP_OK;
+    }
+
+    // KSPSolve, KSPCG with the unpreconditioned norm, reference norm ||b||
+    // (KSPConvergedDefault with a nonzero initial guess)
+    int solve(const double *b, double *x, int *its_out, double *rnorm_out, double *bnorm_out, double *hist,
+              int hist_cap) {
+        if (!ready) return TP_ERR_STATE;
+        Level<DOF> &L = lv[0];
+        hipStream_t s = grid->stream;
+        const long off = L.own_off(), n = L.own_n();
+        const int nb = grid_for(n, MAX_RED_BLOCKS);
+        double *r = cg_r, *p = cg_p, *w = cg_w;
+        {
+            NodeArgs a{};
+            a.x = x;
+            a.out = r;
+            a.b = b;
+            TP_TRY(halo(0, x));
+            TP_TRY(op<EPI_RESID>(0, a));
+        }
+        hipLaunchKernelGGL(k_dot2, dim3(nb), dim3(BLK), 0, s, b, b, r, r, off, n, grid->partials);
+        count_launch(grid, 16.0 * n, 4.0 * n);
+        TP_TRY(finish_reduction<2>(grid, nb, S_BB));
+        double v2[2];
+        TP_TRY(read_scal(grid, S_BB, 2, v2));
+        const double bnorm = sqrt(v2[0]);
+        double rnorm = sqrt(v2[1]);
+        const double ttol = fmax(opt.rtol * bnorm, opt.atol);
+        if (bnorm_out) *bnorm_out = bnorm;
+        if (hist && hist_cap > 0) hist[0] = rnorm;
+        int its = 0, rc = TP_OK;
+        int rz_cur = S_RZ0, rz_old = S_RZ1;
+        if (rnorm > ttol) {
+            for (its = 1; its <= opt.max_it; its++) {
+                double *z;
+                TP_TRY(precond(r, &z));
+                TP_TRY(dot_to_slot(grid, r + off, z + off, n, rz_cur));
+                hipLaunchKernelGGL(k_cg_update_p, dim3(grid_for(n)), dim3(BLK), 0, s, p, z, grid->scal, rz_cur, rz_old,
+                                   its == 1 ? 1 : 0, off, n);
+                count_launch(grid, 24.0 * n, 2.0 * n);
+                {
+                    NodeArgs a{};
+                    a.x = p;
+                    a.out = w;
+                    a.partials = grid->partials;
+                    TP_TRY(halo(0, p));
+                    TP_TRY(op<EPI_APPLY_DOT>(0, a));
+                    TP_TRY(finish_reduction<1>(grid, (int)((L.g.owned_nodes() + BLK - 1) / BLK), S_PW));
+                }
+                hipLaunchKernelGGL(k_cg_update_xr, dim3(nb), dim3(BLK), 0, s, x, r, p, w, grid->scal, rz_cur, off, n,
+                                   grid->partials);
+                count_launch(grid, 48.0 * n, 6.0 * n);
+                TP_TRY(finish_reduction<1>(grid, nb, S_RR));
+                double rr;
+                TP_TRY(read_scal(grid, S_RR, 1, &rr));
+                rnorm = sqrt(rr);
+                if (hist && its < hist_cap) hist[its] = rnorm;
+                if (rnorm <= ttol) break;
+                if (!(rnorm <= opt.dtol * bnorm)) {  // also catches NaN
+                    rc = TP_ERR_DIVERGED;
+                    break;
+                }
+                if (its == opt.max_it) break;
+                std::swap(rz_cur, rz_old);
+            }
+        }
+        if (its_out) *its_out = its;
+        if (rnorm_out) *rnorm_out = rnorm;
+        return rc;
+    }
+};

@@ -1,0 +1,259 @@
+// operators.h -- level operators and the node-centric kernels built on them.
+//
+// Two operator kinds (both applied by GATHER, one thread per node, no atomics,
+// coalesced stores, bitwise reproducible):
+//   MatfreeOp<DOF>: y_i = sum over the <=8 elements around node i of
+//                   E_e * KE[rows of i] * (N u)_e, then the Dirichlet rows
+//                   y = N y + (I-N) u           (LinearElasticity.cc:510-542)
+//   DiaOp<DOF>    : 27-point block stencil stored by diagonals (Galerkin levels)
+#pragma once
+#include "common.h"
+
+// ---------------------------------------------------------------------------
+template <int DOF>
+struct MatfreeOp {
+    const double *__restrict__ KE;      // (8*DOF)^2, row major, wave-uniform -> scalar loads
+    const double *__restrict__ E;       // per stored element scale, or nullptr (== 1)
+    const uint8_t *__restrict__ mask;   // per node: bit c set = dof c clamped; or nullptr
+    Geom g;
+
+    __device__ inline void load_masked(const double *__restrict__ u, long nb, double ub[DOF]) const {
+#pragma unroll
+        for (int c = 0; c < DOF; c++) ub[c] = u[nb * DOF + c];
+        if (mask) {
+            const unsigned m = mask[nb];
+#pragma unroll
+            for (int c = 0; c < DOF; c++)
+                if ((m >> c) & 1u) ub[c] = 0.0;
+        }
+    }
+
+    __device__ inline void apply(const double *__restrict__ u, int i, int j, int k, long n, double y[DOF]) const {
+        constexpr int ED = 8 * DOF;
+#pragma unroll
+        for (int r = 0; r < DOF; r++) y[r] = 0.0;
+        // this node is local corner `a` of the element at (i-LX[a], j-LY[a], k-LZ[a])
+#pragma unroll
+        for (int a = 0; a < 8; a++) {
+            const int ei = i - LXc(a), ej = j - LYc(a), ek = k - LZc(a);
+            if (ei < 0 || ei >= g.ex || ej < 0 || ej >= g.ey || ek < 0 || ek >= g.ezl) continue;
+            const double Ee = E ? E[(long)ei + (long)g.ex * (ej + (long)g.ey * ek)] : 1.0;
+            double s[DOF];
+#pragma unroll
+            for (int r = 0; r < DOF; r++) s[r] = 0.0;
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const long nb = (long)(ei + LXc(b)) + (long)g.nx * ((ej + LYc(b)) + (long)g.ny * (ek + LZc(b)));
+                double ub[DOF];
+                load_masked(u, nb, ub);
+#pragma unroll
+                for (int r = 0; r < DOF; r++)
+#pragma unroll
+                    for (int c = 0; c < DOF; c++) s[r] = fma(KE[(a * DOF + r) * ED + b * DOF + c], ub[c], s[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < DOF; r++) y[r] = fma(Ee, s[r], y[r]);
+        }
+        if (mask) {
+            const unsigned m = mask[n];
+#pragma unroll
+            for (int r = 0; r < DOF; r++)
+                if ((m >> r) & 1u) y[r] = u[n * DOF + r];
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------
+// Block 27-point stencil by diagonals: S[(blk*DOF + c) * nrows + row],
+// row = node*DOF + r, blk = (dk+1)*9 + (dj+1)*3 + (di+1), column dof c.
+template <int DOF>
+struct DiaOp {
+    const double *__restrict__ S;
+    long nrows;  // DOF * local nodes
+    Geom g;
+
+    __device__ inline void apply(const double *__restrict__ u, int i, int j, int k, long n, double y[DOF]) const {
+#pragma unroll
+        for (int r = 0; r < DOF; r++) y[r] = 0.0;
+#pragma unroll
+        for (int dk = -1; dk <= 1; dk++) {
+            if (k + dk < 0 || k + dk >= g.nzl) continue;
+#pragma unroll
+            for (int dj = -1; dj <= 1; dj++) {
+                if (j + dj < 0 || j + dj >= g.ny) continue;
+#pragma unroll
+                for (int di = -1; di <= 1; di++) {
+                    if (i + di < 0 || i + di >= g.nx) continue;
+                    const int blk = (dk + 1) * 9 + (dj + 1) * 3 + (di + 1);
+                    const long nb = n + di + (long)g.nx * (dj + (long)g.ny * dk);
+#pragma unroll
+                    for (int c = 0; c < DOF; c++) {
+                        const double uc = u[nb * DOF + c];
+                        const double *__restrict__ Sd = S + (long)(blk * DOF + c) * nrows + n * DOF;
+#pragma unroll
+                        for (int r = 0; r < DOF; r++) y[r] = fma(Sd[r], uc, y[r]);
+                    }
+                }
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------
+// epilogues of the node kernel
+enum { EPI_APPLY = 0, EPI_RESID = 1, EPI_CHEB = 2, EPI_APPLY_DOT = 3 };
+
+struct NodeArgs {
+    const double *x;     // operator input
+    double *out;         // APPLY: y | RESID: r | CHEB: x_out | APPLY_DOT: w
+    const double *b;     // RESID, CHEB
+    double *d;           // CHEB direction (in/out)
+    const double *dinv;  // CHEB Jacobi
+    double c1, c2;       // CHEB recurrence coefficients
+    double *partials;    // APPLY_DOT: per-block partial of x . (A x)
+};
+
+template <int DOF, class Op, int EPI>
+__global__ __launch_bounds__(BLK) void k_node(Op op, NodeArgs a) {
+    const Geom &g = op.g;
+    const long plane = g.plane();
+    const long t = blockIdx.x * (long)BLK + threadIdx.x;
+    double pdot = 0.0;
+    if (t < g.owned_nodes()) {
+        const int k = g.own_lo + (int)(t / plane);
+        const int rem = (int)(t % plane);
+        const int j = rem / g.nx, i = rem % g.nx;
+        const long n = t + plane * g.own_lo;
+        double y[DOF];
+        op.apply(a.x, i, j, k, n, y);
+#pragma unroll
+        for (int r = 0; r < DOF; r++) {
+            const long q = n * DOF + r;
+            if (EPI == EPI_APPLY) {
+                a.out[q] = y[r];
+            } else if (EPI == EPI_RESID) {
+                a.out[q] = a.b[q] - y[r];
+            } else if (EPI == EPI_CHEB) {
+                const double res = a.b[q] - y[r];
+                const double dn = a.c1 * a.d[q] + a.c2 * (a.dinv[q] * res);
+                a.d[q] = dn;
+                a.out[q] = a.x[q] + dn;
+            } else {
+                a.out[q] = y[r];
+                pdot = fma(a.x[q], y[r], pdot);
+            }
+        }
+    }
+    if (EPI == EPI_APPLY_DOT) {
+        pdot = block_sum(pdot);
+        if (threadIdx.x == 0) a.partials[blockIdx.x] = pdot;
+    }
+}
+
+// first Chebyshev step with a zero initial guess: d = dinv*b/theta, x = d (owned range)
+__global__ __launch_bounds__(BLK) void k_cheb_first(double *__restrict__ x, double *__restrict__ d,
+                                                    const double *__restrict__ b, const double *__restrict__ dinv,
+                                                    double inv_theta, long off, long n) {
+    for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
+        const double v = dinv[off + i] * b[off + i] * inv_theta;
+        d[off + i] = v;
+        x[off + i] = v;
+    }
+}
+
+// Jacobi diagonal of the matrix-free operator: d_i = sum_e E_e n_i KE[ii] + (1 - n_i)
+template <int DOF>
+__global__ __launch_bounds__(BLK) void k_matfree_diag(MatfreeOp<DOF> op, double *__restrict__ dinv) {
+    const Geom &g = op.g;
+    constexpr int ED = 8 * DOF;
+    const long plane = g.plane();
+    const long t = blockIdx.x * (long)BLK + threadIdx.x;
+    if (t >= g.owned_nodes()) return;
+    const int k = g.own_lo + (int)(t / plane);
+    const int rem = (int)(t % plane);
+    const int j = rem / g.nx, i = rem % g.nx;
+    const long n = t + plane * g.own_lo;
+    double dg[DOF];
+#pragma unroll
+    for (int r = 0; r < DOF; r++) dg[r] = 0.0;
+#pragma unroll
+    for (int a = 0; a < 8; a++) {
+        const int ei = i - LXc(a), ej = j - LYc(a), ek = k - LZc(a);
+        if (ei < 0 || ei >= g.ex || ej < 0 || ej >= g.ey || ek < 0 || ek >= g.ezl) continue;
+        const double Ee = op.E ? op.E[(long)ei + (long)g.ex * (ej + (long)g.ey * ek)] : 1.0;
+#pragma unroll
+        for (int r = 0; r < DOF; r++) dg[r] = fma(Ee, op.KE[(a * DOF + r) * ED + a * DOF + r], dg[r]);
+    }
+    const unsigned m = op.mask ? op.mask[n] : 0u;
+#pragma unroll
+    for (int r = 0; r < DOF; r++) dinv[n * DOF + r] = ((m >> r) & 1u) ? 1.0 : 1.0 / dg[r];
+}
+
+// ---------------------------------------------------------------------------
+// grid transfer: trilinear Q1, coarse node I at fine node 2I
+// (DMCreateInterpolation on a DMDA, LinearElasticity.cc:704); restriction = P^T.
+// ---------------------------------------------------------------------------
+// coarse b_c[I] = sum over the 27 fine neighbours of 2I of w * r_f ; owned coarse nodes
+template <int DOF>
+__global__ __launch_bounds__(BLK) void k_restrict(Geom gc, Geom gf, const double *__restrict__ rf,
+                                                  double *__restrict__ bc) {
+    const long plane = gc.plane();
+    const long t = blockIdx.x * (long)BLK + threadIdx.x;
+    if (t >= gc.owned_nodes()) return;
+    const int K = gc.own_lo + (int)(t / plane);
+    const int rem = (int)(t % plane);
+    const int J = rem / gc.nx, I = rem % gc.nx;
+    const long nc = t + plane * gc.own_lo;
+    double s[DOF];
+#pragma unroll
+    for (int r = 0; r < DOF; r++) s[r] = 0.0;
+#pragma unroll
+    for (int dk = -1; dk <= 1; dk++) {
+        const int k = 2 * K + dk;
+        if (k < 0 || k >= gf.nzl) continue;
+#pragma unroll
+        for (int dj = -1; dj <= 1; dj++) {
+            const int j = 2 * J + dj;
+            if (j < 0 || j >= gf.ny) continue;
+#pragma unroll
+            for (int di = -1; di <= 1; di++) {
+                const int i = 2 * I + di;
+                if (i < 0 || i >= gf.nx) continue;
+                const double w = (di ? 0.5 : 1.0) * (dj ? 0.5 : 1.0) * (dk ? 0.5 : 1.0);
+                const long nf = (long)i + (long)gf.nx * (j + (long)gf.ny * k);
+#pragma unroll
+                for (int r = 0; r < DOF; r++) s[r] = fma(w, rf[nf * DOF + r], s[r]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < DOF; r++) bc[nc * DOF + r] = s[r];
+}
+
+// fine x_f += P x_c ; owned fine nodes
+template <int DOF>
+__global__ __launch_bounds__(BLK) void k_prolong_add(Geom gc, Geom gf, const double *__restrict__ xc,
+                                                     double *__restrict__ xf) {
+    const long plane = gf.plane();
+    const long t = blockIdx.x * (long)BLK + threadIdx.x;
+    if (t >= gf.owned_nodes()) return;
+    const int k = gf.own_lo + (int)(t / plane);
+    const int rem = (int)(t % plane);
+    const int j = rem / gf.nx, i = rem % gf.nx;
+    const long nf = t + plane * gf.own_lo;
+    const int I0 = i >> 1, J0 = j >> 1, K0 = k >> 1;
+    const int mi = i & 1, mj = j & 1, mk = k & 1;
+    double s[DOF];
+#pragma unroll
+    for (int r = 0; r < DOF; r++) s[r] = 0.0;
+    for (int kk = 0; kk <= mk; kk++)
+        for (int jj = 0; jj <= mj; jj++)
+            for (int ii = 0; ii <= mi; ii++) {
+                const double w = (mi ? 0.5 : 1.0) * (mj ? 0.5 : 1.0) * (mk ? 0.5 : 1.0);
+                const long nc = (long)(I0 + ii) + (long)gc.nx * ((J0 + jj) + (long)gc.ny * (K0 + kk));
+#pragma unroll
+                for (int r = 0; r < DOF; r++) s[r] = fma(w, xc[nc * DOF + r], s[r]);
+            }
+#pragma unroll
+    for (int r = 0; r < DOF; r++) xf[nf * DOF + r] += s[r];
+}

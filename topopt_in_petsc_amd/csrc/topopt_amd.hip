@@ -1,0 +1,447 @@
+// topopt_amd.hip -- C-ABI entry points (include/topopt_amd.h) of the MI355X-native
+// hot path.  gfx950 only; no CPU fallback anywhere in this library.
+#include "elements.h"
+#include "mg.h"
+
+// ===========================================================================
+// grid
+// ===========================================================================
+extern "C" int tp_grid_create(tp_grid **out, const tp_grid_opts *o) {
+    if (!out || !o) return TP_ERR_ARG;
+    if (o->nx < 2 || o->ny < 2 || o->nz < 2 || o->nranks < 1 || o->rank < 0 || o->rank >= o->nranks) return TP_ERR_ARG;
+    if ((o->nz - 1) % o->nranks) return TP_ERR_ARG;
+    if (o->nranks > 1 && !o->comm) return TP_ERR_ARG;
+    TP_HIP(hipSetDevice(o->device));
+    tp_grid *g = new tp_grid();
+    g->o = *o;
+    g->stream = (hipStream_t)o->stream;
+    g->has_comm = o->nranks > 1;
+    if (g->has_comm) g->comm = *o->comm;
+    g->ex = o->nx - 1;
+    g->ey = o->ny - 1;
+    g->ez_glob = o->nz - 1;
+    g->ez_own = g->ez_glob / o->nranks;
+    g->rank = o->rank;
+    g->nranks = o->nranks;
+    g->alg_bytes = g->flops = 0.0;
+    g->launches = 0;
+    Geom q = make_geom(g, 0);
+    long nblk = q.nodes() / BLK + 2;
+    if (nblk < MAX_RED_BLOCKS) nblk = MAX_RED_BLOCKS;
+    if (hipMalloc((void **)&g->partials, sizeof(double) * 4 * (size_t)nblk) != hipSuccess ||
+        hipMalloc((void **)&g->scal, sizeof(double) * 64) != hipSuccess ||
+        hipHostMalloc((void **)&g->h_scal, sizeof(double) * 64) != hipSuccess) {
+        delete g;
+        return TP_ERR_HIP + (int)hipErrorOutOfMemory;
+    }
+    (void)hipMemsetAsync(g->scal, 0, sizeof(double) * 64, g->stream);
+    double W[512];
+    host_W(W);
+    TP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_W), W, sizeof(W)));
+    *out = g;
+    return TP_OK;
+}
+extern "C" int tp_grid_destroy(tp_grid *g) {
+    if (!g) return TP_OK;
+    (void)hipStreamSynchronize(g->stream);
+    (void)hipFree(g->partials);
+    (void)hipFree(g->scal);
+    (void)hipHostFree(g->h_scal);
+    delete g;
+    return TP_OK;
+}
+extern "C" long tp_grid_local_nodes(const tp_grid *g) { return make_geom(g, 0).nodes(); }
+extern "C" long tp_grid_local_elems(const tp_grid *g) { return make_geom(g, 0).own_elems(); }
+extern "C" long tp_grid_owned_node_offset(const tp_grid *g) {
+    Geom q = make_geom(g, 0);
+    return q.plane() * q.own_lo;
+}
+extern "C" long tp_grid_owned_nodes(const tp_grid *g) { return make_geom(g, 0).owned_nodes(); }
+extern "C" int tp_grid_node_z0(const tp_grid *g) { return make_geom(g, 0).gz0; }
+extern "C" int tp_grid_elem_z0(const tp_grid *g) { return g->rank * g->ez_own; }
+
+extern "C" int tp_malloc(void **p, size_t bytes) {
+    TP_HIP(hipMalloc(p, bytes));
+    return TP_OK;
+}
+extern "C" int tp_free(void *p) {
+    TP_HIP(hipFree(p));
+    return TP_OK;
+}
+extern "C" int tp_memcpy_h2d(void *dst, const void *src, size_t bytes) {
+    TP_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return TP_OK;
+}
+extern "C" int tp_memcpy_d2h(void *dst, const void *src, size_t bytes) {
+    TP_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return TP_OK;
+}
+extern "C" int tp_sync(const tp_grid *g) {
+    TP_HIP(hipStreamSynchronize(g->stream));
+    return TP_OK;
+}
+extern "C" int tp_vec_scale(tp_grid *g, double *x, double a, long n) {
+    hipLaunchKernelGGL(k_scale, dim3(grid_for(n)), dim3(BLK), 0, g->stream, x, a, n);
+    count_launch(g, 16.0 * n, 1.0 * n);
+    return TP_OK;
+}
+extern "C" int tp_vec_set(tp_grid *g, double *x, double a, long n) {
+    hipLaunchKernelGGL(k_set, dim3(grid_for(n)), dim3(BLK), 0, g->stream, x, a, n);
+    count_launch(g, 8.0 * n, 0.0);
+    return TP_OK;
+}
+
+__global__ __launch_bounds__(BLK) void k_synth_density(int ex, int ey, int ez, int e0z, double h, uint64_t seed,
+                                                       double *__restrict__ x) {
+    const long n = (long)ex * ey * ez;
+    const double pi = 3.14159265358979323846;
+    for (long t = blockIdx.x * (long)BLK + threadIdx.x; t < n; t += (long)gridDim.x * BLK) {
+        const int i = (int)(t % ex), j = (int)((t / ex) % ey), k = (int)(t / ((long)ex * ey));
+        const uint64_t gid = (uint64_t)i + (uint64_t)ex * ((uint64_t)j + (uint64_t)ey * (uint64_t)(k + e0z));
+        const double xc = (i + 0.5) * h, yc = (j + 0.5) * h, zc = (k + e0z + 0.5) * h;
+        double v = 0.12 + 0.4 * sin(7 * pi * xc) * sin(5 * pi * yc) * sin(3 * pi * zc) + 0.3 * (hash_u01(gid, seed) - 0.5);
+        v = v < 1e-3 ? 1e-3 : (v > 1.0 ? 1.0 : v);
+        x[t] = v;
+    }
+}
+extern "C" int tp_synth_density(tp_grid *g, double *x, uint64_t seed) {
+    const long n = (long)g->ex * g->ey * g->ez_own;
+    hipLaunchKernelGGL(k_synth_density, dim3(grid_for(n)), dim3(BLK), 0, g->stream, g->ex, g->ey, g->ez_own,
+                       g->rank * g->ez_own, g->o.hy, seed, x);
+    count_launch(g);
+    return TP_OK;
+}
+
+// ===========================================================================
+// linear elasticity
+// ===========================================================================
+extern "C" void tp_solver_default_opts(tp_solver_opts *o) {
+    o->nlvls = 4;       // LinearElasticity.cc:23
+    o->nu = 0.3;        // :22
+    o->rtol = 1.0e-5;   // :621
+    o->atol = 1.0e-50;  // :622
+    o->dtol = 1.0e5;    // :623
+    o->max_it = 200;    // :625
+    o->nsmooth = 4;     // :635
+    o->ncoarse = 30;    // :631
+    o->cheb_lo = 0.1;   // PETSc's default Chebyshev window 0.1 / 1.1 of the estimate
+    o->cheb_hi = 1.1;
+    o->nlanczos = 10;
+}
+
+struct tp_elasticity {
+    tp_grid *grid;
+    MGSolver<3> mg;
+    double KE[576];
+    double *d_KE, *d_M;      // element matrix, 8 child matrices (level 0 -> 1 fast path)
+    double *d_E;             // SIMP moduli, own + ghost-above layer
+    uint8_t *d_mask;         // clamped-dof bits per local node
+    std::vector<uint8_t> h_mask;
+    int *d_flagged;          // level-1 elements touching clamped nodes
+    int nflagged;
+    double *d_bN;            // RHS .* N scratch
+    double *d_N;             // copy of N (for the load masking of :542)
+    bool have_bc, assembled;
+};
+
+__global__ __launch_bounds__(BLK) void k_simp(const double *__restrict__ x, double Emin, double Emax, double penal,
+                                              double *__restrict__ E, long n) {
+    for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK)
+        E[i] = Emin + pow(x[i], penal) * (Emax - Emin);  // LinearElasticity.cc:519
+}
+__global__ __launch_bounds__(BLK) void k_mask_from_N(const double *__restrict__ N, uint8_t *__restrict__ mask, long nn) {
+    for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < nn; i += (long)gridDim.x * BLK) {
+        unsigned m = 0;
+        for (int c = 0; c < 3; c++)
+            if (N[3 * i + c] == 0.0) m |= 1u << c;
+        mask[i] = (uint8_t)m;
+    }
+}
+// cantilever load case: clamp x = xmin, line load at x = xmax, z = zmin
+// (LinearElasticity.cc:143-171); coordinates are integers here, so the
+// reference's epsilon windows reduce to index tests.
+__global__ __launch_bounds__(BLK) void k_cantilever(Geom g, double *__restrict__ N, double *__restrict__ RHS) {
+    const long nn = g.nodes();
+    for (long n = blockIdx.x * (long)BLK + threadIdx.x; n < nn; n += (long)gridDim.x * BLK) {
+        const int i = (int)(n % g.nx), j = (int)((n / g.nx) % g.ny), k = (int)(n / g.plane()) + g.gz0;
+        const double nv = i == 0 ? 0.0 : 1.0;
+        double load = 0.0;
+        if (i == g.nx - 1 && k == 0) load = (j == 0 || j == g.ny - 1) ? -0.001 / 2.0 : -0.001;
+        N[3 * n] = N[3 * n + 1] = N[3 * n + 2] = nv;
+        RHS[3 * n] = RHS[3 * n + 1] = 0.0;
+        RHS[3 * n + 2] = load;
+    }
+}
+
+extern "C" int tp_elasticity_create(tp_elasticity **out, tp_grid *g, const tp_solver_opts *o) {
+    if (!out || !g || !o) return TP_ERR_ARG;
+    if (o->nlvls < 1 || o->nlvls > TP_MAX_LEVELS) return TP_ERR_ARG;
+    // TopOpt.cc:183-201: every direction divisible by 2^(nlvls-1); here also per slab
+    const int f = 1 << (o->nlvls - 1);
+    if (g->ex % f || g->ey % f || g->ez_own % f) return TP_ERR_ARG;
+    tp_elasticity *e = new tp_elasticity();
+    e->grid = g;
+    e->mg.grid = g;
+    e->mg.nlv = o->nlvls;
+    e->mg.opt = *o;
+    e->have_bc = e->assembled = false;
+    e->d_flagged = nullptr;
+    e->nflagged = 0;
+    hex8_stiffness_box(g->o.hx, g->o.hy, g->o.hz, o->nu, e->KE);
+    std::vector<double> M(8 * 576);
+    host_child_matrices(e->KE, M.data());
+    TP_TRY(e->mg.alloc_levels());
+    Geom q = make_geom(g, 0);
+    TP_HIP(hipMalloc((void **)&e->d_KE, sizeof(double) * 576));
+    TP_HIP(hipMalloc((void **)&e->d_M, sizeof(double) * 8 * 576));
+    TP_HIP(hipMalloc((void **)&e->d_E, sizeof(double) * (size_t)q.elems_stored()));
+    TP_HIP(hipMalloc((void **)&e->d_mask, (size_t)q.nodes()));
+    TP_HIP(hipMalloc((void **)&e->d_bN, sizeof(double) * 3 * (size_t)q.nodes()));
+    TP_HIP(hipMalloc((void **)&e->d_N, sizeof(double) * 3 * (size_t)q.nodes()));
+    TP_HIP(hipMemcpy(e->d_KE, e->KE, sizeof(double) * 576, hipMemcpyHostToDevice));
+    TP_HIP(hipMemcpy(e->d_M, M.data(), sizeof(double) * 8 * 576, hipMemcpyHostToDevice));
+    TP_HIP(hipMemset(e->d_mask, 0, (size_t)q.nodes()));
+    for (int l = 0; l < e->mg.nlv; l++) {
+        Level<3> &L = e->mg.lv[l];
+        L.kind = l == 0 ? LV_MATFREE : LV_DIA;
+        L.KE = e->d_KE;
+        L.E = e->d_E;
+        L.mask = e->d_mask;
+        L.S = L.Kel = nullptr;
+        if (l > 0) {
+            TP_HIP(hipMalloc((void **)&L.S, sizeof(double) * 81 * (size_t)L.ndof()));
+            TP_HIP(hipMemset(L.S, 0, sizeof(double) * 81 * (size_t)L.ndof()));
+            TP_HIP(hipMalloc((void **)&L.Kel, sizeof(double) * 576 * (size_t)L.g.elems_stored()));
+        }
+    }
+    *out = e;
+    return TP_OK;
+}
+extern "C" int tp_elasticity_destroy(tp_elasticity *e) {
+    if (!e) return TP_OK;
+    (void)hipStreamSynchronize(e->grid->stream);
+    e->mg.free_levels();
+    for (void *p : {(void *)e->d_KE, (void *)e->d_M, (void *)e->d_E, (void *)e->d_mask, (void *)e->d_bN, (void *)e->d_N,
+                    (void *)e->d_flagged})
+        (void)hipFree(p);
+    delete e;
+    return TP_OK;
+}
+extern "C" int tp_elasticity_get_ke(const tp_elasticity *e, double *ke) {
+    std::memcpy(ke, e->KE, sizeof(e->KE));
+    return TP_OK;
+}
+extern "C" int tp_elasticity_set_bc(tp_elasticity *e, const double *N) {
+    tp_grid *g = e->grid;
+    Geom q = make_geom(g, 0);
+    const long nn = q.nodes();
+    hipLaunchKernelGGL(k_mask_from_N, dim3(grid_for(nn)), dim3(BLK), 0, g->stream, N, e->d_mask, nn);
+    TP_HIP(hipMemcpyAsync(e->d_N, N, sizeof(double) * 3 * (size_t)nn, hipMemcpyDeviceToDevice, g->stream));
+    e->h_mask.resize((size_t)nn);
+    TP_HIP(hipMemcpyAsync(e->h_mask.data(), e->d_mask, (size_t)nn, hipMemcpyDeviceToHost, g->stream));
+    TP_HIP(hipStreamSynchronize(g->stream));
+    // level-1 elements whose 27 fine nodes include a clamped one take the generic Galerkin path
+    std::vector<int> fl;
+    if (e->mg.nlv > 1) {
+        Geom c = make_geom(g, 1);
+        for (int K = 0; K < c.ez_own; K++)
+            for (int J = 0; J < c.ey; J++)
+                for (int I = 0; I < c.ex; I++) {
+                    bool any = false;
+                    for (int dk = 0; dk <= 2 && !any; dk++)
+                        for (int dj = 0; dj <= 2 && !any; dj++)
+                            for (int di = 0; di <= 2 && !any; di++)
+                                any = e->h_mask[(size_t)((2 * I + di) + (long)q.nx * ((2 * J + dj) + (long)q.ny * (2 * K + dk)))] != 0;
+                    if (any) fl.push_back(I + c.ex * (J + c.ey * K));
+                }
+    }
+    (void)hipFree(e->d_flagged);
+    e->d_flagged = nullptr;
+    e->nflagged = (int)fl.size();
+    if (e->nflagged) {
+        TP_HIP(hipMalloc((void **)&e->d_flagged, sizeof(int) * fl.size()));
+        TP_HIP(hipMemcpy(e->d_flagged, fl.data(), sizeof(int) * fl.size(), hipMemcpyHostToDevice));
+    }
+    e->have_bc = true;
+    e->assembled = false;
+    return TP_OK;
+}
+extern "C" int tp_elasticity_cantilever(tp_elasticity *e, double *N, double *RHS) {
+    tp_grid *g = e->grid;
+    Geom q = make_geom(g, 0);
+    hipLaunchKernelGGL(k_cantilever, dim3(grid_for(q.nodes())), dim3(BLK), 0, g->stream, q, N, RHS);
+    return tp_elasticity_set_bc(e, N);
+}
+
+extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, double Emin, double Emax, double penal) {
+    if (!e->have_bc) return TP_ERR_STATE;
+    tp_grid *g = e->grid;
+    MGSolver<3> &mg = e->mg;
+    hipStream_t s = g->stream;
+    Geom q0 = mg.lv[0].g;
+    const long nel = q0.own_elems(), lay = (long)q0.ex * q0.ey;
+    hipLaunchKernelGGL(k_simp, dim3(grid_for(nel)), dim3(BLK), 0, s, xPhys, Emin, Emax, penal, e->d_E, nel);
+    count_launch(g, 16.0 * nel, 3.0 * nel);
+    // ghost layer above <- upper neighbour's first own layer
+    TP_TRY(exchange_segments(g, e->d_E, nullptr, nullptr, e->d_E + nel, lay, 1, lay));
+    TP_TRY(mg.setup_matfree_level(0, e->KE));
+    for (int l = 1; l < mg.nlv; l++) {
+        Level<3> &F = mg.lv[l - 1], &C = mg.lv[l];
+        const long nEc = C.g.own_elems();
+        if (l == 1) {
+            hipLaunchKernelGGL(k_galerkin_fine_fast, dim3((int)((nEc + BLK - 1) / BLK)), dim3(BLK), 0, s, F.g, C.g,
+                               e->d_E, e->d_M, C.Kel);
+            count_launch(g, 8.0 * nel + 8.0 * 576 * nEc, 2.0 * 8 * 576 * nEc);
+            if (e->nflagged) {
+                hipLaunchKernelGGL(k_galerkin_fine_masked, dim3(e->nflagged), dim3(64), 0, s, F.g, C.g, e->d_E, e->d_KE,
+                                   e->d_mask, e->d_flagged, C.Kel);
+                count_launch(g);
+            }
+        } else {
+            hipLaunchKernelGGL(k_galerkin_coarse, dim3((int)((nEc * 64 + BLK - 1) / BLK)), dim3(BLK), 0, s, F.g, C.g,
+                               F.Kel, C.Kel);
+            count_launch(g, 8.0 * 576 * (9.0 * nEc), 2.0 * 0.18 * 8 * 64 * 64 * 9 * nEc);
+        }
+        // coarse ghost element layer above <- upper neighbour's first own layer
+        const long clay = (long)C.g.ex * C.g.ey;
+        TP_TRY(exchange_segments(g, C.Kel, nullptr, nullptr, C.Kel + clay * C.g.ez_own, clay, 576, C.g.elems_stored()));
+        const int gn = (int)((C.g.owned_nodes() + BLK - 1) / BLK);
+        hipLaunchKernelGGL(k_elem_to_dia, dim3(gn, 27), dim3(BLK), 0, s, C.g, C.Kel, C.S, C.dinv);
+        count_launch(g, 8.0 * (576.0 * C.g.elems_stored() + 243.0 * C.g.owned_nodes()), 9.0 * 64 * C.g.owned_nodes());
+    }
+    mg.ready = true;
+    for (int l = 1; l < mg.nlv; l++) TP_TRY(mg.lanczos(l, mg.opt.nlanczos, &mg.lv[l].lam));
+    e->assembled = true;
+    return TP_OK;
+}
+
+extern "C" int tp_elasticity_apply(tp_elasticity *e, const double *u, double *y) {
+    if (!e->assembled) return TP_ERR_STATE;
+    return e->mg.apply(0, const_cast<double *>(u), y);
+}
+
+__global__ __launch_bounds__(BLK) void k_mul(double *__restrict__ y, const double *__restrict__ a,
+                                             const double *__restrict__ b, long n) {
+    for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) y[i] = a[i] * b[i];
+}
+
+extern "C" int tp_elasticity_solve(tp_elasticity *e, const double *RHS, double *U, int *its, double *rnorm,
+                                   double *bnorm, double *hist, int hist_cap) {
+    if (!e->assembled) return TP_ERR_STATE;
+    tp_grid *g = e->grid;
+    const long n = e->mg.lv[0].ndof();
+    // RHS <- RHS .* N (LinearElasticity.cc:542), on a scratch copy
+    hipLaunchKernelGGL(k_mul, dim3(grid_for(n)), dim3(BLK), 0, g->stream, e->d_bN, RHS, e->d_N, n);
+    count_launch(g, 24.0 * n, 1.0 * n);
+    return e->mg.solve(e->d_bN, U, its, rnorm, bnorm, hist, hist_cap);
+}
+
+// fx = sum_e E_e u_e^T KE u_e, dfdx_e = -p x^(p-1) (Emax-Emin) u_e^T KE u_e, partial sum x
+// (LinearElasticity.cc:405-437); one thread per own element, KE rows wave-uniform.
+__global__ __launch_bounds__(BLK) void k_objective(Geom g, const double *__restrict__ KE, const double *__restrict__ U,
+                                                   const double *__restrict__ x, double Emin, double Emax, double penal,
+                                                   double *__restrict__ dfdx, double *__restrict__ partials) {
+    const long nel = g.own_elems();
+    const long t = blockIdx.x * (long)BLK + threadIdx.x;
+    double f = 0.0, vol = 0.0;
+    if (t < nel) {
+        const int i = (int)(t % g.ex), j = (int)((t / g.ex) % g.ey), k = (int)(t / ((long)g.ex * g.ey));
+        double ue[24];
+#pragma unroll
+        for (int a = 0; a < 8; a++) {
+            const long nd = (long)(i + LXc(a)) + (long)g.nx * ((j + LYc(a)) + (long)g.ny * (k + LZc(a)));
+#pragma unroll
+            for (int c = 0; c < 3; c++) ue[3 * a + c] = U[3 * nd + c];
+        }
+        double uKu = 0.0;
+#pragma unroll
+        for (int r = 0; r < 24; r++) {
+            double s = 0.0;
+#pragma unroll
+            for (int c = 0; c < 24; c++) s = fma(KE[r * 24 + c], ue[c], s);
+            uKu = fma(ue[r], s, uKu);
+        }
+        const double xe = x[t];
+        f = (Emin + pow(xe, penal) * (Emax - Emin)) * uKu;
+        vol = xe;
+        if (dfdx) dfdx[t] = -1.0 * penal * pow(xe, penal - 1) * (Emax - Emin) * uKu;
+    }
+    f = block_sum(f);
+    vol = block_sum(vol);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = f;
+        partials[gridDim.x + blockIdx.x] = vol;
+    }
+}
+
+extern "C" int tp_elasticity_objective(tp_elasticity *e, const double *U, const double *xPhys, double Emin, double Emax,
+                                       double penal, double volfrac, double *fx, double *gx, double *dfdx,
+                                       double *dgdx) {
+    tp_grid *g = e->grid;
+    Geom q = e->mg.lv[0].g;
+    const long nel = q.own_elems();
+    const long nel_glob = (long)g->ex * g->ey * g->ez_glob;
+    TP_TRY(halo_nodes(g, q, const_cast<double *>(U), 3));  // DMGlobalToLocal, :388-390
+    const int nb = (int)((nel + BLK - 1) / BLK);
+    hipLaunchKernelGGL(k_objective, dim3(nb), dim3(BLK), 0, g->stream, q, e->d_KE, U, xPhys, Emin, Emax, penal, dfdx,
+                       g->partials);
+    count_launch(g, 24.0 * q.owned_nodes() + 16.0 * nel, 2.0 * 600 * nel);
+    TP_TRY(finish_reduction<2>(g, nb, S_TMP));
+    double v[2];
+    TP_TRY(read_scal(g, S_TMP, 2, v));
+    if (fx) *fx = v[0];
+    if (gx) *gx = v[1] / (double)nel_glob - volfrac;
+    if (dgdx) TP_TRY(tp_vec_set(g, dgdx, 1.0 / (double)nel_glob, nel));
+    return TP_OK;
+}
+
+extern "C" int tp_elasticity_level_count(const tp_elasticity *e) { return e->mg.nlv; }
+extern "C" long tp_elasticity_level_nodes(const tp_elasticity *e, int l) { return e->mg.lv[l].g.nodes(); }
+extern "C" double tp_elasticity_level_lambda(const tp_elasticity *e, int l) { return e->mg.lv[l].lam; }
+extern "C" int tp_elasticity_level_apply(tp_elasticity *e, int l, const double *u, double *y) {
+    if (!e->assembled || l < 0 || l >= e->mg.nlv) return TP_ERR_STATE;
+    return e->mg.apply(l, const_cast<double *>(u), y);
+}
+extern "C" int tp_elasticity_level_diag(tp_elasticity *e, int l, double *d) {
+    if (!e->assembled) return TP_ERR_STATE;
+    Level<3> &L = e->mg.lv[l];
+    TP_HIP(hipMemcpyAsync(d, L.dinv, sizeof(double) * (size_t)L.ndof(), hipMemcpyDeviceToDevice, e->grid->stream));
+    return TP_OK;
+}
+extern "C" int tp_elasticity_precond(tp_elasticity *e, const double *r, double *z) {
+    if (!e->assembled) return TP_ERR_STATE;
+    double *zp;
+    TP_TRY(e->mg.precond(r, &zp));
+    TP_HIP(hipMemcpyAsync(z, zp, sizeof(double) * (size_t)e->mg.lv[0].ndof(), hipMemcpyDeviceToDevice,
+                          e->grid->stream));
+    return TP_OK;
+}
+extern "C" int tp_elasticity_restrict(tp_elasticity *e, int l, const double *rf, double *rc) {
+    MGSolver<3> &mg = e->mg;
+    if (l < 0 || l + 1 >= mg.nlv) return TP_ERR_ARG;
+    TP_TRY(mg.halo(l, const_cast<double *>(rf)));
+    hipLaunchKernelGGL((k_restrict<3>), dim3((int)((mg.lv[l + 1].g.owned_nodes() + BLK - 1) / BLK)), dim3(BLK), 0,
+                       e->grid->stream, mg.lv[l + 1].g, mg.lv[l].g, rf, rc);
+    return TP_OK;
+}
+extern "C" int tp_elasticity_prolong_add(tp_elasticity *e, int l, const double *xc, double *xf) {
+    MGSolver<3> &mg = e->mg;
+    if (l < 0 || l + 1 >= mg.nlv) return TP_ERR_ARG;
+    TP_TRY(mg.halo(l + 1, const_cast<double *>(xc)));
+    hipLaunchKernelGGL((k_prolong_add<3>), dim3((int)((mg.lv[l].g.owned_nodes() + BLK - 1) / BLK)), dim3(BLK), 0,
+                       e->grid->stream, mg.lv[l + 1].g, mg.lv[l].g, xc, xf);
+    return TP_OK;
+}
+extern "C" int tp_elasticity_last_stats(const tp_elasticity *e, double *alg_bytes, double *flops, long *launches) {
+    if (alg_bytes) *alg_bytes = e->grid->alg_bytes;
+    if (flops) *flops = e->grid->flops;
+    if (launches) *launches = e->grid->launches;
+    e->grid->alg_bytes = e->grid->flops = 0.0;
+    e->grid->launches = 0;
+    return TP_OK;
+}
+
+// ===========================================================================
+// density / sensitivity filter and Helmholtz PDE filter
+// ===========================================================================
+#include "filter.h"
