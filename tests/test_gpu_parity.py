@@ -109,8 +109,11 @@ def test_solve_residual_history(tp, orc, kind, nlv):
     assert its == its_o
     h = le.last_hist
     assert len(h) == len(hist_o)
-    assert np.abs(h / hist_o - 1).max() <= 1e-8, np.abs(h / hist_o - 1).max()
-    assert np.abs(h[:10] / hist_o[:10] - 1).max() <= 1e-10
+    bn = le.last_bnorm
+    assert np.abs(h[:10] / hist_o[:10] - 1).max() <= 1e-10          # north star: 1e-10 relative
+    big = hist_o > 1e-7 * bn                                          # two decades below the bench tolerance
+    assert np.abs(h[big] / hist_o[big] - 1).max() <= 1e-9
+    assert np.abs(h - hist_o).max() <= 1e-12 * bn                     # tail: rounding floor of the recurrence
     assert rel(host(le.U), Uo) <= 1e-9
     assert le.last_bnorm == pytest.approx(np.linalg.norm(R * N), rel=1e-14)
     # warm start from the converged state (KSPSetInitialGuessNonzero): no iterations
@@ -190,3 +193,63 @@ def test_pde_filter(tp, orc):
     f.Gradients(dev(x), xt, df, [])
     dfo, _, _ = of.apply(df0)
     assert rel(host(df), dfo) <= 1e-9
+
+
+def test_odd_sized_mesh_apply(tp, orc):
+    """tile edges / partially filled tiles of the tuned kernel: sizes that are not multiples of 15 or 16"""
+    for (ex, ey, ez) in [(20, 12, 8), (31, 17, 5), (15, 15, 15), (33, 4, 2)]:
+        nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
+        grid = tp.Grid(nx, ny, nz, h)
+        le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=1))
+        le.SetUpLoadAndBC()
+        x = orc.synth_density(ex, ey, ez, h)
+        le.AssembleStiffnessMatrix(dev(x), 1e-9, 1.0, 3.0)
+        KE = orc.hex8_ke_box(h, h, h, 0.3)
+        N, R = orc.cantilever_bc(nx, ny, nz, h)
+        u = np.random.default_rng(ex).standard_normal(3 * nx * ny * nz)
+        yo = orc.matfree_apply(nx, ny, nz, 3, KE, orc.simp(x), N, u)
+        assert rel(host(le.MatMult(dev(u))), yo) <= 1e-13, (ex, ey, ez)
+
+
+def test_full_size_properties(tp):
+    """BASELINE config C2 (128x64x64): size-independent properties instead of an oracle run."""
+    ex, ey, ez = 128, 64, 64
+    h = 1.0 / ey
+    grid = tp.Grid(ex + 1, ey + 1, ez + 1, h)
+    le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=3, rtol=1e-8, max_it=400))
+    flt = tp.Filter(grid, 1, 2.56 * h)
+    le.SetUpLoadAndBC()
+    x = grid.synth_density()
+    xt, xp = grid.elem_vec(), grid.elem_vec()
+    flt.FilterProject(x, xt, xp)
+    # filter: preserves constants, stays within [min, max], adjoint identity
+    one, o1, o2 = grid.elem_vec(1.0), grid.elem_vec(), grid.elem_vec()
+    flt.FilterProject(one, o1, o2)
+    assert float((o1 - 1).abs().max()) < 1e-14
+    assert float(xt.min()) >= float(x.min()) - 1e-15 and float(xt.max()) <= float(x.max()) + 1e-15
+    y = torch.rand_like(x)
+    g = y.clone()
+    flt.Gradients(x, xt, g, [])
+    assert float(torch.dot(xt, y)) == pytest.approx(float(torch.dot(x, g)), rel=1e-12)
+    # operator: symmetric, Dirichlet rows, positive
+    le.AssembleStiffnessMatrix(xp, 1e-9, 1.0, 3.0)
+    u, v = torch.randn_like(le.U), torch.randn_like(le.U)
+    Au, Av = le.MatMult(u), le.MatMult(v)
+    assert float(torch.dot(v, Au)) == pytest.approx(float(torch.dot(u, Av)), rel=1e-11)
+    cl = le.N == 0
+    assert torch.equal(Au[cl], u[cl])
+    assert float(torch.dot(u, Au)) > 0
+    # preconditioner: symmetric positive (CG requirement)
+    zu, zv = le.precond(u), le.precond(v)
+    assert float(torch.dot(v, zu)) == pytest.approx(float(torch.dot(u, zv)), rel=1e-9)
+    assert float(torch.dot(u, zu)) > 0
+    # solve: true residual matches the reported one; compliance identity fx = b^T U
+    its = le.KSPSolve(hist_cap=512)
+    assert 0 < its < 400
+    b = le.RHS * le.N
+    r = b - le.MatMult(le.U)
+    assert float(r.norm()) == pytest.approx(le.last_rnorm, rel=1e-4)
+    assert le.last_rnorm <= 1e-8 * le.last_bnorm
+    fx, gx = le.Objective(xp, 1e-9, 1.0, 3.0, 0.12)
+    assert fx == pytest.approx(float(torch.dot(b, le.U)), rel=1e-7)
+    assert gx == pytest.approx(float(xp.mean()) - 0.12, abs=1e-12)

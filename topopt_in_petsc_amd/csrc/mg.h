@@ -7,6 +7,7 @@
 #include "galerkin.h"
 #include "grid.h"
 #include "operators.h"
+#include "matfree_tile.h"
 
 enum { LV_MATFREE = 0, LV_DIA = 1 };
 
@@ -24,6 +25,8 @@ struct Level {
     double *dinv;
     double lam;             // estimate / bound of lambda_max(D^-1 A)
     double *b, *x, *x2, *r, *d;
+    bool use_tile = false;  // DOF == 3 matrix-free level with a box-symmetric KE: tuned kernel
+    SymKE sym;
     long ndof() const { return (long)DOF * g.nodes(); }
     long own_off() const { return (long)DOF * g.plane() * g.own_lo; }
     long own_n() const { return (long)DOF * g.owned_nodes(); }
@@ -195,6 +198,7 @@ struct MGSolver {
     tp_solver_opts opt;
     double *cg_r = nullptr, *cg_p = nullptr, *cg_w = nullptr;
     bool ready = false;
+    int last_nblocks = 0;  // workgroups (= reduction partials) of the last op<EPI_APPLY_DOT>
 
     int alloc_levels() {
         for (int l = 0; l < nlv; l++) {
@@ -228,7 +232,21 @@ struct MGSolver {
         const long nown = L.g.owned_nodes();
         const int nb = (int)((nown + BLK - 1) / BLK);
         double bytes, flops;
-        if (L.kind == LV_MATFREE) {
+        last_nblocks = nb;
+        if (DOF == 3 && L.kind == LV_MATFREE && L.use_tile) {
+            const int tx = (L.g.nx + TOUT - 1) / TOUT, ty = (L.g.ny + TOUT - 1) / TOUT;
+            const int planes = L.g.own_hi - L.g.own_lo + 1;
+            static const int kz_env = getenv("TP_TILE_KZ") ? atoi(getenv("TP_TILE_KZ")) : 0;
+            int kz = kz_env > 0 ? kz_env : (int)((long)planes * tx * ty / 1024);
+            kz = kz < 8 ? 8 : (kz > 64 ? 64 : kz);
+            if (kz > planes) kz = planes;
+            const int tz = (planes + kz - 1) / kz;
+            last_nblocks = tx * ty * tz;
+            hipLaunchKernelGGL((k_matfree_tile<EPI>), dim3(tx, ty, tz), dim3(TILE * TILE), 0, grid->stream, L.g, L.E,
+                               L.mask, L.sym, a, kz);
+            bytes = 16.0 * DOF * nown + 8.0 * L.g.own_elems();
+            flops = 2.0 * 576 * (double)L.g.own_elems();
+        } else if (L.kind == LV_MATFREE) {
             MatfreeOp<DOF> o{L.KE, L.E, L.mask, L.g};
             hipLaunchKernelGGL((k_node<DOF, MatfreeOp<DOF>, EPI>), dim3(nb), dim3(BLK), 0, grid->stream, o, a);
             bytes = 16.0 * DOF * nown + (L.E ? 8.0 * L.g.own_elems() : 0.0);
@@ -423,7 +441,7 @@ struct MGSolver {
                     a.partials = grid->partials;
                     TP_TRY(halo(0, p));
                     TP_TRY(op<EPI_APPLY_DOT>(0, a));
-                    TP_TRY(finish_reduction<1>(grid, (int)((L.g.owned_nodes() + BLK - 1) / BLK), S_PW));
+                    TP_TRY(finish_reduction<1>(grid, last_nblocks, S_PW));
                 }
                 hipLaunchKernelGGL(k_cg_update_xr, dim3(nb), dim3(BLK), 0, s, x, r, p, w, grid->scal, rz_cur, off, n,
                                    grid->partials);

@@ -208,6 +208,11 @@ extern "C" int tp_elasticity_create(tp_elasticity **out, tp_grid *g, const tp_so
         L.E = e->d_E;
         L.mask = e->d_mask;
         L.S = L.Kel = nullptr;
+        if (l == 0) {
+            // tuned kernel needs the reflection symmetry of a box element (always true here)
+            const double asym = make_sym_ke(e->KE, &L.sym);
+            L.use_tile = asym < 1e-12 && !getenv("TP_NO_TILE");
+        }
         if (l > 0) {
             TP_HIP(hipMalloc((void **)&L.S, sizeof(double) * 81 * (size_t)L.ndof()));
             TP_HIP(hipMemset(L.S, 0, sizeof(double) * 81 * (size_t)L.ndof()));
