@@ -23,18 +23,50 @@
 #pragma once
 #include "operators.h"
 
+// Non-zero pattern of the blocks (structural for any box element: q = 0 and 7 are
+// full; a single-bit class only couples the two components other than that bit
+// (the third is a rigid translation / pure shear pattern with zero energy);
+// a two-bit class couples the two components of its bits and leaves the third
+// one alone on the diagonal).  33 distinct values -> they live in SGPRs.
+__host__ __device__ constexpr bool symke_nz(int q, int r, int s) {
+    if (q == 0 || q == 7) return true;
+    if (q == 1 || q == 2 || q == 4) {
+        const int b = q == 1 ? 0 : (q == 2 ? 1 : 2);
+        return r != b && s != b;
+    }
+    const int m = q == 6 ? 0 : (q == 5 ? 1 : 2);  // the component whose bit is NOT in q
+    return (r != m && s != m) || (r == m && s == m);
+}
+// index of the (symmetric) value B_q[r][s] in the packed array, -1 if structurally zero
+__host__ __device__ constexpr int symke_idx(int q, int r, int s) {
+    if (!symke_nz(q, r, s)) return -1;
+    const int lo = r < s ? r : s, hi = r < s ? s : r;
+    int n = 0;
+    for (int qq = 0; qq < 8; qq++)
+        for (int a = 0; a < 3; a++)
+            for (int b = a; b < 3; b++) {
+                if (!symke_nz(qq, a, b)) continue;
+                if (qq == q && a == lo && b == hi) return n;
+                n++;
+            }
+    return -1;
+}
+constexpr int SYMKE_N = 33;
+static_assert(symke_idx(7, 2, 2) == SYMKE_N - 1, "packed size");
+
 struct SymKE {
-    double B[72];  // B[q*9 + r*3 + s], q = parity class, r/s = displacement component
+    double a[SYMKE_N];
 };
 
 // natural index m = lx + 2 ly + 4 lz  ->  reference corner number
 static const int h_M2A[8] = {0, 1, 3, 2, 4, 5, 7, 6};
 
-// B = blockdiag(T KE T^T) / 64.  Returns the largest |off-block entry| relative to
-// the largest entry (0 for an exactly box-symmetric KE).
+// Packs blockdiag(T KE T^T) / 64.  Returns the largest entry that the packed form
+// drops (off-block or structurally-zero position), relative to the largest entry:
+// ~1e-17 for a box element, O(1) if KE is not box symmetric.
 inline double make_sym_ke(const double *KE, SymKE *out) {
-    double D[24][24];
-    double maxabs = 0.0, maxoff = 0.0;
+    static double D[24][24];
+    double maxabs = 0.0, dropped = 0.0;
     for (int p = 0; p < 8; p++)
         for (int r = 0; r < 3; r++)
             for (int p2 = 0; p2 < 8; p2++)
@@ -52,17 +84,18 @@ inline double make_sym_ke(const double *KE, SymKE *out) {
         for (int j = 0; j < 24; j++) {
             maxabs = fmax(maxabs, fabs(D[i][j]));
             const int qi = (i / 3) ^ (1 << (i % 3)), qj = (j / 3) ^ (1 << (j % 3));
-            if (qi != qj) maxoff = fmax(maxoff, fabs(D[i][j]));
+            if (qi != qj || !symke_nz(qi, i % 3, j % 3)) dropped = fmax(dropped, fabs(D[i][j]));
         }
     for (int q = 0; q < 8; q++)
         for (int r = 0; r < 3; r++)
-            for (int s = 0; s < 3; s++) {
-                // symmetrise the block (KE itself is symmetric only to rounding)
+            for (int s = r; s < 3; s++) {
+                const int id = symke_idx(q, r, s);
+                if (id < 0) continue;
                 const double a = D[(q ^ (1 << r)) * 3 + r][(q ^ (1 << s)) * 3 + s];
                 const double b = D[(q ^ (1 << s)) * 3 + s][(q ^ (1 << r)) * 3 + r];
-                out->B[q * 9 + r * 3 + s] = 0.5 * (a + b);
+                out->a[id] = 0.5 * (a + b);  // KE itself is symmetric only to rounding
             }
-    return maxabs > 0 ? maxoff / maxabs : 0.0;
+    return maxabs > 0 ? dropped / maxabs : 0.0;
 }
 
 __device__ inline double dpp_row_shr1(double v) {
@@ -72,32 +105,71 @@ __device__ inline double dpp_row_shr1(double v) {
     return __hiloint2double(hi, lo);
 }
 
-// in-place 8-point Walsh-Hadamard butterfly on natural-order data
-__device__ inline void wht8(double v[8]) {
-#pragma unroll
-    for (int h = 1; h < 8; h <<= 1)
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-            if (!(i & h)) {
-                const double a = v[i], b = v[i + h];
-                v[i] = a + b;
-                v[i + h] = a - b;
-            }
+// 2-D Walsh-Hadamard butterfly over the 4 in-plane nodes (index lx + 2 ly); self-inverse up to 1/4
+__device__ inline void wht4(double v[4]) {
+    const double a = v[0] + v[1], b = v[0] - v[1], c = v[2] + v[3], d = v[2] - v[3];
+    v[0] = a + c;
+    v[1] = b + d;
+    v[2] = a - c;
+    v[3] = b - d;
 }
 
-// f = KE * u for one element; u, f indexed [natural node m][component]
-__device__ inline void sym_ke_apply(const SymKE &S, double u[3][8], double f[3][8]) {
-#pragma unroll
-    for (int c = 0; c < 3; c++) wht8(u[c]);
+// The packed blocks live in constant memory so that they are fetched with SCALAR
+// loads (s_load -> SGPR operands of v_fma_f64: no vector registers, no LDS).  A
+// small pool of slots lets several solver contexts (different KE) coexist.
+constexpr int SYMKE_SLOTS = 16, SYMKE_STRIDE = 40;
+__constant__ double c_symB[SYMKE_SLOTS * SYMKE_STRIDE];
+
+struct SymSlots {
+    double key[SYMKE_SLOTS][SYMKE_N];
+    int refs[SYMKE_SLOTS];
+};
+inline SymSlots &sym_slots() {
+    static SymSlots s = {};
+    return s;
+}
+// returns a slot holding `sk` (shared between equal matrices), or -1 if the pool is exhausted
+inline int sym_slot_acquire(const SymKE &sk) {
+    SymSlots &S = sym_slots();
+    for (int i = 0; i < SYMKE_SLOTS; i++)
+        if (S.refs[i] > 0 && std::memcmp(S.key[i], sk.a, sizeof(sk.a)) == 0) {
+            S.refs[i]++;
+            return i;
+        }
+    for (int i = 0; i < SYMKE_SLOTS; i++)
+        if (S.refs[i] == 0) {
+            if (hipMemcpyToSymbol(HIP_SYMBOL(c_symB), sk.a, sizeof(sk.a), sizeof(double) * i * SYMKE_STRIDE) != hipSuccess)
+                return -1;
+            std::memcpy(S.key[i], sk.a, sizeof(sk.a));
+            S.refs[i] = 1;
+            return i;
+        }
+    return -1;
+}
+inline void sym_slot_release(int i) {
+    if (i >= 0 && sym_slots().refs[i] > 0) sym_slots().refs[i]--;
+}
+
+// fhat = B uhat for one element in the Walsh-Hadamard basis; [component][p], p = px + 2 py + 4 pz.
+__device__ inline void sym_ke_blocks(const double *B, const double u[3][8], double f[3][8]) {
 #pragma unroll
     for (int q = 0; q < 8; q++) {
-        const double vx = u[0][q ^ 1], vy = u[1][q ^ 2], vz = u[2][q ^ 4];
-        f[0][q ^ 1] = fma(S.B[q * 9 + 0], vx, fma(S.B[q * 9 + 1], vy, S.B[q * 9 + 2] * vz));
-        f[1][q ^ 2] = fma(S.B[q * 9 + 3], vx, fma(S.B[q * 9 + 4], vy, S.B[q * 9 + 5] * vz));
-        f[2][q ^ 4] = fma(S.B[q * 9 + 6], vx, fma(S.B[q * 9 + 7], vy, S.B[q * 9 + 8] * vz));
-    }
+        const double v[3] = {u[0][q ^ 1], u[1][q ^ 2], u[2][q ^ 4]};
 #pragma unroll
-    for (int c = 0; c < 3; c++) wht8(f[c]);
+        for (int r = 0; r < 3; r++) {
+            double acc = 0.0;
+            bool first = true;
+#pragma unroll
+            for (int s = 0; s < 3; s++) {
+                const int id = symke_idx(q, r, s);
+                if (id >= 0) {
+                    acc = first ? B[id] * v[s] : fma(B[id], v[s], acc);
+                    first = false;
+                }
+            }
+            f[r][q ^ (1 << r)] = acc;
+        }
+    }
 }
 
 constexpr int TILE = 16;             // threads per tile edge
@@ -105,51 +177,60 @@ constexpr int TOUT = TILE - 1;       // node columns produced per tile edge
 constexpr int TSTG = TILE + 1;       // staged node columns per tile edge
 constexpr int STG_N = TSTG * TSTG * 3;
 
+// per-launch constants that do not depend on the epilogue
+struct TileArgs {
+    int nx, ny, nzl, ex, ey, ezl, own_lo, own_hi, kz;
+    const double *E;           // [stored elements]
+    const uint8_t *mask;       // per node clamped-dof bits (may be null)
+    const uint8_t *colmask;    // per node COLUMN: OR of mask over the planes (may be null)
+    int slot_off;              // offset of the packed SymKE inside c_symB
+};
+
 template <int EPI>
-__global__ __launch_bounds__(TILE * TILE) void k_matfree_tile(Geom g, const double *__restrict__ E,
-                                                             const uint8_t *__restrict__ mask, SymKE S, NodeArgs a,
-                                                             int KZ) {
+__global__ __launch_bounds__(TILE * TILE, 3) void k_matfree_tile(TileArgs t, NodeArgs a) {
     __shared__ double s_u[2][STG_N];
-    __shared__ double s_y[TILE * TILE * 6];
+    __shared__ double s_y[TILE * TILE * 3];
     const int tid = threadIdx.x;
     const int tx = tid & (TILE - 1), ty = tid / TILE;
     const int bx = blockIdx.x * TOUT, by = blockIdx.y * TOUT;
-    const int kz0 = g.own_lo + blockIdx.z * KZ;
-    const int kz1 = min(kz0 + KZ - 1, g.own_hi);
+    const int kz0 = t.own_lo + blockIdx.z * t.kz;
+    const int kz1 = min(kz0 + t.kz - 1, t.own_hi);
     const int nsteps = kz1 - kz0 + 2;  // element layers kz0-1 .. kz1
     const int ei = bx - 1 + tx, ej = by - 1 + ty;
-    const bool elem_ok = ei >= 0 && ei < g.ex && ej >= 0 && ej < g.ey;
-    const bool node_ok = tx >= 1 && ty >= 1 && ei < g.nx && ej < g.ny;
-    const long plane = g.plane();
+    const bool elem_ok = ei >= 0 && ei < t.ex && ej >= 0 && ej < t.ey;
+    const bool node_ok = tx >= 1 && ty >= 1 && ei < t.nx && ej < t.ny;
+    const long plane = (long)t.nx * t.ny;
     const double *__restrict__ x = a.x;
 
-    // staging slots of this thread: flat index f -> (row, node column, component)
-    int st_off[4];   // offset inside a node plane (doubles), -1 = outside the domain
-    int st_node[4];  // node offset inside a plane
+    // ---- staging slots of this thread: flat index f -> (row, node column, component)
+    int st_off[4];        // offset inside a node plane (doubles), -1 = outside the domain
+    unsigned st_cm = 0;   // bit s set: slot s belongs to a column with a clamped dof somewhere
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         const int f = tid + s * TILE * TILE;
         st_off[s] = -1;
-        st_node[s] = 0;
         if (f < STG_N) {
             const int r = f / (TSTG * 3), c = f % (TSTG * 3);
             const int gi = bx - 1 + c / 3, gj = by - 1 + r;
-            if (gi >= 0 && gi < g.nx && gj >= 0 && gj < g.ny) {
-                st_node[s] = gi + g.nx * gj;
-                st_off[s] = 3 * st_node[s] + c % 3;
+            if (gi >= 0 && gi < t.nx && gj >= 0 && gj < t.ny) {
+                st_off[s] = 3 * (gi + t.nx * gj) + c % 3;
+                if (t.colmask && ((t.colmask[gi + t.nx * gj] >> (c % 3)) & 1u)) st_cm |= 1u << s;
             }
         }
     }
     auto load_plane = [&](int p, double v[4]) {
-        const bool pok = p >= 0 && p < g.nzl;
+        const bool pok = p >= 0 && p < t.nzl;
+        const double *__restrict__ xp = x + 3 * plane * p;
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-            double t = 0.0;
+            double w = 0.0;
             if (pok && st_off[s] >= 0) {
-                t = x[3 * plane * p + st_off[s]];
-                if (mask && ((mask[plane * p + st_node[s]] >> (st_off[s] % 3)) & 1u)) t = 0.0;
+                w = xp[st_off[s]];
+                if ((st_cm >> s) & 1u) {  // rare: only columns that carry a Dirichlet condition
+                    if ((t.mask[plane * p + st_off[s] / 3] >> (st_off[s] % 3)) & 1u) w = 0.0;
+                }
             }
-            v[s] = t;
+            v[s] = w;
         }
     };
     auto store_plane = [&](int buf, const double v[4]) {
@@ -159,17 +240,22 @@ __global__ __launch_bounds__(TILE * TILE) void k_matfree_tile(Geom g, const doub
             if (f < STG_N) s_u[buf][f] = v[s];
         }
     };
-    // the 4 in-plane nodes of this thread's element, natural order (lx + 2 ly)
+    // the 4 in-plane nodes of this thread's element, natural order (lx + 2 ly), 2-D transformed
     const int o00 = (ty * TSTG + tx) * 3, o10 = o00 + 3, o01 = o00 + TSTG * 3, o11 = o01 + 3;
-    auto read_nodes = [&](int buf, double u[3][8], int zoff) {
+    auto read_plane_wht = [&](int buf, double U[3][4]) {
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            u[c][zoff + 0] = s_u[buf][o00 + c];
-            u[c][zoff + 1] = s_u[buf][o10 + c];
-            u[c][zoff + 2] = s_u[buf][o01 + c];
-            u[c][zoff + 3] = s_u[buf][o11 + c];
+            U[c][0] = s_u[buf][o00 + c];
+            U[c][1] = s_u[buf][o10 + c];
+            U[c][2] = s_u[buf][o01 + c];
+            U[c][3] = s_u[buf][o11 + c];
+            wht4(U[c]);
         }
     };
+
+    // own output node column: epilogue operands are prefetched one step ahead
+    const long ncol = node_ok ? (long)ei + (long)t.nx * ej : 0;
+    const unsigned own_cm = (node_ok && t.colmask) ? t.colmask[ncol] : 0u;
 
     double pre[4];
     load_plane(kz0 - 1, pre);
@@ -177,87 +263,92 @@ __global__ __launch_bounds__(TILE * TILE) void k_matfree_tile(Geom g, const doub
     load_plane(kz0, pre);
     store_plane(1, pre);
     __syncthreads();
-    double ubot[3][4];
-    {
-        double tmp[3][8];
-        read_nodes(0, tmp, 0);
+    double Ub[3][4];
+    read_plane_wht(0, Ub);
+    double Cy[3][4];
 #pragma unroll
-        for (int c = 0; c < 3; c++)
+    for (int c = 0; c < 3; c++)
 #pragma unroll
-            for (int m = 0; m < 4; m++) ubot[c][m] = tmp[c][m];
-    }
-    double carry[3] = {0.0, 0.0, 0.0};
+        for (int m = 0; m < 4; m++) Cy[c][m] = 0.0;
     double pdot = 0.0;
 
     for (int s = 0; s < nsteps; s++) {
-        const int el = kz0 - 1 + s;  // element layer; bottom node plane el, top el+1
-        double u[3][8], f[3][8];
-#pragma unroll
-        for (int c = 0; c < 3; c++)
-#pragma unroll
-            for (int m = 0; m < 4; m++) u[c][m] = ubot[c][m];
-        read_nodes((s + 1) & 1, u, 4);
-#pragma unroll
-        for (int c = 0; c < 3; c++)
-#pragma unroll
-            for (int m = 0; m < 4; m++) ubot[c][m] = u[c][4 + m];
+        const int el = kz0 - 1 + s;  // element layer; bottom node plane el, top plane el+1
         const bool more = s + 1 < nsteps;
-        if (more) load_plane(el + 2, pre);  // prefetch, consumed after the compute below
-
+        const bool outp = s >= 1 && node_ok;
+        // ---- issue the long-latency loads of this step first
+        if (more) load_plane(el + 2, pre);
         double Ee = 0.0;
-        if (elem_ok && el >= 0 && el < g.ezl) Ee = E[(long)ei + (long)g.ex * (ej + (long)g.ey * el)];
-        sym_ke_apply(S, u, f);
-        // nodal partial sums at this thread's node column: own element + left neighbour (DPP)
-        double sB0[3], sB1[3], sT0[3], sT1[3];
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const double f0 = Ee * f[c][0], f1 = Ee * f[c][1], f2 = Ee * f[c][2], f3 = Ee * f[c][3];
-            const double f4 = Ee * f[c][4], f5 = Ee * f[c][5], f6 = Ee * f[c][6], f7 = Ee * f[c][7];
-            sB0[c] = f0 + dpp_row_shr1(f1);  // node (ei, ej  , el  )
-            sB1[c] = f2 + dpp_row_shr1(f3);  // node (ei, ej+1, el  )
-            sT0[c] = f4 + dpp_row_shr1(f5);  // node (ei, ej  , el+1)
-            sT1[c] = f6 + dpp_row_shr1(f7);  // node (ei, ej+1, el+1)
-        }
-        // y-combination: pass the upper-row sums to the thread above
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            s_y[tid * 6 + c] = sB1[c];
-            s_y[tid * 6 + 3 + c] = sT1[c];
-        }
-        __syncthreads();
-        double yB[3], yT[3];
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const double b1 = ty >= 1 ? s_y[(tid - TILE) * 6 + c] : 0.0;
-            const double t1 = ty >= 1 ? s_y[(tid - TILE) * 6 + 3 + c] : 0.0;
-            yB[c] = carry[c] + (sB0[c] + b1);
-            yT[c] = sT0[c] + t1;
-        }
-        if (s >= 1 && node_ok) {
-            const long n = (long)ei + (long)g.nx * ej + plane * el;
-            const unsigned m = mask ? mask[n] : 0u;
+        if (elem_ok && el >= 0 && el < t.ezl) Ee = t.E[(long)ei + (long)t.ex * (ej + (long)t.ey * el)];
+        const long nq = 3 * (ncol + plane * el);
+        double xo[3] = {0, 0, 0}, bo[3] = {0, 0, 0}, dd[3] = {0, 0, 0}, di[3] = {0, 0, 0};
+        if (outp) {
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const long q = n * 3 + c;
-                const double xq = x[q];
-                const double y = ((m >> c) & 1u) ? xq : yB[c];
-                if (EPI == EPI_APPLY) {
-                    a.out[q] = y;
-                } else if (EPI == EPI_RESID) {
-                    a.out[q] = a.b[q] - y;
-                } else if (EPI == EPI_CHEB) {
-                    const double res = a.b[q] - y;
-                    const double dn = a.c1 * a.d[q] + a.c2 * (a.dinv[q] * res);
-                    a.d[q] = dn;
-                    a.out[q] = xq + dn;
-                } else {
-                    a.out[q] = y;
-                    pdot = fma(xq, y, pdot);
+                if (EPI != EPI_RESID || own_cm) xo[c] = x[nq + c];
+                if (EPI == EPI_RESID || EPI == EPI_CHEB) bo[c] = a.b[nq + c];
+                if (EPI == EPI_CHEB) {
+                    dd[c] = a.d[nq + c];
+                    di[c] = a.dinv[nq + c];
                 }
             }
         }
+        // ---- element in the Walsh-Hadamard basis
+        double Ut[3][4], u[3][8], f[3][8];
+        read_plane_wht((s + 1) & 1, Ut);
 #pragma unroll
-        for (int c = 0; c < 3; c++) carry[c] = yT[c];
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                u[c][m] = Ub[c][m] + Ut[c][m];
+                u[c][m + 4] = Ub[c][m] - Ut[c][m];
+                Ub[c][m] = Ut[c][m];
+            }
+        // opaque offset: keeps the 33 scalar loads inside the loop instead of 66 live SGPRs
+        int boff;
+        asm volatile("s_mov_b32 %0, %1" : "=s"(boff) : "s"(t.slot_off));
+        sym_ke_blocks(c_symB + boff, u, f);
+        // ---- back to the two planes; the upper plane's part is carried (still transformed)
+        double P[3][4];
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const double sum = f[c][m] + f[c][m + 4], dif = f[c][m] - f[c][m + 4];
+                P[c][m] = fma(Ee, sum, Cy[c][m]);
+                Cy[c][m] = Ee * dif;
+            }
+        double s0[3], s1[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            wht4(P[c]);  // nodal contributions of this element column to plane el
+            s0[c] = P[c][0] + dpp_row_shr1(P[c][1]);  // node (ei, ej  ): own + left element
+            s1[c] = P[c][2] + dpp_row_shr1(P[c][3]);  // node (ei, ej+1)
+            s_y[tid * 3 + c] = s1[c];
+        }
+        __syncthreads();
+        if (outp) {
+            unsigned m = 0;
+            if (own_cm) m = t.mask[ncol + plane * el];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                double y = s0[c] + s_y[(tid - TILE) * 3 + c];
+                if ((m >> c) & 1u) y = xo[c];
+                const long q = nq + c;
+                if (EPI == EPI_APPLY) {
+                    a.out[q] = y;
+                } else if (EPI == EPI_RESID) {
+                    a.out[q] = bo[c] - y;
+                } else if (EPI == EPI_CHEB) {
+                    const double dn = a.c1 * dd[c] + a.c2 * (di[c] * (bo[c] - y));
+                    a.d[q] = dn;
+                    a.out[q] = xo[c] + dn;
+                } else {
+                    a.out[q] = y;
+                    pdot = fma(xo[c], y, pdot);
+                }
+            }
+        }
         if (more) store_plane(s & 1, pre);
         __syncthreads();
     }

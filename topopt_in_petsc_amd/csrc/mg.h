@@ -26,7 +26,8 @@ struct Level {
     double lam;             // estimate / bound of lambda_max(D^-1 A)
     double *b, *x, *x2, *r, *d;
     bool use_tile = false;  // DOF == 3 matrix-free level with a box-symmetric KE: tuned kernel
-    SymKE sym;
+    int sym_slot = -1;                // slot of the packed SymKE in constant memory
+    const uint8_t *colmask = nullptr; // [dev] per node column: OR of mask over z
     long ndof() const { return (long)DOF * g.nodes(); }
     long own_off() const { return (long)DOF * g.plane() * g.own_lo; }
     long own_n() const { return (long)DOF * g.owned_nodes(); }
@@ -242,8 +243,9 @@ struct MGSolver {
             if (kz > planes) kz = planes;
             const int tz = (planes + kz - 1) / kz;
             last_nblocks = tx * ty * tz;
-            hipLaunchKernelGGL((k_matfree_tile<EPI>), dim3(tx, ty, tz), dim3(TILE * TILE), 0, grid->stream, L.g, L.E,
-                               L.mask, L.sym, a, kz);
+            TileArgs ta{L.g.nx, L.g.ny, L.g.nzl, L.g.ex, L.g.ey, L.g.ezl, L.g.own_lo, L.g.own_hi, kz,
+                        L.E, L.mask, L.colmask, L.sym_slot * SYMKE_STRIDE};
+            hipLaunchKernelGGL((k_matfree_tile<EPI>), dim3(tx, ty, tz), dim3(TILE * TILE), 0, grid->stream, ta, a);
             bytes = 16.0 * DOF * nown + 8.0 * L.g.own_elems();
             flops = 2.0 * 576 * (double)L.g.own_elems();
         } else if (L.kind == LV_MATFREE) {

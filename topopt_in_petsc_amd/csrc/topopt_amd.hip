@@ -136,6 +136,7 @@ struct tp_elasticity {
     double *d_KE, *d_M;      // element matrix, 8 child matrices (level 0 -> 1 fast path)
     double *d_E;             // SIMP moduli, own + ghost-above layer
     uint8_t *d_mask;         // clamped-dof bits per local node
+    uint8_t *d_colmask;      // OR of d_mask over the planes of a node column
     std::vector<uint8_t> h_mask;
     int *d_flagged;          // level-1 elements touching clamped nodes
     int nflagged;
@@ -187,6 +188,7 @@ extern "C" int tp_elasticity_create(tp_elasticity **out, tp_grid *g, const tp_so
     e->have_bc = e->assembled = false;
     e->d_flagged = nullptr;
     e->nflagged = 0;
+    e->d_colmask = nullptr;
     hex8_stiffness_box(g->o.hx, g->o.hy, g->o.hz, o->nu, e->KE);
     std::vector<double> M(8 * 576);
     host_child_matrices(e->KE, M.data());
@@ -210,8 +212,13 @@ extern "C" int tp_elasticity_create(tp_elasticity **out, tp_grid *g, const tp_so
         L.S = L.Kel = nullptr;
         if (l == 0) {
             // tuned kernel needs the reflection symmetry of a box element (always true here)
-            const double asym = make_sym_ke(e->KE, &L.sym);
-            L.use_tile = asym < 1e-12 && !getenv("TP_NO_TILE");
+            SymKE sk;
+            const double asym = make_sym_ke(e->KE, &sk);
+            L.sym_slot = (asym < 1e-12 && !getenv("TP_NO_TILE")) ? sym_slot_acquire(sk) : -1;
+            TP_HIP(hipMalloc((void **)&e->d_colmask, (size_t)q.plane()));
+            TP_HIP(hipMemset(e->d_colmask, 0, (size_t)q.plane()));
+            L.colmask = e->d_colmask;
+            L.use_tile = L.sym_slot >= 0;
         }
         if (l > 0) {
             TP_HIP(hipMalloc((void **)&L.S, sizeof(double) * 81 * (size_t)L.ndof()));
@@ -225,9 +232,10 @@ extern "C" int tp_elasticity_create(tp_elasticity **out, tp_grid *g, const tp_so
 extern "C" int tp_elasticity_destroy(tp_elasticity *e) {
     if (!e) return TP_OK;
     (void)hipStreamSynchronize(e->grid->stream);
+    sym_slot_release(e->mg.lv[0].sym_slot);
     e->mg.free_levels();
     for (void *p : {(void *)e->d_KE, (void *)e->d_M, (void *)e->d_E, (void *)e->d_mask, (void *)e->d_bN, (void *)e->d_N,
-                    (void *)e->d_flagged})
+                    (void *)e->d_flagged, (void *)e->d_colmask})
         (void)hipFree(p);
     delete e;
     return TP_OK;
@@ -245,6 +253,11 @@ extern "C" int tp_elasticity_set_bc(tp_elasticity *e, const double *N) {
     e->h_mask.resize((size_t)nn);
     TP_HIP(hipMemcpyAsync(e->h_mask.data(), e->d_mask, (size_t)nn, hipMemcpyDeviceToHost, g->stream));
     TP_HIP(hipStreamSynchronize(g->stream));
+    {
+        std::vector<uint8_t> cm((size_t)q.plane(), 0);
+        for (long n = 0; n < nn; n++) cm[(size_t)(n % q.plane())] |= e->h_mask[(size_t)n];
+        TP_HIP(hipMemcpy(e->d_colmask, cm.data(), cm.size(), hipMemcpyHostToDevice));
+    }
     // level-1 elements whose 27 fine nodes include a clamped one take the generic Galerkin path
     std::vector<int> fl;
     if (e->mg.nlv > 1) {
