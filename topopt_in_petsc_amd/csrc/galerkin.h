@@ -199,3 +199,74 @@ __global__ __launch_bounds__(BLK) void k_elem_to_dia(Geom g, const double *__res
         for (int r = 0; r < 3; r++) dinv[n * 3 + r] = 1.0 / acc[r * 3 + r];
     }
 }
+
+// Jacobi inverse diagonal straight from the coarse element matrices (levels whose
+// operator is applied matrix-free): thread = owned node
+__global__ __launch_bounds__(BLK) void k_elem_diag(Geom g, const double *__restrict__ Kel, double *__restrict__ dinv) {
+    const long nE = g.elems_stored();
+    const long plane = g.plane();
+    const long t = blockIdx.x * (long)BLK + threadIdx.x;
+    if (t >= g.owned_nodes()) return;
+    const int k = g.own_lo + (int)(t / plane);
+    const int rem = (int)(t % plane);
+    const int j = rem / g.nx, i = rem % g.nx;
+    const long n = t + plane * g.own_lo;
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int I = 0; I < 8; I++) {
+        const int ei = i - c_LX[I], ej = j - c_LY[I], ek = k - c_LZ[I];
+        if (ei < 0 || ei >= g.ex || ej < 0 || ej >= g.ey || ek < 0 || ek >= g.ezl) continue;
+        const long el = (long)ei + (long)g.ex * (ej + (long)g.ey * ek);
+#pragma unroll
+        for (int r = 0; r < 3; r++) acc[r] += Kel[(long)((3 * I + r) * 25) * nE + el];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++) dinv[n * 3 + r] = 1.0 / acc[r];
+}
+
+// ---- Dirichlet correction of the matrix-free level-1 operator -----------------
+// dK[f][entry] = K_E (exact Galerkin element matrix, with N K N + D) - sum_c E_c M_c
+// for the listed (flagged) coarse elements; thread = (flagged element, entry)
+__global__ __launch_bounds__(BLK) void k_macro_delta(Geom gf, Geom gc, const double *__restrict__ E,
+                                                     const double *__restrict__ M, const double *__restrict__ Kel,
+                                                     const int *__restrict__ list, int nlist, double *__restrict__ dK) {
+    const long t = blockIdx.x * (long)BLK + threadIdx.x;
+    if (t >= (long)nlist * 576) return;
+    const int f = (int)(t / 576), e = (int)(t % 576);
+    const long ce = list[f];
+    const int I = (int)(ce % gc.ex), J = (int)((ce / gc.ex) % gc.ey), K = (int)(ce / ((long)gc.ex * gc.ey));
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const int i = 2 * I + (c & 1), j = 2 * J + ((c >> 1) & 1), k = 2 * K + ((c >> 2) & 1);
+        s = fma(E[(long)i + (long)gf.ex * (j + (long)gf.ey * k)], M[c * 576 + e], s);
+    }
+    dK[t] = Kel[(long)e * gc.elems_stored() + ce] - s;
+}
+// corr[node] = sum over the flagged elements around it of dK_E[rows of node] x_E ; thread = affected node.
+// adj[8*a + I] = index of the flagged element in which the node is corner I, or -1.
+__global__ __launch_bounds__(BLK) void k_macro_corr(Geom g, const double *__restrict__ dK, const int *__restrict__ nodes,
+                                                    const int *__restrict__ adj, const int *__restrict__ list, int nnodes,
+                                                    const double *__restrict__ x, double *__restrict__ corr) {
+    const int a = blockIdx.x * BLK + threadIdx.x;
+    if (a >= nnodes) return;
+    const long n = nodes[a];
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int I = 0; I < 8; I++) {
+        const int f = adj[8 * a + I];
+        if (f < 0) continue;
+        const long ce = list[f];
+        const int ei = (int)(ce % g.ex), ej = (int)((ce / g.ex) % g.ey), ek = (int)(ce / ((long)g.ex * g.ey));
+        const double *__restrict__ D = dK + (long)f * 576 + (3 * I) * 24;
+        for (int J = 0; J < 8; J++) {
+            const long nb = (long)(ei + c_LX[J]) + (long)g.nx * ((ej + c_LY[J]) + (long)g.ny * (ek + c_LZ[J]));
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const double xv = x[3 * nb + c];
+#pragma unroll
+                for (int r = 0; r < 3; r++) acc[r] = fma(D[r * 24 + 3 * J + c], xv, acc[r]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++) corr[3 * n + r] = acc[r];
+}

@@ -184,10 +184,24 @@ struct TileArgs {
     const uint8_t *mask;       // per node clamped-dof bits (may be null)
     const uint8_t *colmask;    // per node COLUMN: OR of mask over the planes (may be null)
     int slot_off;              // offset of the packed SymKE inside c_symB
+    // MACRO (level-1 Galerkin operator applied from the fine densities):
+    int fex, fey;              // FINE element counts per row / column (children indexing)
+    const double *corr;        // [level-1 dofs] Dirichlet correction added to y (k_macro_corr), or null
 };
 
-template <int EPI>
-__global__ __launch_bounds__(TILE * TILE, 3) void k_matfree_tile(TileArgs t, NodeArgs a) {
+// MACRO = 0: fine level, one element per thread and step.
+// MACRO = 1: level 1.  The Galerkin operator P^T A_0 P is never stored: inside a
+//   coarse element the interpolated field is trilinear, so in the Walsh-Hadamard
+//   basis the 8 children see  uhat_child = R_c D uhat  with D = diag(2^-|p|) and R_c a
+//   product of per-axis maps (a0, a1) -> (a0 - s a1, a1), s = +-1 the child's side:
+//       y = T^T D [ sum_c R_c^T E_c B R_c ] D T u
+//   (12 adds per component in, 45 block ops, 12 adds out per child).  Bytes per
+//   apply drop from 1944 B per coarse node (stored stencil) to the 8 child densities.
+//   This kernel applies the operator WITHOUT Dirichlet conditions; the (few) coarse
+//   elements that contain a clamped fine node differ from it by a stored 24x24
+//   matrix dK_E whose action k_macro_corr precomputes into `corr`.
+template <int EPI, int MACRO>
+__global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(TileArgs t, NodeArgs a) {
     __shared__ double s_u[2][STG_N];
     __shared__ double s_y[TILE * TILE * 3];
     const int tid = threadIdx.x;
@@ -279,9 +293,9 @@ __global__ __launch_bounds__(TILE * TILE, 3) void k_matfree_tile(TileArgs t, Nod
         // ---- issue the long-latency loads of this step first
         if (more) load_plane(el + 2, pre);
         double Ee = 0.0;
-        if (elem_ok && el >= 0 && el < t.ezl) Ee = t.E[(long)ei + (long)t.ex * (ej + (long)t.ey * el)];
+        if (!MACRO && elem_ok && el >= 0 && el < t.ezl) Ee = t.E[(long)ei + (long)t.ex * (ej + (long)t.ey * el)];
         const long nq = 3 * (ncol + plane * el);
-        double xo[3] = {0, 0, 0}, bo[3] = {0, 0, 0}, dd[3] = {0, 0, 0}, di[3] = {0, 0, 0};
+        double xo[3] = {0, 0, 0}, bo[3] = {0, 0, 0}, dd[3] = {0, 0, 0}, di[3] = {0, 0, 0}, co[3] = {0, 0, 0};
         if (outp) {
 #pragma unroll
             for (int c = 0; c < 3; c++) {
@@ -291,6 +305,7 @@ __global__ __launch_bounds__(TILE * TILE, 3) void k_matfree_tile(TileArgs t, Nod
                     dd[c] = a.d[nq + c];
                     di[c] = a.dinv[nq + c];
                 }
+                if (MACRO && t.corr) co[c] = t.corr[nq + c];
             }
         }
         // ---- element in the Walsh-Hadamard basis
@@ -307,7 +322,61 @@ __global__ __launch_bounds__(TILE * TILE, 3) void k_matfree_tile(TileArgs t, Nod
         // opaque offset: keeps the 33 scalar loads inside the loop instead of 66 live SGPRs
         int boff;
         asm volatile("s_mov_b32 %0, %1" : "=s"(boff) : "s"(t.slot_off));
-        sym_ke_blocks(c_symB + boff, u, f);
+        if (!MACRO) {
+            sym_ke_blocks(c_symB + boff, u, f);
+        } else {
+            const bool eok = elem_ok && el >= 0 && el < t.ezl;
+            Ee = eok ? 1.0 : 0.0;  // children moduli are applied inside
+            {
+                // D: scale mode p by 2^-|p|
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+#pragma unroll
+                    for (int p = 1; p < 8; p++) u[c][p] *= (p == 7 ? 0.125 : ((p == 3 || p == 5 || p == 6) ? 0.25 : 0.5));
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+#pragma unroll
+                    for (int p = 0; p < 8; p++) f[c][p] = 0.0;
+#pragma unroll 1
+                for (int ch = 0; ch < 8; ch++) {
+                    const double sx = (ch & 1) ? 1.0 : -1.0, sy = (ch & 2) ? 1.0 : -1.0, sz = (ch & 4) ? 1.0 : -1.0;
+                    double Ec = 0.0;
+                    if (eok)
+                        Ec = t.E[(long)(2 * ei + (ch & 1)) + (long)t.fex * ((2 * ej + ((ch >> 1) & 1)) + (long)t.fey * (2 * el + (ch >> 2)))];
+                    double w[3][8], g[3][8];
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+#pragma unroll
+                        for (int p = 0; p < 8; p++) w[c][p] = u[c][p];
+#pragma unroll
+                        for (int p = 0; p < 8; p += 2) w[c][p] -= sx * w[c][p + 1];
+#pragma unroll
+                        for (int p = 0; p < 8; p++)
+                            if (!(p & 2)) w[c][p] -= sy * w[c][p + 2];
+#pragma unroll
+                        for (int p = 0; p < 4; p++) w[c][p] -= sz * w[c][p + 4];
+                    }
+                    sym_ke_blocks(c_symB + boff, w, g);
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        // R_c^T: (f0, f1) -> (f0, f1 - s f0) per axis, then accumulate with the child's modulus
+#pragma unroll
+                        for (int p = 0; p < 4; p++) g[c][p + 4] -= sz * g[c][p];
+#pragma unroll
+                        for (int p = 0; p < 8; p++)
+                            if (!(p & 2)) g[c][p + 2] -= sy * g[c][p];
+#pragma unroll
+                        for (int p = 0; p < 8; p += 2) g[c][p + 1] -= sx * g[c][p];
+#pragma unroll
+                        for (int p = 0; p < 8; p++) f[c][p] = fma(Ec, g[c][p], f[c][p]);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+#pragma unroll
+                    for (int p = 1; p < 8; p++) f[c][p] *= (p == 7 ? 0.125 : ((p == 3 || p == 5 || p == 6) ? 0.25 : 0.5));
+            }
+        }
         // ---- back to the two planes; the upper plane's part is carried (still transformed)
         double P[3][4];
 #pragma unroll
@@ -333,6 +402,7 @@ __global__ __launch_bounds__(TILE * TILE, 3) void k_matfree_tile(TileArgs t, Nod
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 double y = s0[c] + s_y[(tid - TILE) * 3 + c];
+                if (MACRO) y += co[c];
                 if ((m >> c) & 1u) y = xo[c];
                 const long q = nq + c;
                 if (EPI == EPI_APPLY) {

@@ -9,7 +9,7 @@
 #include "operators.h"
 #include "matfree_tile.h"
 
-enum { LV_MATFREE = 0, LV_DIA = 1 };
+enum { LV_MATFREE = 0, LV_DIA = 1, LV_MACRO = 2 };
 
 template <int DOF>
 struct Level {
@@ -27,6 +27,15 @@ struct Level {
     double *b, *x, *x2, *r, *d;
     bool use_tile = false;  // DOF == 3 matrix-free level with a box-symmetric KE: tuned kernel
     int sym_slot = -1;                // slot of the packed SymKE in constant memory
+    // LV_MACRO (level 1 applied from the fine densities)
+    int fex = 0, fey = 0;             // fine element counts
+    // Dirichlet correction (elements containing a clamped fine node)
+    const double *dK = nullptr;       // [dev] nflag x 576
+    const int *flag_list = nullptr;   // [dev] flagged stored coarse elements
+    const int *corr_nodes = nullptr;  // [dev] affected owned nodes
+    const int *corr_adj = nullptr;    // [dev] 8 per affected node
+    int ncorr_nodes = 0;
+    double *corr = nullptr;           // [dev] level dofs, zero outside the affected nodes
     const uint8_t *colmask = nullptr; // [dev] per node column: OR of mask over z
     long ndof() const { return (long)DOF * g.nodes(); }
     long own_off() const { return (long)DOF * g.plane() * g.own_lo; }
@@ -244,10 +253,30 @@ struct MGSolver {
             const int tz = (planes + kz - 1) / kz;
             last_nblocks = tx * ty * tz;
             TileArgs ta{L.g.nx, L.g.ny, L.g.nzl, L.g.ex, L.g.ey, L.g.ezl, L.g.own_lo, L.g.own_hi, kz,
-                        L.E, L.mask, L.colmask, L.sym_slot * SYMKE_STRIDE};
-            hipLaunchKernelGGL((k_matfree_tile<EPI>), dim3(tx, ty, tz), dim3(TILE * TILE), 0, grid->stream, ta, a);
+                        L.E, L.mask, L.colmask, L.sym_slot * SYMKE_STRIDE, 0, 0, nullptr};
+            hipLaunchKernelGGL((k_matfree_tile<EPI, 0>), dim3(tx, ty, tz), dim3(TILE * TILE), 0, grid->stream, ta, a);
             bytes = 16.0 * DOF * nown + 8.0 * L.g.own_elems();
             flops = 2.0 * 576 * (double)L.g.own_elems();
+        } else if (DOF == 3 && L.kind == LV_MACRO) {
+            const int tx = (L.g.nx + TOUT - 1) / TOUT, ty = (L.g.ny + TOUT - 1) / TOUT;
+            const int planes = L.g.own_hi - L.g.own_lo + 1;
+            static const int kz_env = getenv("TP_MACRO_KZ") ? atoi(getenv("TP_MACRO_KZ")) : 0;
+            int kz = kz_env > 0 ? kz_env : (int)((long)planes * tx * ty / 768);
+            kz = kz < 4 ? 4 : (kz > 64 ? 64 : kz);
+            if (kz > planes) kz = planes;
+            const int tz = (planes + kz - 1) / kz;
+            last_nblocks = tx * ty * tz;
+            if (L.ncorr_nodes) {
+                hipLaunchKernelGGL(k_macro_corr, dim3((L.ncorr_nodes + BLK - 1) / BLK), dim3(BLK), 0, grid->stream, L.g,
+                                   L.dK, L.corr_nodes, L.corr_adj, L.flag_list, L.ncorr_nodes, a.x, L.corr);
+                count_launch(grid);
+            }
+            TileArgs ta{L.g.nx, L.g.ny, L.g.nzl, L.g.ex, L.g.ey, L.g.ezl, L.g.own_lo, L.g.own_hi, kz,
+                        L.E, nullptr, nullptr, L.sym_slot * SYMKE_STRIDE, L.fex, L.fey,
+                        L.ncorr_nodes ? L.corr : nullptr};
+            hipLaunchKernelGGL((k_matfree_tile<EPI, 1>), dim3(tx, ty, tz), dim3(TILE * TILE), 0, grid->stream, ta, a);
+            bytes = 16.0 * DOF * nown + 8.0 * 8.0 * L.g.own_elems();
+            flops = 2.0 * 576 * 8.0 * (double)L.g.own_elems();
         } else if (L.kind == LV_MATFREE) {
             MatfreeOp<DOF> o{L.KE, L.E, L.mask, L.g};
             hipLaunchKernelGGL((k_node<DOF, MatfreeOp<DOF>, EPI>), dim3(nb), dim3(BLK), 0, grid->stream, o, a);

@@ -139,6 +139,10 @@ struct tp_elasticity {
     uint8_t *d_colmask;      // OR of d_mask over the planes of a node column
     std::vector<uint8_t> h_mask;
     int *d_flagged;          // level-1 elements touching clamped nodes
+    int *d_flag_all;         // flagged level-1 elements incl. the ghost layer (matrix-free level 1)
+    int nflag_all;
+    int *d_corr_nodes, *d_corr_adj;
+    double *d_dK, *d_corr;
     int nflagged;
     double *d_bN;            // RHS .* N scratch
     double *d_N;             // copy of N (for the load masking of :542)
@@ -189,6 +193,9 @@ extern "C" int tp_elasticity_create(tp_elasticity **out, tp_grid *g, const tp_so
     e->d_flagged = nullptr;
     e->nflagged = 0;
     e->d_colmask = nullptr;
+    e->d_flag_all = e->d_corr_nodes = e->d_corr_adj = nullptr;
+    e->d_dK = e->d_corr = nullptr;
+    e->nflag_all = 0;
     hex8_stiffness_box(g->o.hx, g->o.hy, g->o.hz, o->nu, e->KE);
     std::vector<double> M(8 * 576);
     host_child_matrices(e->KE, M.data());
@@ -196,7 +203,8 @@ extern "C" int tp_elasticity_create(tp_elasticity **out, tp_grid *g, const tp_so
     Geom q = make_geom(g, 0);
     TP_HIP(hipMalloc((void **)&e->d_KE, sizeof(double) * 576));
     TP_HIP(hipMalloc((void **)&e->d_M, sizeof(double) * 8 * 576));
-    TP_HIP(hipMalloc((void **)&e->d_E, sizeof(double) * (size_t)q.elems_stored()));
+    TP_HIP(hipMalloc((void **)&e->d_E, sizeof(double) * (size_t)((long)q.ex * q.ey * (q.ez_own + 2))));
+    TP_HIP(hipMemset(e->d_E, 0, sizeof(double) * (size_t)((long)q.ex * q.ey * (q.ez_own + 2))));
     TP_HIP(hipMalloc((void **)&e->d_mask, (size_t)q.nodes()));
     TP_HIP(hipMalloc((void **)&e->d_bN, sizeof(double) * 3 * (size_t)q.nodes()));
     TP_HIP(hipMalloc((void **)&e->d_N, sizeof(double) * 3 * (size_t)q.nodes()));
@@ -220,9 +228,22 @@ extern "C" int tp_elasticity_create(tp_elasticity **out, tp_grid *g, const tp_so
             L.colmask = e->d_colmask;
             L.use_tile = L.sym_slot >= 0;
         }
+        if (l == 1 && e->mg.lv[0].use_tile && !getenv("TP_NO_MACRO")) {
+            // level 1 is applied from the fine densities (k_matfree_tile<.,1>): no stencil storage
+            L.kind = LV_MACRO;
+            L.use_tile = true;
+            L.sym_slot = e->mg.lv[0].sym_slot;
+            L.fex = q.ex;
+            L.fey = q.ey;
+            TP_HIP(hipMalloc((void **)&e->d_corr, sizeof(double) * (size_t)L.ndof()));
+            TP_HIP(hipMemset(e->d_corr, 0, sizeof(double) * (size_t)L.ndof()));
+            L.corr = e->d_corr;
+        }
         if (l > 0) {
-            TP_HIP(hipMalloc((void **)&L.S, sizeof(double) * 81 * (size_t)L.ndof()));
-            TP_HIP(hipMemset(L.S, 0, sizeof(double) * 81 * (size_t)L.ndof()));
+            if (L.kind == LV_DIA) {
+                TP_HIP(hipMalloc((void **)&L.S, sizeof(double) * 81 * (size_t)L.ndof()));
+                TP_HIP(hipMemset(L.S, 0, sizeof(double) * 81 * (size_t)L.ndof()));
+            }
             TP_HIP(hipMalloc((void **)&L.Kel, sizeof(double) * 576 * (size_t)L.g.elems_stored()));
         }
     }
@@ -235,7 +256,8 @@ extern "C" int tp_elasticity_destroy(tp_elasticity *e) {
     sym_slot_release(e->mg.lv[0].sym_slot);
     e->mg.free_levels();
     for (void *p : {(void *)e->d_KE, (void *)e->d_M, (void *)e->d_E, (void *)e->d_mask, (void *)e->d_bN, (void *)e->d_N,
-                    (void *)e->d_flagged, (void *)e->d_colmask})
+                    (void *)e->d_flagged, (void *)e->d_colmask, (void *)e->d_flag_all, (void *)e->d_corr_nodes,
+                    (void *)e->d_corr_adj, (void *)e->d_dK, (void *)e->d_corr})
         (void)hipFree(p);
     delete e;
     return TP_OK;
@@ -276,6 +298,69 @@ extern "C" int tp_elasticity_set_bc(tp_elasticity *e, const double *N) {
     (void)hipFree(e->d_flagged);
     e->d_flagged = nullptr;
     e->nflagged = (int)fl.size();
+    if (e->mg.nlv > 1 && e->mg.lv[1].kind == LV_MACRO) {
+        // matrix-free level 1: flagged elements incl. the ghost layer above (flags of the upper
+        // neighbour's first layer travel as doubles through the halo mechanism)
+        Level<3> &L1 = e->mg.lv[1];
+        Geom c = L1.g;
+        const long clay = (long)c.ex * c.ey;
+        std::vector<double> fl_d((size_t)c.elems_stored(), 0.0);
+        for (int id : fl) fl_d[(size_t)id] = 1.0;
+        if (g->has_comm) {
+            double *tmp;
+            TP_HIP(hipMalloc((void **)&tmp, sizeof(double) * fl_d.size()));
+            TP_HIP(hipMemcpy(tmp, fl_d.data(), sizeof(double) * fl_d.size(), hipMemcpyHostToDevice));
+            TP_TRY(exchange_segments(g, tmp, nullptr, nullptr, tmp + clay * c.ez_own, clay, 1, clay));
+            TP_HIP(hipStreamSynchronize(g->stream));
+            TP_HIP(hipMemcpy(fl_d.data(), tmp, sizeof(double) * fl_d.size(), hipMemcpyDeviceToHost));
+            (void)hipFree(tmp);
+        }
+        std::vector<int> fall, fidx((size_t)c.elems_stored(), -1);
+        for (size_t i = 0; i < fl_d.size(); i++)
+            if (fl_d[i] != 0.0) {
+                fidx[i] = (int)fall.size();
+                fall.push_back((int)i);
+            }
+        std::vector<int> cn, cadj;
+        for (int k = c.own_lo; k <= c.own_hi; k++)
+            for (int j = 0; j < c.ny; j++)
+                for (int i = 0; i < c.nx; i++) {
+                    int adj[8];
+                    bool any = false;
+                    for (int I = 0; I < 8; I++) {
+                        const int ei = i - h_LX[I], ej = j - h_LY[I], ek = k - h_LZ[I];
+                        adj[I] = -1;
+                        if (ei < 0 || ei >= c.ex || ej < 0 || ej >= c.ey || ek < 0 || ek >= c.ezl) continue;
+                        adj[I] = fidx[(size_t)(ei + (long)c.ex * (ej + (long)c.ey * ek))];
+                        any = any || adj[I] >= 0;
+                    }
+                    if (any) {
+                        cn.push_back((int)(i + (long)c.nx * (j + (long)c.ny * k)));
+                        cadj.insert(cadj.end(), adj, adj + 8);
+                    }
+                }
+        for (void *p : {(void *)e->d_flag_all, (void *)e->d_corr_nodes, (void *)e->d_corr_adj, (void *)e->d_dK}) (void)hipFree(p);
+        e->d_flag_all = e->d_corr_nodes = e->d_corr_adj = nullptr;
+        e->d_dK = nullptr;
+        e->nflag_all = (int)fall.size();
+        TP_HIP(hipMemset(e->d_corr, 0, sizeof(double) * (size_t)L1.ndof()));
+        if (!fall.empty()) {
+            TP_HIP(hipMalloc((void **)&e->d_flag_all, sizeof(int) * fall.size()));
+            TP_HIP(hipMemcpy(e->d_flag_all, fall.data(), sizeof(int) * fall.size(), hipMemcpyHostToDevice));
+            TP_HIP(hipMalloc((void **)&e->d_dK, sizeof(double) * 576 * fall.size()));
+        }
+        if (!cn.empty()) {
+            TP_HIP(hipMalloc((void **)&e->d_corr_nodes, sizeof(int) * cn.size()));
+            TP_HIP(hipMemcpy(e->d_corr_nodes, cn.data(), sizeof(int) * cn.size(), hipMemcpyHostToDevice));
+            TP_HIP(hipMalloc((void **)&e->d_corr_adj, sizeof(int) * cadj.size()));
+            TP_HIP(hipMemcpy(e->d_corr_adj, cadj.data(), sizeof(int) * cadj.size(), hipMemcpyHostToDevice));
+        }
+        L1.dK = e->d_dK;
+        L1.flag_list = e->d_flag_all;
+        L1.corr_nodes = e->d_corr_nodes;
+        L1.corr_adj = e->d_corr_adj;
+        L1.ncorr_nodes = (int)cn.size();
+    }
     if (e->nflagged) {
         TP_HIP(hipMalloc((void **)&e->d_flagged, sizeof(int) * fl.size()));
         TP_HIP(hipMemcpy(e->d_flagged, fl.data(), sizeof(int) * fl.size(), hipMemcpyHostToDevice));
@@ -300,8 +385,9 @@ extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, dou
     const long nel = q0.own_elems(), lay = (long)q0.ex * q0.ey;
     hipLaunchKernelGGL(k_simp, dim3(grid_for(nel)), dim3(BLK), 0, s, xPhys, Emin, Emax, penal, e->d_E, nel);
     count_launch(g, 16.0 * nel, 3.0 * nel);
-    // ghost layer above <- upper neighbour's first own layer
-    TP_TRY(exchange_segments(g, e->d_E, nullptr, nullptr, e->d_E + nel, lay, 1, lay));
+    // two ghost layers above <- upper neighbour's first own layers (level 1 is applied
+    // from the fine densities and reaches one coarse = two fine layers up)
+    TP_TRY(exchange_segments(g, e->d_E, nullptr, nullptr, e->d_E + nel, 2 * lay, 1, 2 * lay));
     TP_TRY(mg.setup_matfree_level(0, e->KE));
     for (int l = 1; l < mg.nlv; l++) {
         Level<3> &F = mg.lv[l - 1], &C = mg.lv[l];
@@ -324,8 +410,18 @@ extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, dou
         const long clay = (long)C.g.ex * C.g.ey;
         TP_TRY(exchange_segments(g, C.Kel, nullptr, nullptr, C.Kel + clay * C.g.ez_own, clay, 576, C.g.elems_stored()));
         const int gn = (int)((C.g.owned_nodes() + BLK - 1) / BLK);
-        hipLaunchKernelGGL(k_elem_to_dia, dim3(gn, 27), dim3(BLK), 0, s, C.g, C.Kel, C.S, C.dinv);
-        count_launch(g, 8.0 * (576.0 * C.g.elems_stored() + 243.0 * C.g.owned_nodes()), 9.0 * 64 * C.g.owned_nodes());
+        if (C.kind == LV_MACRO) {
+            if (e->nflag_all) {
+                hipLaunchKernelGGL(k_macro_delta, dim3((int)(((long)e->nflag_all * 576 + BLK - 1) / BLK)), dim3(BLK), 0, s,
+                                   F.g, C.g, e->d_E, e->d_M, C.Kel, e->d_flag_all, e->nflag_all, e->d_dK);
+                count_launch(g);
+            }
+            hipLaunchKernelGGL(k_elem_diag, dim3(gn), dim3(BLK), 0, s, C.g, C.Kel, C.dinv);
+            count_launch(g, 8.0 * (24.0 + 3.0) * C.g.owned_nodes(), 24.0 * C.g.owned_nodes());
+        } else {
+            hipLaunchKernelGGL(k_elem_to_dia, dim3(gn, 27), dim3(BLK), 0, s, C.g, C.Kel, C.S, C.dinv);
+            count_launch(g, 8.0 * (576.0 * C.g.elems_stored() + 243.0 * C.g.owned_nodes()), 9.0 * 64 * C.g.owned_nodes());
+        }
     }
     mg.ready = true;
     for (int l = 1; l < mg.nlv; l++) TP_TRY(mg.lanczos(l, mg.opt.nlanczos, &mg.lv[l].lam));
