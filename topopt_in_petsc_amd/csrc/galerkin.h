@@ -224,14 +224,14 @@ __global__ __launch_bounds__(BLK) void k_elem_diag(Geom g, const double *__restr
 }
 
 // ---- Dirichlet correction of the matrix-free level-1 operator -----------------
-// dK[f][entry] = K_E (exact Galerkin element matrix, with N K N + D) - sum_c E_c M_c
-// for the listed (flagged) coarse elements; thread = (flagged element, entry)
+// dK[entry][f] = K_E (exact Galerkin element matrix, with N K N + D) - sum_c E_c M_c
+// for the listed (flagged) coarse elements; thread = (entry, flagged element)
 __global__ __launch_bounds__(BLK) void k_macro_delta(Geom gf, Geom gc, const double *__restrict__ E,
                                                      const double *__restrict__ M, const double *__restrict__ Kel,
                                                      const int *__restrict__ list, int nlist, double *__restrict__ dK) {
     const long t = blockIdx.x * (long)BLK + threadIdx.x;
     if (t >= (long)nlist * 576) return;
-    const int f = (int)(t / 576), e = (int)(t % 576);
+    const int e = (int)(t / nlist), f = (int)(t % nlist);
     const long ce = list[f];
     const int I = (int)(ce % gc.ex), J = (int)((ce / gc.ex) % gc.ey), K = (int)(ce / ((long)gc.ex * gc.ey));
     double s = 0.0;
@@ -242,30 +242,39 @@ __global__ __launch_bounds__(BLK) void k_macro_delta(Geom gf, Geom gc, const dou
     }
     dK[t] = Kel[(long)e * gc.elems_stored() + ce] - s;
 }
-// corr[node] = sum over the flagged elements around it of dK_E[rows of node] x_E ; thread = affected node.
-// adj[8*a + I] = index of the flagged element in which the node is corner I, or -1.
-__global__ __launch_bounds__(BLK) void k_macro_corr(Geom g, const double *__restrict__ dK, const int *__restrict__ nodes,
-                                                    const int *__restrict__ adj, const int *__restrict__ list, int nnodes,
-                                                    const double *__restrict__ x, double *__restrict__ corr) {
+// tmp[r][f] = dK_E[row r] . x_E ; thread = (row r of 24, flagged element f), coalesced over f
+__global__ __launch_bounds__(BLK) void k_macro_corr_rows(Geom g, const double *__restrict__ dK,
+                                                         const int *__restrict__ list, int nlist,
+                                                         const double *__restrict__ x, double *__restrict__ tmp) {
+    const long t = blockIdx.x * (long)BLK + threadIdx.x;
+    if (t >= (long)nlist * 24) return;
+    const int r = (int)(t / nlist), f = (int)(t % nlist);
+    const long ce = list[f];
+    const int ei = (int)(ce % g.ex), ej = (int)((ce / g.ex) % g.ey), ek = (int)(ce / ((long)g.ex * g.ey));
+    double acc = 0.0;
+#pragma unroll
+    for (int J = 0; J < 8; J++) {
+        const long nb = (long)(ei + LXc(J)) + (long)g.nx * ((ej + LYc(J)) + (long)g.ny * (ek + LZc(J)));
+#pragma unroll
+        for (int c = 0; c < 3; c++) acc = fma(dK[(long)(r * 24 + 3 * J + c) * nlist + f], x[3 * nb + c], acc);
+    }
+    tmp[t] = acc;
+}
+// corr[node] = sum over the flagged elements around it; adj[8*a + I] = flagged index of the
+// element in which the node is corner I, or -1.  thread = affected node.
+__global__ __launch_bounds__(BLK) void k_macro_corr_gather(const int *__restrict__ nodes, const int *__restrict__ adj,
+                                                           int nnodes, const double *__restrict__ tmp,
+                                                           double *__restrict__ corr, int nlist) {
     const int a = blockIdx.x * BLK + threadIdx.x;
     if (a >= nnodes) return;
     const long n = nodes[a];
     double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
     for (int I = 0; I < 8; I++) {
         const int f = adj[8 * a + I];
         if (f < 0) continue;
-        const long ce = list[f];
-        const int ei = (int)(ce % g.ex), ej = (int)((ce / g.ex) % g.ey), ek = (int)(ce / ((long)g.ex * g.ey));
-        const double *__restrict__ D = dK + (long)f * 576 + (3 * I) * 24;
-        for (int J = 0; J < 8; J++) {
-            const long nb = (long)(ei + c_LX[J]) + (long)g.nx * ((ej + c_LY[J]) + (long)g.ny * (ek + c_LZ[J]));
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const double xv = x[3 * nb + c];
-#pragma unroll
-                for (int r = 0; r < 3; r++) acc[r] = fma(D[r * 24 + 3 * J + c], xv, acc[r]);
-            }
-        }
+        for (int r = 0; r < 3; r++) acc[r] += tmp[(long)(3 * I + r) * nlist + f];
     }
 #pragma unroll
     for (int r = 0; r < 3; r++) corr[3 * n + r] = acc[r];

@@ -34,7 +34,8 @@ struct Level {
     const int *flag_list = nullptr;   // [dev] flagged stored coarse elements
     const int *corr_nodes = nullptr;  // [dev] affected owned nodes
     const int *corr_adj = nullptr;    // [dev] 8 per affected node
-    int ncorr_nodes = 0;
+    int ncorr_nodes = 0, nflag = 0;
+    double *corr_tmp = nullptr;       // [dev] nflag x 24 element-row products
     double *corr = nullptr;           // [dev] level dofs, zero outside the affected nodes
     const uint8_t *colmask = nullptr; // [dev] per node column: OR of mask over z
     long ndof() const { return (long)DOF * g.nodes(); }
@@ -267,8 +268,11 @@ struct MGSolver {
             const int tz = (planes + kz - 1) / kz;
             last_nblocks = tx * ty * tz;
             if (L.ncorr_nodes) {
-                hipLaunchKernelGGL(k_macro_corr, dim3((L.ncorr_nodes + BLK - 1) / BLK), dim3(BLK), 0, grid->stream, L.g,
-                                   L.dK, L.corr_nodes, L.corr_adj, L.flag_list, L.ncorr_nodes, a.x, L.corr);
+                hipLaunchKernelGGL(k_macro_corr_rows, dim3((L.nflag * 24 + BLK - 1) / BLK), dim3(BLK), 0, grid->stream, L.g,
+                                   L.dK, L.flag_list, L.nflag, a.x, L.corr_tmp);
+                hipLaunchKernelGGL(k_macro_corr_gather, dim3((L.ncorr_nodes + BLK - 1) / BLK), dim3(BLK), 0, grid->stream,
+                                   L.corr_nodes, L.corr_adj, L.ncorr_nodes, L.corr_tmp, L.corr, L.nflag);
+                count_launch(grid);
                 count_launch(grid);
             }
             TileArgs ta{L.g.nx, L.g.ny, L.g.nzl, L.g.ex, L.g.ey, L.g.ezl, L.g.own_lo, L.g.own_hi, kz,
@@ -284,7 +288,9 @@ struct MGSolver {
             flops = 2.0 * (8 * DOF) * (8 * DOF) * (double)L.g.own_elems();
         } else {
             DiaOp<DOF> o{L.S, L.ndof(), L.g};
-            hipLaunchKernelGGL((k_node<DOF, DiaOp<DOF>, EPI>), dim3(nb), dim3(BLK), 0, grid->stream, o, a);
+            const int nbr = (int)((nown * DOF + BLK - 1) / BLK);
+            last_nblocks = nbr;
+            hipLaunchKernelGGL((k_dia_row<DOF, EPI>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
             bytes = (27.0 * DOF * DOF + 2.0 * DOF) * 8.0 * nown;
             flops = 2.0 * 27 * DOF * DOF * (double)nown;
         }

@@ -257,3 +257,55 @@ __global__ __launch_bounds__(BLK) void k_prolong_add(Geom gc, Geom gf, const dou
 #pragma unroll
     for (int r = 0; r < DOF; r++) xf[nf * DOF + r] += s[r];
 }
+
+// ---------------------------------------------------------------------------
+// Stencil levels, one thread per matrix ROW (node x dof): the coarse grids are
+// small (17^3 .. 65^3 nodes), so the finer decomposition is what fills the chip.
+template <int DOF, int EPI>
+__global__ __launch_bounds__(BLK) void k_dia_row(DiaOp<DOF> op, NodeArgs a) {
+    const Geom &g = op.g;
+    const long plane = g.plane();
+    const long t = blockIdx.x * (long)BLK + threadIdx.x;
+    double pdot = 0.0;
+    if (t < g.owned_nodes() * DOF) {
+        const long q = t + plane * g.own_lo * DOF;  // row
+        const long n = q / DOF;
+        const int k = (int)(n / plane);
+        const int rem = (int)(n % plane);
+        const int j = rem / g.nx, i = rem % g.nx;
+        const double *__restrict__ u = a.x;
+        double y = 0.0;
+#pragma unroll
+        for (int dk = -1; dk <= 1; dk++) {
+            if (k + dk < 0 || k + dk >= g.nzl) continue;
+#pragma unroll
+            for (int dj = -1; dj <= 1; dj++) {
+                if (j + dj < 0 || j + dj >= g.ny) continue;
+#pragma unroll
+                for (int di = -1; di <= 1; di++) {
+                    if (i + di < 0 || i + di >= g.nx) continue;
+                    const int blk = (dk + 1) * 9 + (dj + 1) * 3 + (di + 1);
+                    const long nb = n + di + (long)g.nx * (dj + (long)g.ny * dk);
+#pragma unroll
+                    for (int c = 0; c < DOF; c++) y = fma(op.S[(long)(blk * DOF + c) * op.nrows + q], u[nb * DOF + c], y);
+                }
+            }
+        }
+        if (EPI == EPI_APPLY) {
+            a.out[q] = y;
+        } else if (EPI == EPI_RESID) {
+            a.out[q] = a.b[q] - y;
+        } else if (EPI == EPI_CHEB) {
+            const double dn = a.c1 * a.d[q] + a.c2 * (a.dinv[q] * (a.b[q] - y));
+            a.d[q] = dn;
+            a.out[q] = u[q] + dn;
+        } else {
+            a.out[q] = y;
+            pdot = u[q] * y;
+        }
+    }
+    if (EPI == EPI_APPLY_DOT) {
+        pdot = block_sum(pdot);
+        if (threadIdx.x == 0) a.partials[blockIdx.x] = pdot;
+    }
+}

@@ -142,7 +142,7 @@ struct tp_elasticity {
     int *d_flag_all;         // flagged level-1 elements incl. the ghost layer (matrix-free level 1)
     int nflag_all;
     int *d_corr_nodes, *d_corr_adj;
-    double *d_dK, *d_corr;
+    double *d_dK, *d_corr, *d_corr_tmp;
     int nflagged;
     double *d_bN;            // RHS .* N scratch
     double *d_N;             // copy of N (for the load masking of :542)
@@ -194,7 +194,7 @@ extern "C" int tp_elasticity_create(tp_elasticity **out, tp_grid *g, const tp_so
     e->nflagged = 0;
     e->d_colmask = nullptr;
     e->d_flag_all = e->d_corr_nodes = e->d_corr_adj = nullptr;
-    e->d_dK = e->d_corr = nullptr;
+    e->d_dK = e->d_corr = e->d_corr_tmp = nullptr;
     e->nflag_all = 0;
     hex8_stiffness_box(g->o.hx, g->o.hy, g->o.hz, o->nu, e->KE);
     std::vector<double> M(8 * 576);
@@ -257,7 +257,7 @@ extern "C" int tp_elasticity_destroy(tp_elasticity *e) {
     e->mg.free_levels();
     for (void *p : {(void *)e->d_KE, (void *)e->d_M, (void *)e->d_E, (void *)e->d_mask, (void *)e->d_bN, (void *)e->d_N,
                     (void *)e->d_flagged, (void *)e->d_colmask, (void *)e->d_flag_all, (void *)e->d_corr_nodes,
-                    (void *)e->d_corr_adj, (void *)e->d_dK, (void *)e->d_corr})
+                    (void *)e->d_corr_adj, (void *)e->d_dK, (void *)e->d_corr, (void *)e->d_corr_tmp})
         (void)hipFree(p);
     delete e;
     return TP_OK;
@@ -339,15 +339,18 @@ extern "C" int tp_elasticity_set_bc(tp_elasticity *e, const double *N) {
                         cadj.insert(cadj.end(), adj, adj + 8);
                     }
                 }
-        for (void *p : {(void *)e->d_flag_all, (void *)e->d_corr_nodes, (void *)e->d_corr_adj, (void *)e->d_dK}) (void)hipFree(p);
+        for (void *p : {(void *)e->d_flag_all, (void *)e->d_corr_nodes, (void *)e->d_corr_adj, (void *)e->d_dK,
+                        (void *)e->d_corr_tmp})
+            (void)hipFree(p);
         e->d_flag_all = e->d_corr_nodes = e->d_corr_adj = nullptr;
-        e->d_dK = nullptr;
+        e->d_dK = e->d_corr_tmp = nullptr;
         e->nflag_all = (int)fall.size();
         TP_HIP(hipMemset(e->d_corr, 0, sizeof(double) * (size_t)L1.ndof()));
         if (!fall.empty()) {
             TP_HIP(hipMalloc((void **)&e->d_flag_all, sizeof(int) * fall.size()));
             TP_HIP(hipMemcpy(e->d_flag_all, fall.data(), sizeof(int) * fall.size(), hipMemcpyHostToDevice));
             TP_HIP(hipMalloc((void **)&e->d_dK, sizeof(double) * 576 * fall.size()));
+            TP_HIP(hipMalloc((void **)&e->d_corr_tmp, sizeof(double) * 24 * fall.size()));
         }
         if (!cn.empty()) {
             TP_HIP(hipMalloc((void **)&e->d_corr_nodes, sizeof(int) * cn.size()));
@@ -360,6 +363,8 @@ extern "C" int tp_elasticity_set_bc(tp_elasticity *e, const double *N) {
         L1.corr_nodes = e->d_corr_nodes;
         L1.corr_adj = e->d_corr_adj;
         L1.ncorr_nodes = (int)cn.size();
+        L1.nflag = e->nflag_all;
+        L1.corr_tmp = e->d_corr_tmp;
     }
     if (e->nflagged) {
         TP_HIP(hipMalloc((void **)&e->d_flagged, sizeof(int) * fl.size()));
