@@ -1,0 +1,58 @@
+"""N > 1 path: world_size-2 runs.  CPU (gloo): partition + halo + reductions with an
+oracle-driven slab CG.  GPU: the real HIP solver on two z-slabs sharing one GPU
+(gloo with host staging) against the serial oracle."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(mode, nproc=2, timeout=600):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "mp_gloo_worker.py"), mode]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-3000:]
+    for k in range(nproc):
+        assert "rank %d %s OK" % (k, mode) in r.stdout, r.stdout[-2000:]
+
+
+def test_partition_logic():
+    from topopt_in_petsc_amd.partition import SlabPartition
+    nx, ny, nz = 9, 5, 17
+    owned = np.zeros(nz, dtype=int)
+    for r in range(4):
+        p = SlabPartition(nx, ny, nz, r, 4)
+        assert p.ez_own == 4 and p.elem_z0 == 4 * r and p.node_z0 == 4 * r
+        assert p.nz_local == (6 if r < 3 else 5)
+        assert (p.own_lo, p.own_hi) == ((0, 4) if r == 0 else (1, 4))
+        owned[p.node_z0 + p.own_lo: p.node_z0 + p.own_hi + 1] += 1
+        assert p.n_owned_nodes == nx * ny * (5 if r == 0 else 4)
+        assert p.coarsenable(3) and not p.coarsenable(4)
+        assert p.level(2).ez_own == 1
+    assert (owned == 1).all()
+    with pytest.raises(ValueError):
+        SlabPartition(9, 5, 16, 0, 4)
+
+
+def test_two_ranks_cpu_gloo():
+    _launch("cpu")
+
+
+@pytest.mark.gpu
+def test_two_ranks_one_gpu():
+    _launch("gpu")

@@ -275,17 +275,19 @@ __global__ __launch_bounds__(BLK) void k_dia_row(DiaOp<DOF> op, NodeArgs a) {
         const int j = rem / g.nx, i = rem % g.nx;
         const double *__restrict__ u = a.x;
         double y = 0.0;
+        // branch-free: coefficients of non-existent neighbours are stored as zeros, so only the
+        // ADDRESS has to be made safe (clamped to the own node); all 2 x 27 x DOF loads can be in flight
 #pragma unroll
         for (int dk = -1; dk <= 1; dk++) {
-            if (k + dk < 0 || k + dk >= g.nzl) continue;
+            const bool okk = k + dk >= 0 && k + dk < g.nzl;
 #pragma unroll
             for (int dj = -1; dj <= 1; dj++) {
-                if (j + dj < 0 || j + dj >= g.ny) continue;
+                const bool okj = okk && j + dj >= 0 && j + dj < g.ny;
 #pragma unroll
                 for (int di = -1; di <= 1; di++) {
-                    if (i + di < 0 || i + di >= g.nx) continue;
+                    const bool ok = okj && i + di >= 0 && i + di < g.nx;
                     const int blk = (dk + 1) * 9 + (dj + 1) * 3 + (di + 1);
-                    const long nb = n + di + (long)g.nx * (dj + (long)g.ny * dk);
+                    const long nb = ok ? n + di + (long)g.nx * (dj + (long)g.ny * dk) : n;
 #pragma unroll
                     for (int c = 0; c < DOF; c++) y = fma(op.S[(long)(blk * DOF + c) * op.nrows + q], u[nb * DOF + c], y);
                 }
