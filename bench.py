@@ -41,6 +41,9 @@ def parse():
     p.add_argument("--spmv-reps", type=int, default=50)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", default="96x48x48")
+    p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                   help="gloo + --same-device validates the multi-rank path on a 1-GPU box")
+    p.add_argument("--same-device", action="store_true")
     return p.parse_args()
 
 
@@ -83,10 +86,14 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    torch.cuda.set_device(local_rank)
+    dev = 0 if a.same_device else local_rank
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo")
 
     ex, ey, ezg, nlv = WORKLOADS[a.workload]
     ez = ezg * world  # weak scaling: fixed slab per GPU
@@ -149,8 +156,17 @@ def main():
     torch.cuda.synchronize()
     spmv_ms = ev0.elapsed_time(ev1) / a.spmv_reps
     achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "k_node<3,MatfreeOp<3>,EPI_APPLY> (fine-level hex8 SpMV)",
-                "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+    # HBM traffic per launch from the rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, see
+    # profiles/README.md); only valid for the mesh it was measured on
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "spmv_traffic.json")
+    if os.path.exists(tj):
+        rec = json.load(open(tj)).get("%dx%dx%d" % (ex, ey, part.ez_own))
+        if rec:
+            traffic = rec["hbm_bytes_per_launch"] / 1e9
+    roofline = {"bound": "hbm", "kernel": "k_matfree_tile<EPI_APPLY,0> (fine-level matrix-free hex8 SpMV)",
+                "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                "traffic_unit": "GB per launch (PMC)",
                 "alg_bytes_per_launch": spmv_bytes, "avg_launch_ms": spmv_ms,
                 "fp64_tflops": 1152.0 * n_el_own / (spmv_ms * 1e-3) / 1e12}
 

@@ -187,6 +187,7 @@ struct TileArgs {
     // MACRO (level-1 Galerkin operator applied from the fine densities):
     int fex, fey;              // FINE element counts per row / column (children indexing)
     const double *corr;        // [level-1 dofs] Dirichlet correction added to y (k_macro_corr), or null
+    int xcd_remap;             // 1: contiguous tile ranges per XCD
 };
 
 // MACRO = 0: fine level, one element per thread and step.
@@ -202,12 +203,24 @@ struct TileArgs {
 //   matrix dK_E whose action k_macro_corr precomputes into `corr`.
 template <int EPI, int MACRO>
 __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(TileArgs t, NodeArgs a) {
-    __shared__ double s_u[2][STG_N];
-    __shared__ double s_y[TILE * TILE * 3];
+    __shared__ double s_u[3][STG_N];          // node-plane ring: bottom, top, next
+    __shared__ double s_y[2][TILE * TILE * 3];  // y-combination, double buffered -> one barrier per step
     const int tid = threadIdx.x;
     const int tx = tid & (TILE - 1), ty = tid / TILE;
-    const int bx = blockIdx.x * TOUT, by = blockIdx.y * TOUT;
-    const int kz0 = t.own_lo + blockIdx.z * t.kz;
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (private L2 each); give every XCD a
+    // contiguous run of tiles so that neighbouring tiles, which share halo columns, meet in one L2
+    int bxi, byi, bzi;
+    {
+        const int nb = gridDim.x * gridDim.y * gridDim.z;
+        const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int x8 = lin & 7;
+        const int m = t.xcd_remap ? x8 * (nb >> 3) + min(x8, nb & 7) + (lin >> 3) : lin;  // bijection of [0, nb)
+        bxi = m % gridDim.x;
+        byi = (m / gridDim.x) % gridDim.y;
+        bzi = m / (gridDim.x * gridDim.y);
+    }
+    const int bx = bxi * TOUT, by = byi * TOUT;
+    const int kz0 = t.own_lo + bzi * t.kz;
     const int kz1 = min(kz0 + t.kz - 1, t.own_hi);
     const int nsteps = kz1 - kz0 + 2;  // element layers kz0-1 .. kz1
     const int ei = bx - 1 + tx, ej = by - 1 + ty;
@@ -276,6 +289,8 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
     store_plane(0, pre);
     load_plane(kz0, pre);
     store_plane(1, pre);
+    load_plane(kz0 + 1, pre);
+    store_plane(2, pre);
     __syncthreads();
     double Ub[3][4];
     read_plane_wht(0, Ub);
@@ -291,7 +306,8 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
         const bool more = s + 1 < nsteps;
         const bool outp = s >= 1 && node_ok;
         // ---- issue the long-latency loads of this step first
-        if (more) load_plane(el + 2, pre);
+        const int b0 = s % 3, b1 = (s + 1) % 3;  // ring slots of the bottom / top plane of this step
+        if (more) load_plane(el + 3, pre);      // lands in slot b0 once this step is done with it
         double Ee = 0.0;
         if (!MACRO && elem_ok && el >= 0 && el < t.ezl) Ee = t.E[(long)ei + (long)t.ex * (ej + (long)t.ey * el)];
         const long nq = 3 * (ncol + plane * el);
@@ -299,7 +315,9 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
         if (outp) {
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                if (EPI != EPI_RESID || own_cm) xo[c] = x[nq + c];
+                // own input value: the staged (masked) copy in LDS is exact unless the column carries a
+                // Dirichlet condition (rare) -> no second trip to memory for x
+                if (EPI != EPI_RESID || own_cm) xo[c] = own_cm ? x[nq + c] : s_u[b0][o00 + c];
                 if (EPI == EPI_RESID || EPI == EPI_CHEB) bo[c] = a.b[nq + c];
                 if (EPI == EPI_CHEB) {
                     dd[c] = a.d[nq + c];
@@ -310,7 +328,7 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
         }
         // ---- element in the Walsh-Hadamard basis
         double Ut[3][4], u[3][8], f[3][8];
-        read_plane_wht((s + 1) & 1, Ut);
+        read_plane_wht(b1, Ut);
 #pragma unroll
         for (int c = 0; c < 3; c++)
 #pragma unroll
@@ -393,7 +411,7 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
             wht4(P[c]);  // nodal contributions of this element column to plane el
             s0[c] = P[c][0] + dpp_row_shr1(P[c][1]);  // node (ei, ej  ): own + left element
             s1[c] = P[c][2] + dpp_row_shr1(P[c][3]);  // node (ei, ej+1)
-            s_y[tid * 3 + c] = s1[c];
+            s_y[s & 1][tid * 3 + c] = s1[c];
         }
         __syncthreads();
         if (outp) {
@@ -401,7 +419,7 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
             if (own_cm) m = t.mask[ncol + plane * el];
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                double y = s0[c] + s_y[(tid - TILE) * 3 + c];
+                double y = s0[c] + s_y[s & 1][(tid - TILE) * 3 + c];
                 if (MACRO) y += co[c];
                 if ((m >> c) & 1u) y = xo[c];
                 const long q = nq + c;
@@ -419,8 +437,8 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
                 }
             }
         }
-        if (more) store_plane(s & 1, pre);
-        __syncthreads();
+        // slot b0 was last read before the barrier above; its next reader (step s+2) is behind the next one
+        if (more) store_plane(b0, pre);
     }
     if (EPI == EPI_APPLY_DOT) {
         pdot = block_sum(pdot);

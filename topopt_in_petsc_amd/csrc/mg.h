@@ -201,6 +201,11 @@ inline double elem_lambda_bound(int n, const double *KE) {
     return l;
 }
 
+inline int xcd_remap() {
+    static const int v = getenv("TP_XCD_REMAP") ? atoi(getenv("TP_XCD_REMAP")) : 0;
+    return v;
+}
+
 template <int DOF>
 struct MGSolver {
     tp_grid *grid = nullptr;
@@ -248,13 +253,13 @@ struct MGSolver {
             const int tx = (L.g.nx + TOUT - 1) / TOUT, ty = (L.g.ny + TOUT - 1) / TOUT;
             const int planes = L.g.own_hi - L.g.own_lo + 1;
             static const int kz_env = getenv("TP_TILE_KZ") ? atoi(getenv("TP_TILE_KZ")) : 0;
-            int kz = kz_env > 0 ? kz_env : (int)((long)planes * tx * ty / 1024);
-            kz = kz < 8 ? 8 : (kz > 64 ? 64 : kz);
+            int kz = kz_env > 0 ? kz_env : (int)((long)planes * tx * ty / 5120);  // ~5k workgroups
+            kz = kz < 8 ? 8 : (kz > 32 ? 32 : kz);
             if (kz > planes) kz = planes;
             const int tz = (planes + kz - 1) / kz;
             last_nblocks = tx * ty * tz;
             TileArgs ta{L.g.nx, L.g.ny, L.g.nzl, L.g.ex, L.g.ey, L.g.ezl, L.g.own_lo, L.g.own_hi, kz,
-                        L.E, L.mask, L.colmask, L.sym_slot * SYMKE_STRIDE, 0, 0, nullptr};
+                        L.E, L.mask, L.colmask, L.sym_slot * SYMKE_STRIDE, 0, 0, nullptr, xcd_remap()};
             hipLaunchKernelGGL((k_matfree_tile<EPI, 0>), dim3(tx, ty, tz), dim3(TILE * TILE), 0, grid->stream, ta, a);
             bytes = 16.0 * DOF * nown + 8.0 * L.g.own_elems();
             flops = 2.0 * 576 * (double)L.g.own_elems();
@@ -277,7 +282,7 @@ struct MGSolver {
             }
             TileArgs ta{L.g.nx, L.g.ny, L.g.nzl, L.g.ex, L.g.ey, L.g.ezl, L.g.own_lo, L.g.own_hi, kz,
                         L.E, nullptr, nullptr, L.sym_slot * SYMKE_STRIDE, L.fex, L.fey,
-                        L.ncorr_nodes ? L.corr : nullptr};
+                        L.ncorr_nodes ? L.corr : nullptr, xcd_remap()};
             hipLaunchKernelGGL((k_matfree_tile<EPI, 1>), dim3(tx, ty, tz), dim3(TILE * TILE), 0, grid->stream, ta, a);
             bytes = 16.0 * DOF * nown + 8.0 * 8.0 * L.g.own_elems();
             flops = 2.0 * 576 * 8.0 * (double)L.g.own_elems();
