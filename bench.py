@@ -38,6 +38,10 @@ def parse():
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--workload", default="cantilever128", choices=sorted(WORKLOADS))
     p.add_argument("--rtol", type=float, default=1e-5)
+    p.add_argument("--fine-eig", type=int, default=0, help="1: Lanczos estimate for the fine-level Chebyshev window")
+    p.add_argument("--nlvls", type=int, default=0, help="override the multigrid depth of the workload")
+    p.add_argument("--ncoarse", type=int, default=30)
+    p.add_argument("--nsmooth", type=int, default=4)
     p.add_argument("--spmv-reps", type=int, default=50)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", default="96x48x48")
@@ -47,7 +51,7 @@ def parse():
     return p.parse_args()
 
 
-def cpu_baseline(sample, rtol):
+def cpu_baseline(sample, rtol, fine_eig):
     """The oracle (a port of the reference's assembled-CSR path, OpenMP) timed on
     the host cores for one step of the same algorithm on a bounded sample mesh."""
     from oracle import oracle as orc
@@ -59,7 +63,7 @@ def cpu_baseline(sample, rtol):
     KE = orc.hex8_ke_box(h, h, h, 0.3)
     N, R = orc.cantilever_bc(nx, ny, nz, h)
     flt = orc.Filter(nx, ny, nz, h, 2.56 * h)
-    mg = orc.MG(nx, ny, nz, 3, nlv)
+    mg = orc.MG(nx, ny, nz, 3, nlv, fine_eig=fine_eig)
     t0 = time.perf_counter()
     xt, xp = flt.project(1, x)
     mg.assemble(KE, orc.simp(xp), N)
@@ -96,11 +100,12 @@ def main():
             dist.init_process_group("gloo")
 
     ex, ey, ezg, nlv = WORKLOADS[a.workload]
+    nlv = a.nlvls or nlv
     ez = ezg * world  # weak scaling: fixed slab per GPU
     nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
     ndof = 3 * nx * ny * nz
     grid = tp.Grid(nx, ny, nz, h, rank=rank, nranks=world)
-    le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=nlv, rtol=a.rtol))
+    le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=nlv, rtol=a.rtol, fine_eig=a.fine_eig, ncoarse=a.ncoarse, nsmooth=a.nsmooth))
     flt = tp.Filter(grid, 1, 2.56 * h)
     le.SetUpLoadAndBC()
     x = grid.synth_density(12345)
@@ -176,8 +181,9 @@ def main():
         "ms_per_step": t_step * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s: cantilever %dx%dx%d elements (%d DOF), z-slabs over %d GPU(s), rmin=2.56h density "
-                               "filter, CG + %d-level GMG (Chebyshev(4)-Jacobi, Galerkin), rtol %g, cold start, "
-                               "filtered synthetic density seed 12345" % (a.workload, ex, ey, ez, ndof, world, nlv, a.rtol),
+                               "filter, CG + %d-level GMG (Chebyshev(%d)-Jacobi, coarse Chebyshev(%d), Galerkin), rtol %g, fine-level eig %s, cold start, "
+                               "filtered synthetic density seed 12345" % (a.workload, ex, ey, ez, ndof, world, nlv, a.nsmooth, a.ncoarse, a.rtol,
+                                                                         "Lanczos(10)" if a.fine_eig else "element bound"),
                    "n_dof": ndof, "cg_its": info.get("its"), "rel_residual": info.get("rel_res"), "fx": info.get("fx"),
                    "parallelism": "zslab%d" % world, "kernel_launches_per_step": launches / max(a.steps, 1),
                    "alg_GB_per_step": alg_bytes / max(a.steps, 1) / 1e9,
@@ -185,7 +191,7 @@ def main():
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.cpu_sample, a.rtol)
+        out["cpu_baseline"] = cpu_baseline(a.cpu_sample, a.rtol, a.fine_eig)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -106,7 +106,8 @@ typedef struct tp_solver_opts {
     int nsmooth;        /* smoother iterations per sweep, :635 */
     int ncoarse;        /* coarse-solve iterations, :631 */
     double cheb_lo, cheb_hi; /* Chebyshev window as fractions of the eigenvalue estimate */
-    int nlanczos;       /* Lanczos steps for the coarse-level estimates */
+    int nlanczos;       /* Lanczos steps for the eigenvalue estimates */
+    int fine_eig;       /* fine-level estimate: 0 = rigorous element bound (free), 1 = Lanczos like the coarse levels */
 } tp_solver_opts;
 void tp_solver_default_opts(tp_solver_opts *o);
 

@@ -35,6 +35,7 @@ def lib():
         L.orc_mg_create.restype = C.c_void_p
         L.orc_mg_create.argtypes = [C.c_int] * 7 + [C.c_double] * 2
         L.orc_mg_destroy.argtypes = [C.c_void_p]
+        L.orc_mg_set_fine_eig.argtypes = [C.c_void_p, C.c_int]
         L.orc_mg_assemble.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_mg_precond.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_mg_solve.restype = C.c_int
@@ -46,6 +47,8 @@ def lib():
         L.orc_mg_level_nnz.argtypes = [C.c_void_p, C.c_int]
         L.orc_mg_level_lambda.restype = C.c_double
         L.orc_mg_level_lambda.argtypes = [C.c_void_p, C.c_int]
+        L.orc_mg_level_lambda_min.restype = C.c_double
+        L.orc_mg_level_lambda_min.argtypes = [C.c_void_p, C.c_int]
         for f in ("orc_mg_level_apply", "orc_mg_prolong", "orc_mg_restrict"):
             getattr(L, f).argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_mg_level_diag.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -156,11 +159,12 @@ def compliance_sens(nx, ny, nz, KE, U, xPhys, Emin=1e-9, Emax=1.0, penal=3.0, vo
 class MG:
     """CG + Galerkin multigrid on assembled CSR matrices (the oracle solver)."""
 
-    def __init__(self, nx, ny, nz, dof=3, nlv=3, nsmooth=4, ncoarse=30, cheb_lo=0.1, cheb_hi=1.1):
+    def __init__(self, nx, ny, nz, dof=3, nlv=3, nsmooth=4, ncoarse=30, cheb_lo=0.1, cheb_hi=1.1, fine_eig=0):
         self.L = lib()
         self.h = self.L.orc_mg_create(nx, ny, nz, dof, nlv, nsmooth, ncoarse, cheb_lo, cheb_hi)
         if not self.h:
             raise ValueError("mesh not coarsenable %d times" % (nlv - 1))
+        self.L.orc_mg_set_fine_eig(self.h, fine_eig)
         self.nlv, self.dof = nlv, dof
         self.n = dof * nx * ny * nz
 
@@ -178,6 +182,9 @@ class MG:
 
     def lam(self, l):
         return self.L.orc_mg_level_lambda(self.h, l)
+
+    def lam_min(self, l):
+        return self.L.orc_mg_level_lambda_min(self.h, l)
 
     def apply(self, l, u):
         u = f64(u)

@@ -590,8 +590,9 @@ typedef struct {
     csr_t *P[MAXLV]; /* P[l]: level l+1 (coarse) -> level l (fine) */
     double *dinv[MAXLV];
     double lam[MAXLV];
+    double lam_min[MAXLV]; /* coarsest level only: smallest Ritz value (coarse-solve window) */
     double *b[MAXLV], *x[MAXLV], *r[MAXLV], *d[MAXLV];
-    int nsmooth, ncoarse, nlanczos;
+    int nsmooth, ncoarse, nlanczos, nlanczos_coarse, fine_eig;
     double cheb_lo, cheb_hi;
 } orc_mg_t;
 
@@ -622,43 +623,80 @@ static double tridiag_lmax(int m, const double *a, const double *b) {
     return 0.5 * (lo + hi);
 }
 
-static double lanczos_lmax(const csr_t *A, const double *dinv, int nsteps) {
+/* smallest eigenvalue of the symmetric tridiagonal, Sturm bisection */
+static double tridiag_lmin(int m, const double *a, const double *b) {
+    double lo = a[0], hi = a[0];
+    for (int i = 0; i < m; i++) {
+        double rad = (i > 0 ? fabs(b[i - 1]) : 0.0) + (i < m - 1 ? fabs(b[i]) : 0.0);
+        if (a[i] - rad < lo) lo = a[i] - rad;
+        if (a[i] + rad > hi) hi = a[i] + rad;
+    }
+    for (int it = 0; it < 200; it++) {
+        double mid = 0.5 * (lo + hi);
+        if (mid == lo || mid == hi) break;
+        int cnt  = 0;
+        double q = a[0] - mid;
+        if (q < 0) cnt++;
+        for (int i = 1; i < m; i++) {
+            double den = (fabs(q) < 1e-300) ? 1e-300 : q;
+            q          = a[i] - mid - b[i - 1] * b[i - 1] / den;
+            if (q < 0) cnt++;
+        }
+        if (cnt >= 1) hi = mid; /* at least one eigenvalue below mid */
+        else lo = mid;
+    }
+    return 0.5 * (lo + hi);
+}
+
+/* Extreme Ritz values of D^-1/2 A D^-1/2 from `nsteps` Lanczos steps with FULL
+ * reorthogonalisation (classical Gram-Schmidt applied twice against all previous
+ * vectors): without it the estimates depend on rounding at the 1e-5 level after a
+ * few dozen steps, which would make the Chebyshev windows -- and with them the CG
+ * residual history -- irreproducible between implementations. */
+static double lanczos_lmax(const csr_t *A, const double *dinv, int nsteps, double *lmin_out) {
     long n = A->nrow;
-    double *dis = (double *)xmalloc(sizeof(double) * (size_t)n), *v = (double *)xmalloc(sizeof(double) * (size_t)n),
-           *vp = (double *)xcalloc((size_t)n, sizeof(double)), *w = (double *)xmalloc(sizeof(double) * (size_t)n),
+    if (nsteps > 128) nsteps = 128;
+    double *dis = (double *)xmalloc(sizeof(double) * (size_t)n), *w = (double *)xmalloc(sizeof(double) * (size_t)n),
            *t = (double *)xmalloc(sizeof(double) * (size_t)n);
-    double al[64] = {0}, be[64] = {0};
-    if (nsteps > 64) nsteps = 64;
+    double *V = (double *)xmalloc(sizeof(double) * (size_t)n * (size_t)(nsteps + 1));
+    double al[128] = {0}, be[128] = {0}, h[129];
+    double *v0 = V;
     for (long i = 0; i < n; i++) {
         dis[i] = sqrt(dinv[i]);
-        v[i]   = hash_u01((uint64_t)i, 0x5eedULL) - 0.5;
+        v0[i]  = hash_u01((uint64_t)i, 0x5eedULL) - 0.5;
     }
-    double nv = vnorm(n, v);
-    for (long i = 0; i < n; i++) v[i] /= nv;
-    double beta = 0.0;
-    int m       = 0;
+    double nv = vnorm(n, v0);
+    for (long i = 0; i < n; i++) v0[i] /= nv;
+    int m = 0;
     for (int j = 0; j < nsteps; j++) {
-        for (long i = 0; i < n; i++) t[i] = dis[i] * v[i];
+        const double *vj = V + (size_t)j * n;
+        for (long i = 0; i < n; i++) t[i] = dis[i] * vj[i];
         csr_spmv(A, t, w);
-        for (long i = 0; i < n; i++) w[i] = dis[i] * w[i] - beta * vp[i];
-        double alpha = vdot(n, w, v);
-        for (long i = 0; i < n; i++) w[i] -= alpha * v[i];
+        for (long i = 0; i < n; i++) w[i] = dis[i] * w[i];
+        double alpha = 0.0;
+        for (int pass = 0; pass < 2; pass++) {
+            for (int q = 0; q <= j; q++) h[q] = vdot(n, V + (size_t)q * n, w);
+            for (int q = 0; q <= j; q++) {
+                const double *vq = V + (size_t)q * n;
+                const double hq  = h[q];
+                for (long i = 0; i < n; i++) w[i] -= hq * vq[i];
+            }
+            alpha += h[j];
+        }
+        double beta = vnorm(n, w);
         al[m] = alpha;
-        beta  = vnorm(n, w);
         be[m] = beta;
         m++;
-        if (beta < 1e-14 * fabs(alpha)) break;
-        for (long i = 0; i < n; i++) {
-            vp[i] = v[i];
-            v[i]  = w[i] / beta;
-        }
+        if (!(beta > 1e-14 * fabs(alpha))) break;
+        double *vn = V + (size_t)(j + 1) * n;
+        for (long i = 0; i < n; i++) vn[i] = w[i] / beta;
     }
     double l = tridiag_lmax(m, al, be);
+    if (lmin_out) *lmin_out = tridiag_lmin(m, al, be);
     free(dis);
-    free(v);
-    free(vp);
     free(w);
     free(t);
+    free(V);
     return l;
 }
 
@@ -711,6 +749,7 @@ ORC_API orc_mg_t *orc_mg_create(int nx, int ny, int nz, int dof, int nlv, int ns
     s->nsmooth = nsmooth;
     s->ncoarse = ncoarse;
     s->nlanczos = 10;
+    s->nlanczos_coarse = 40;
     s->cheb_lo = cheb_lo;
     s->cheb_hi = cheb_hi;
     for (int l = 0; l < nlv; l++) {
@@ -731,6 +770,8 @@ ORC_API orc_mg_t *orc_mg_create(int nx, int ny, int nz, int dof, int nlv, int ns
     for (int l = 0; l + 1 < nlv; l++) s->P[l] = interp_csr(s->nx[l + 1], s->ny[l + 1], s->nz[l + 1], dof);
     return s;
 }
+
+ORC_API void orc_mg_set_fine_eig(orc_mg_t *s, int mode) { s->fine_eig = mode; }
 
 ORC_API void orc_mg_destroy(orc_mg_t *s) {
     if (!s) return;
@@ -772,11 +813,16 @@ ORC_API void orc_mg_assemble(orc_mg_t *s, const double *KE, const double *E, con
                 if (A->ci[p] == r) dg = A->v[p];
             s->dinv[l][r] = 1.0 / dg;
         }
-        if (l == 0) {
+        if (l == 0 && !s->fine_eig) {
             double lb = elem_lambda_bound(8 * s->dof, KE);
             s->lam[0] = lb > 1.0 ? lb : 1.0;
+        } else if (l == s->nlv - 1 && l > 0) {
+            /* coarsest level: the Chebyshev iteration there is a SOLVE (the reference uses a Krylov
+             * method, LinearElasticity.cc:720-731), so its window spans the whole spectrum:
+             * both extreme Ritz values of a longer Lanczos run */
+            s->lam[l] = lanczos_lmax(A, s->dinv[l], s->nlanczos_coarse, &s->lam_min[l]);
         } else {
-            s->lam[l] = lanczos_lmax(A, s->dinv[l], s->nlanczos);
+            s->lam[l] = lanczos_lmax(A, s->dinv[l], s->nlanczos, NULL);
         }
     }
 }
@@ -817,6 +863,7 @@ static void vcycle(orc_mg_t *s, int l) {
     long n         = A->nrow;
     double lmin = s->cheb_lo * s->lam[l], lmax = s->cheb_hi * s->lam[l];
     if (l == s->nlv - 1) {
+        if (l > 0) lmin = s->lam_min[l];
         cheb_smooth(A, s->dinv[l], s->b[l], s->x[l], s->r[l], s->d[l], s->ncoarse, lmin, lmax, 1);
         return;
     }
@@ -895,6 +942,7 @@ ORC_API int orc_mg_solve(orc_mg_t *s, const double *b, double *x, double rtol, d
 ORC_API long orc_mg_level_size(orc_mg_t *s, int l) { return s->A[l] ? s->A[l]->nrow : 0; }
 ORC_API long orc_mg_level_nnz(orc_mg_t *s, int l) { return s->A[l] ? s->A[l]->rp[s->A[l]->nrow] : 0; }
 ORC_API double orc_mg_level_lambda(orc_mg_t *s, int l) { return s->lam[l]; }
+ORC_API double orc_mg_level_lambda_min(orc_mg_t *s, int l) { return s->lam_min[l]; }
 ORC_API void orc_mg_level_apply(orc_mg_t *s, int l, const double *u, double *y) { csr_spmv(s->A[l], u, y); }
 ORC_API void orc_mg_level_diag(orc_mg_t *s, int l, double *d) {
     for (long i = 0; i < s->A[l]->nrow; i++) d[i] = 1.0 / s->dinv[l][i];

@@ -120,6 +120,25 @@ def test_solve_residual_history(tp, orc, kind, nlv):
     assert le.KSPSolve() == 0
 
 
+def test_fine_level_lanczos_option(tp, orc):
+    """fine_eig = 1: Lanczos estimate instead of the element bound on level 0 (both sides)"""
+    ex, ey, ez, nlv = 16, 8, 8, 3
+    nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
+    grid = tp.Grid(nx, ny, nz, h)
+    le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=nlv, rtol=1e-8, fine_eig=1))
+    le.SetUpLoadAndBC()
+    x = orc.synth_density(ex, ey, ez, h)
+    N, R = orc.cantilever_bc(nx, ny, nz, h)
+    mg = orc.MG(nx, ny, nz, 3, nlv, fine_eig=1)
+    mg.assemble(orc.hex8_ke_box(h, h, h, 0.3), orc.simp(x), N)
+    le.AssembleStiffnessMatrix(dev(x), 1e-9, 1.0, 3.0)
+    assert le.level_lambda(0) == pytest.approx(mg.lam(0), rel=1e-10)
+    assert le.level_lambda(0) < orc.elem_lambda_bound(orc.hex8_ke_box(h, h, h, 0.3))
+    its = le.KSPSolve(hist_cap=300)
+    Uo, its_o, hist_o = mg.solve(R * N, rtol=1e-8)
+    assert its == its_o and np.abs(le.last_hist / hist_o - 1).max() <= 1e-7
+
+
 def test_objective_and_sensitivities(tp, orc):
     grid, le, mg, x, KE, N, R = make(tp, orc, 16, 8, 8, 3, rtol=1e-12, max_it=300)
     le.KSPSolve()

@@ -50,10 +50,11 @@ class SolverOptions:
     cheb_lo: float = 0.1
     cheb_hi: float = 1.1
     nlanczos: int = 10
+    fine_eig: int = 0   # 0: element bound on the fine level, 1: Lanczos estimate
 
     def c_struct(self):
         return _lib.SolverOpts(self.nlvls, self.nu, self.rtol, self.atol, self.dtol, self.max_it, self.nsmooth,
-                               self.ncoarse, self.cheb_lo, self.cheb_hi, self.nlanczos)
+                               self.ncoarse, self.cheb_lo, self.cheb_hi, self.nlanczos, self.fine_eig)
 
 
 class Grid:

@@ -261,7 +261,7 @@ extern "C" int tp_filter_create(tp_filter **out, tp_grid *g, int filterType, dou
             TP_TRY(mg.setup_matfree_level(l, f->KF.data()));
         }
         mg.ready = true;
-        for (int l = 1; l < mg.nlv; l++) TP_TRY(mg.lanczos(l, o.nlanczos, &mg.lv[l].lam));
+        TP_TRY(mg.estimate_spectra(1));
         Geom q = mg.lv[0].g;
         TP_HIP(hipMalloc((void **)&f->xe, sizeof(double) * (size_t)q.elems_stored()));
         TP_HIP(hipMalloc((void **)&f->rhs, sizeof(double) * (size_t)q.nodes()));

@@ -24,6 +24,7 @@ struct Level {
     double *Kel;            // [dev] coarse element matrices (DOF = 3 Galerkin levels)
     double *dinv;
     double lam;             // estimate / bound of lambda_max(D^-1 A)
+    double lam_min = 0.0;   // coarsest level: smallest Ritz value (coarse-solve window)
     double *b, *x, *x2, *r, *d;
     bool use_tile = false;  // DOF == 3 matrix-free level with a box-symmetric KE: tuned kernel
     int sym_slot = -1;                // slot of the packed SymKE in constant memory
@@ -104,41 +105,51 @@ __global__ __launch_bounds__(BLK) void k_lanczos_init(Geom g, double *__restrict
         dis[n * DOF + c] = sqrt(dinv[n * DOF + c]);
     }
 }
-// w = dis*w - beta*vp ; partial w.v
-__global__ __launch_bounds__(BLK) void k_lanczos_a(double *__restrict__ w, const double *__restrict__ dis,
-                                                   const double *__restrict__ vp, const double *__restrict__ v,
-                                                   double beta, long off, long n, double *__restrict__ partials) {
-    double s = 0.0;
-    for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
-        const long q = off + i;
-        const double wn = dis[q] * w[q] - beta * vp[q];
-        w[q] = wn;
-        s = fma(wn, v[q], s);
+// partials[q*nb + b] = sum over block b of V_q . w   (q = 0..nv-1; V_q = V + q*stride)
+__global__ __launch_bounds__(BLK) void k_multi_dot(const double *__restrict__ V, long stride, int nv,
+                                                   const double *__restrict__ w, long off, long n,
+                                                   double *__restrict__ partials) {
+    for (int q = 0; q < nv; q++) {
+        const double *__restrict__ vq = V + (long)q * stride;
+        double s = 0.0;
+        for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) s = fma(vq[off + i], w[off + i], s);
+        s = block_sum(s);
+        if (threadIdx.x == 0) partials[(long)q * gridDim.x + blockIdx.x] = s;
     }
-    s = block_sum(s);
-    if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
-// w -= alpha v ; partial w.w
-__global__ __launch_bounds__(BLK) void k_lanczos_b(double *__restrict__ w, const double *__restrict__ v, double alpha,
-                                                   long off, long n, double *__restrict__ partials) {
-    double s = 0.0;
-    for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
-        const long q = off + i;
-        const double wn = w[q] - alpha * v[q];
-        w[q] = wn;
-        s = fma(wn, wn, s);
+// out[q] (+)= sum_b partials[q*nb + b]; one workgroup
+__global__ __launch_bounds__(BLK) void k_reduce_multi(const double *__restrict__ partials, int nb, int nv,
+                                                      double *__restrict__ out) {
+    for (int q = 0; q < nv; q++) {
+        double s = 0.0;
+        for (int b = threadIdx.x; b < nb; b += BLK) s += partials[(long)q * nb + b];
+        s = block_sum(s);
+        if (threadIdx.x == 0) out[q] = s;
     }
-    s = block_sum(s);
-    if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
-// vp = v ; v = w / beta
-__global__ __launch_bounds__(BLK) void k_lanczos_c(double *__restrict__ vp, double *__restrict__ v,
-                                                   const double *__restrict__ w, double inv_beta, long off, long n) {
+// w -= sum_q h[q] V_q ; acc[q] += h[q]  (device-resident coefficients)
+__global__ __launch_bounds__(BLK) void k_multi_axpy(const double *__restrict__ V, long stride, int nv,
+                                                    const double *__restrict__ h, double *__restrict__ w, long off,
+                                                    long n) {
     for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
-        const long q = off + i;
-        vp[q] = v[q];
-        v[q] = w[q] * inv_beta;
+        double acc = w[off + i];
+        for (int q = 0; q < nv; q++) acc = fma(-h[q], V[(long)q * stride + off + i], acc);
+        w[off + i] = acc;
     }
+}
+// alpha[j] = h1[j] + h2[j]
+__global__ void k_lanczos_alpha(const double *__restrict__ h1, const double *__restrict__ h2, int j,
+                                double *__restrict__ alpha) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) alpha[j] = h1[j] + h2[j];
+}
+// beta[j] = sqrt(bb[0]);  v_next = w / beta
+__global__ __launch_bounds__(BLK) void k_lanczos_next(const double *__restrict__ w, const double *__restrict__ bb, int j,
+                                                      double *__restrict__ beta, double *__restrict__ vnext, long off,
+                                                      long n) {
+    const double bt = sqrt(bb[0]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) beta[j] = bt;
+    const double inv = bt > 0.0 ? 1.0 / bt : 0.0;
+    for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) vnext[off + i] = w[off + i] * inv;
 }
 
 // largest eigenvalue of a symmetric tridiagonal matrix, Sturm bisection
@@ -161,6 +172,31 @@ inline double tridiag_lmax(int m, const double *a, const double *b) {
             if (q < 0) cnt++;
         }
         if (cnt >= m) hi = mid;
+        else lo = mid;
+    }
+    return 0.5 * (lo + hi);
+}
+
+// smallest eigenvalue of a symmetric tridiagonal matrix, Sturm bisection
+inline double tridiag_lmin(int m, const double *a, const double *b) {
+    double lo = a[0], hi = a[0];
+    for (int i = 0; i < m; i++) {
+        double rad = (i > 0 ? fabs(b[i - 1]) : 0.0) + (i < m - 1 ? fabs(b[i]) : 0.0);
+        lo = fmin(lo, a[i] - rad);
+        hi = fmax(hi, a[i] + rad);
+    }
+    for (int it = 0; it < 200; it++) {
+        double mid = 0.5 * (lo + hi);
+        if (mid == lo || mid == hi) break;
+        int cnt = 0;
+        double q = a[0] - mid;
+        if (q < 0) cnt++;
+        for (int i = 1; i < m; i++) {
+            double den = (fabs(q) < 1e-300) ? 1e-300 : q;
+            q = a[i] - mid - b[i - 1] * b[i - 1] / den;
+            if (q < 0) cnt++;
+        }
+        if (cnt >= 1) hi = mid;
         else lo = mid;
     }
     return 0.5 * (lo + hi);
@@ -215,6 +251,16 @@ struct MGSolver {
     double *cg_r = nullptr, *cg_p = nullptr, *cg_w = nullptr;
     bool ready = false;
     int last_nblocks = 0;  // workgroups (= reduction partials) of the last op<EPI_APPLY_DOT>
+    static constexpr int NLANCZOS_COARSE = 40;
+
+    // Chebyshev windows of the stencil / coarse levels (and of the fine level if opt.fine_eig)
+    int estimate_spectra(int first_level) {
+        for (int l = first_level; l < nlv; l++) {
+            if (l == nlv - 1 && l > 0) TP_TRY(lanczos(l, NLANCZOS_COARSE, &lv[l].lam, &lv[l].lam_min));
+            else TP_TRY(lanczos(l, opt.nlanczos, &lv[l].lam));
+        }
+        return TP_OK;
+    }
 
     int alloc_levels() {
         for (int l = 0; l < nlv; l++) {
@@ -318,7 +364,9 @@ struct MGSolver {
     // Chebyshev(k)-Jacobi; the iterate ping-pongs between L.x and L.x2, on exit L.x holds it
     int smooth(int l, const double *b, int k, bool zero_guess) {
         Level<DOF> &L = lv[l];
-        const double lmin = opt.cheb_lo * L.lam, lmax = opt.cheb_hi * L.lam;
+        // the coarsest level is a SOLVE (the reference runs a Krylov method there,
+        // LinearElasticity.cc:720-731): its window spans the whole spectrum
+        const double lmin = (l == nlv - 1 && l > 0) ? L.lam_min : opt.cheb_lo * L.lam, lmax = opt.cheb_hi * L.lam;
         const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
         double rho = 1.0 / sigma;
         int it = 0;
@@ -391,43 +439,76 @@ struct MGSolver {
         return TP_OK;
     }
 
-    // largest Ritz value of `steps` Lanczos iterations on D^-1/2 A D^-1/2
-    int lanczos(int l, int steps, double *lam_out) {
+    // sum over ranks of n device doubles (chunks of the 16-double framework buffer)
+    int allreduce_dev(double *p, int n) {
+        if (!grid->has_comm) return TP_OK;
+        for (int o = 0; o < n; o += 16) {
+            const int c = n - o < 16 ? n - o : 16;
+            TP_HIP(hipMemcpyAsync(grid->comm.red, p + o, sizeof(double) * c, hipMemcpyDeviceToDevice, grid->stream));
+            if (grid->comm.allreduce_sum(grid->comm.user, c)) return TP_ERR_COMM;
+            TP_HIP(hipMemcpyAsync(p + o, grid->comm.red, sizeof(double) * c, hipMemcpyDeviceToDevice, grid->stream));
+        }
+        return TP_OK;
+    }
+
+    // Extreme Ritz values of `steps` Lanczos iterations on D^-1/2 A D^-1/2 with FULL
+    // reorthogonalisation (classical Gram-Schmidt twice): the estimates are then reproducible to
+    // ~1e-13 between implementations, which the residual-history parity needs.  All coefficients
+    // stay on the device; one host read at the end.
+    int lanczos(int l, int steps, double *lam_out, double *lam_min_out = nullptr) {
         Level<DOF> &L = lv[l];
-        double *v = L.b, *vp = L.r, *w = L.d, *t = L.x, *dis = L.x2;
-        const long off = L.own_off(), n = L.own_n();
-        const int nb = grid_for(n, MAX_RED_BLOCKS);
+        if (steps > 128) steps = 128;
+        const long off = L.own_off(), n = L.own_n(), nd = L.ndof();
+        const int nb = grid_for(n, 1024);
         const int gn = (int)((L.g.owned_nodes() + BLK - 1) / BLK);
         hipStream_t s = grid->stream;
-        TP_HIP(hipMemsetAsync(vp, 0, sizeof(double) * (size_t)L.ndof(), s));
-        hipLaunchKernelGGL((k_lanczos_init<DOF>), dim3(gn), dim3(BLK), 0, s, L.g, v, dis, L.dinv);
-        TP_TRY(dot_to_slot(grid, v + off, v + off, n, S_TMP));
-        double nv2;
-        TP_TRY(read_scal(grid, S_TMP, 1, &nv2));
-        hipLaunchKernelGGL(k_scale, dim3(grid_for(n)), dim3(BLK), 0, s, v + off, 1.0 / sqrt(nv2), n);
-        double al[64], be[64], beta = 0.0;
+        double *V = nullptr, *coef = nullptr;  // coef: h1[129] h2[129] alpha[128] beta[128] bb[1]
+        TP_HIP(hipMalloc((void **)&V, sizeof(double) * (size_t)nd * (size_t)(steps + 1)));
+        TP_HIP(hipMalloc((void **)&coef, sizeof(double) * 520));
+        TP_HIP(hipMemsetAsync(V, 0, sizeof(double) * (size_t)nd * (size_t)(steps + 1), s));
+        TP_HIP(hipMemsetAsync(coef, 0, sizeof(double) * 520, s));
+        double *h1 = coef, *h2 = coef + 129, *al = coef + 258, *be = coef + 386, *bb = coef + 514;
+        double *w = L.d, *t = L.x, *dis = L.x2;
+        hipLaunchKernelGGL((k_lanczos_init<DOF>), dim3(gn), dim3(BLK), 0, s, L.g, V, dis, L.dinv);
+        hipLaunchKernelGGL(k_multi_dot, dim3(nb), dim3(BLK), 0, s, V, nd, 1, V, off, n, grid->partials);
+        hipLaunchKernelGGL(k_reduce_multi, dim3(1), dim3(BLK), 0, s, grid->partials, nb, 1, bb);
+        TP_TRY(allreduce_dev(bb, 1));
+        hipLaunchKernelGGL(k_lanczos_next, dim3(grid_for(n)), dim3(BLK), 0, s, V, bb, 0, be, V, off, n);  // normalise v0
         int m = 0;
-        if (steps > 64) steps = 64;
         for (int j = 0; j < steps; j++) {
-            hipLaunchKernelGGL(k_pw_mult, dim3(grid_for(n)), dim3(BLK), 0, s, t + off, dis + off, v + off, n);
+            double *vj = V + (size_t)j * nd;
+            hipLaunchKernelGGL(k_pw_mult, dim3(grid_for(n)), dim3(BLK), 0, s, t + off, dis + off, vj + off, n);
             TP_TRY(apply(l, t, w));
-            hipLaunchKernelGGL(k_lanczos_a, dim3(nb), dim3(BLK), 0, s, w, dis, vp, v, beta, off, n, grid->partials);
-            TP_TRY(finish_reduction<1>(grid, nb, S_TMP));
-            double alpha;
-            TP_TRY(read_scal(grid, S_TMP, 1, &alpha));
-            hipLaunchKernelGGL(k_lanczos_b, dim3(nb), dim3(BLK), 0, s, w, v, alpha, off, n, grid->partials);
-            TP_TRY(finish_reduction<1>(grid, nb, S_TMP));
-            double b2;
-            TP_TRY(read_scal(grid, S_TMP, 1, &b2));
-            beta = sqrt(b2);
-            al[m] = alpha;
-            be[m] = beta;
+            hipLaunchKernelGGL(k_pw_mult, dim3(grid_for(n)), dim3(BLK), 0, s, w + off, dis + off, w + off, n);
+            for (int pass = 0; pass < 2; pass++) {
+                double *h = pass ? h2 : h1;
+                hipLaunchKernelGGL(k_multi_dot, dim3(nb), dim3(BLK), 0, s, V, nd, j + 1, w, off, n, grid->partials);
+                hipLaunchKernelGGL(k_reduce_multi, dim3(1), dim3(BLK), 0, s, grid->partials, nb, j + 1, h);
+                TP_TRY(allreduce_dev(h, j + 1));
+                hipLaunchKernelGGL(k_multi_axpy, dim3(grid_for(n)), dim3(BLK), 0, s, V, nd, j + 1, h, w, off, n);
+            }
+            hipLaunchKernelGGL(k_lanczos_alpha, dim3(1), dim3(64), 0, s, h1, h2, j, al);
+            hipLaunchKernelGGL(k_multi_dot, dim3(nb), dim3(BLK), 0, s, w, nd, 1, w, off, n, grid->partials);
+            hipLaunchKernelGGL(k_reduce_multi, dim3(1), dim3(BLK), 0, s, grid->partials, nb, 1, bb);
+            TP_TRY(allreduce_dev(bb, 1));
+            hipLaunchKernelGGL(k_lanczos_next, dim3(grid_for(n)), dim3(BLK), 0, s, w, bb, j, be, V + (size_t)(j + 1) * nd,
+                               off, n);
+            grid->launches += 12;
             m++;
-            if (beta < 1e-14 * fabs(alpha)) break;
-            hipLaunchKernelGGL(k_lanczos_c, dim3(grid_for(n)), dim3(BLK), 0, s, vp, v, w, 1.0 / beta, off, n);
-            grid->launches += 4;
         }
-        *lam_out = tridiag_lmax(m, al, be);
+        double hc[520];
+        TP_HIP(hipMemcpyAsync(hc, coef, sizeof(hc), hipMemcpyDeviceToHost, s));
+        TP_HIP(hipStreamSynchronize(s));
+        (void)hipFree(V);
+        (void)hipFree(coef);
+        const double *ha = hc + 258, *hb = hc + 386;
+        for (int j = 0; j < m; j++)  // breakdown (invariant subspace): truncate like the CPU path
+            if (!(hb[j] > 1e-14 * fabs(ha[j]))) {
+                m = j + 1;
+                break;
+            }
+        *lam_out = tridiag_lmax(m, ha, hb);
+        if (lam_min_out) *lam_min_out = tridiag_lmin(m, ha, hb);
         return TP_OK;
     }
 

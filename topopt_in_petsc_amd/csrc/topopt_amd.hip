@@ -127,6 +127,7 @@ extern "C" void tp_solver_default_opts(tp_solver_opts *o) {
     o->cheb_lo = 0.1;   // PETSc's default Chebyshev window 0.1 / 1.1 of the estimate
     o->cheb_hi = 1.1;
     o->nlanczos = 10;
+    o->fine_eig = 0;
 }
 
 struct tp_elasticity {
@@ -429,7 +430,7 @@ extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, dou
         }
     }
     mg.ready = true;
-    for (int l = 1; l < mg.nlv; l++) TP_TRY(mg.lanczos(l, mg.opt.nlanczos, &mg.lv[l].lam));
+    TP_TRY(mg.estimate_spectra(mg.opt.fine_eig ? 0 : 1));
     e->assembled = true;
     return TP_OK;
 }

@@ -32,7 +32,7 @@ class GridOpts(C.Structure):
 class SolverOpts(C.Structure):
     _fields_ = [("nlvls", C.c_int), ("nu", C.c_double), ("rtol", C.c_double), ("atol", C.c_double),
                 ("dtol", C.c_double), ("max_it", C.c_int), ("nsmooth", C.c_int), ("ncoarse", C.c_int),
-                ("cheb_lo", C.c_double), ("cheb_hi", C.c_double), ("nlanczos", C.c_int)]
+                ("cheb_lo", C.c_double), ("cheb_hi", C.c_double), ("nlanczos", C.c_int), ("fine_eig", C.c_int)]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_long)
