@@ -58,7 +58,7 @@ def cpu_baseline(sample, rtol, fine_eig):
     ex, ey, ez = [int(v) for v in sample.split("x")]
     nlv = 4
     nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
-    cores = os.cpu_count() or 1
+    cores = int(os.environ.get("OMP_NUM_THREADS", min(os.cpu_count() or 1, 16)))
     x = orc.synth_density(ex, ey, ez, h)
     KE = orc.hex8_ke_box(h, h, h, 0.3)
     N, R = orc.cantilever_bc(nx, ny, nz, h)

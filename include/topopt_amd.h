@@ -169,6 +169,23 @@ int tp_filter_gradients(tp_filter *f, const double *x, const double *xTilde, dou
 int tp_filter_mnd(tp_filter *f, const double *x, double *mnd);   /* GetMND, :206-225 */
 int tp_filter_last_pde_its(const tp_filter *f, int *its, double *rnorm);
 
+/* ---- MMA optimizer step on the device (MMA.cc) ------------ */
+typedef struct tp_mma tp_mma;
+/* MMA::MMA(n, m, x) (MMA.cc:108-190): a = 0, c = 1000, d = 0, asymptote factors 0.5 / 0.7 / 1.2.
+ * n_local = own design variables of this rank, n_global = all of them; x [dev, n_local]. */
+int tp_mma_create(tp_mma **mma, tp_grid *g, long n_local, long n_global, int m, const double *x);
+int tp_mma_destroy(tp_mma *mma);
+/* SetOuterMovelimit (MMA.cc:386-405) */
+int tp_mma_set_outer_movelimit(tp_mma *mma, double Xmin, double Xmax, double movlim, const double *x, double *xmin,
+                               double *xmax);
+/* Update (MMA.cc:499-518): x is overwritten by the new design.  gx: host array of m constraint
+ * values; dgdx: host array of m DEVICE pointers.  inner_its (may be NULL): Newton steps taken. */
+int tp_mma_update(tp_mma *mma, double *x, const double *dfdx, const double *gx, const double *const *dgdx,
+                  const double *xmin, const double *xmax, int *inner_its);
+/* DesignChange (MMA.cc:407-426): ch = max |x - xold| over all ranks, then xold <- x */
+int tp_mma_design_change(tp_mma *mma, const double *x, double *xold, double *ch);
+int tp_mma_get_state(const tp_mma *mma, double *lam, double *z, int *k);
+
 /* ---- streaming helpers used by the driver (main.cc:68-73, TopOpt.cc) ----- */
 int tp_vec_scale(tp_grid *g, double *x, double a, long n);
 int tp_vec_set(tp_grid *g, double *x, double a, long n);

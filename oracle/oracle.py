@@ -26,6 +26,9 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
+        # many tiny OpenMP regions + more threads than usable cores (containers) is pathologically slow
+        os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 16)))
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         _LIB = C.CDLL(build())
         L = _LIB
         L.orc_hash_u01.restype = C.c_double
@@ -79,6 +82,17 @@ def lib():
         L.orc_pdef_last_rnorm.argtypes = [C.c_void_p]
         L.orc_pdef_clamp.restype = C.c_long
         L.orc_pdef_clamp.argtypes = [C.c_long, C.c_void_p]
+        L.orc_mma_create.restype = C.c_void_p
+        L.orc_mma_create.argtypes = [C.c_long, C.c_int, C.c_void_p]
+        L.orc_mma_destroy.argtypes = [C.c_void_p]
+        L.orc_mma_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_mma_outer_movelimit.argtypes = [C.c_long, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
+                                              C.c_void_p]
+        L.orc_mma_design_change.restype = C.c_double
+        L.orc_mma_design_change.argtypes = [C.c_long, C.c_void_p, C.c_void_p]
+        L.orc_mma_update.restype = C.c_int
+        L.orc_mma_update.argtypes = [C.c_void_p] * 7
+        L.orc_mma_kkt.argtypes = [C.c_void_p] * 9
         L.orc_simp.argtypes = [C.c_long, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p]
         L.orc_synth_density.argtypes = [C.c_int] * 5 + [C.c_double, C.c_uint64, C.c_void_p]
         L.orc_matfree_apply.argtypes = [C.c_int] * 4 + [C.c_void_p] * 5
@@ -313,3 +327,48 @@ def heaviside_chain(xt, beta, eta):
 def mnd(x):
     x = f64(x)
     return lib().orc_mnd(x.size, _p(x))
+
+
+class MMA:
+    """oracle MMA (mma_oracle.c); vectors are numpy arrays, dgdx a list of m arrays"""
+
+    def __init__(self, x, m=1):
+        self.L = lib()
+        self.n, self.m = x.size, m
+        self.h = self.L.orc_mma_create(self.n, m, _p(f64(x)))
+        self.last_inner = 0
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_mma_destroy(self.h)
+            self.h = None
+
+    def SetOuterMovelimit(self, Xmin, Xmax, movlim, x):
+        xmin, xmax = np.zeros(self.n), np.zeros(self.n)
+        self.L.orc_mma_outer_movelimit(self.n, Xmin, Xmax, movlim, _p(f64(x)), _p(xmin), _p(xmax))
+        return xmin, xmax
+
+    def Update(self, x, dfdx, gx, dgdx, xmin, xmax):
+        """returns the new design"""
+        xn = f64(x).copy()
+        g = f64(np.asarray(gx, dtype=np.float64))
+        dg = f64(np.concatenate([f64(d) for d in dgdx]))
+        self.last_inner = self.L.orc_mma_update(self.h, _p(xn), _p(f64(dfdx)), _p(g), _p(dg), _p(f64(xmin)),
+                                                _p(f64(xmax)))
+        return xn
+
+    def DesignChange(self, x, xold):
+        return self.L.orc_mma_design_change(self.n, _p(f64(x)), _p(xold))
+
+    def state(self):
+        lam = np.zeros(self.m)
+        z = C.c_double()
+        self.L.orc_mma_get_state(self.h, _p(lam), C.addressof(z), None, None)
+        return lam, z.value
+
+    def kkt(self, x, dfdx, fx, dgdx, xmin, xmax):
+        n2, ni = C.c_double(), C.c_double()
+        dg = f64(np.concatenate([f64(d) for d in dgdx]))
+        self.L.orc_mma_kkt(self.h, _p(f64(x)), _p(f64(dfdx)), _p(f64(np.asarray(fx, dtype=np.float64))), _p(dg),
+                           _p(f64(xmin)), _p(f64(xmax)), C.addressof(n2), C.addressof(ni))
+        return n2.value, ni.value

@@ -74,7 +74,7 @@ ORC_API double orc_hash_u01(uint64_t idx, uint64_t seed) { return hash_u01(idx, 
 static double vdot(long n, const double *a, const double *b) {
     long nch = (n + RED_CHUNK - 1) / RED_CHUNK;
     double *part = (double *)xmalloc(sizeof(double) * (size_t)nch);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n > 400000)
     for (long c = 0; c < nch; c++) {
         long lo = c * RED_CHUNK, hi = lo + RED_CHUNK > n ? n : lo + RED_CHUNK;
         double s = 0.0;
@@ -90,7 +90,7 @@ static double vnorm(long n, const double *a) { return sqrt(vdot(n, a, a)); }
 static double vsum(long n, const double *a) {
     long nch = (n + RED_CHUNK - 1) / RED_CHUNK;
     double *part = (double *)xmalloc(sizeof(double) * (size_t)nch);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n > 400000)
     for (long c = 0; c < nch; c++) {
         long lo = c * RED_CHUNK, hi = lo + RED_CHUNK > n ? n : lo + RED_CHUNK;
         double s = 0.0;
@@ -357,7 +357,7 @@ static void csr_free(csr_t *A) {
 }
 
 static void csr_spmv(const csr_t *A, const double *x, double *y) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (A->nrow > 100000)
     for (long r = 0; r < A->nrow; r++) {
         double s = 0.0;
         for (long p = A->rp[r]; p < A->rp[r + 1]; p++) s += A->v[p] * x[A->ci[p]];

@@ -1,0 +1,116 @@
+"""MMA: the oracle restatement on CPU (properties), and the device implementation
+against it (GPU)."""
+import numpy as np
+import pytest
+
+
+def _toy(n=2000, seed=0):
+    """a separable convex problem: min sum c_i / x_i  s.t. mean(x) <= v"""
+    rng = np.random.default_rng(seed)
+    c = rng.random(n) + 0.1
+    return c, 0.3
+
+
+def test_oracle_mma_converges_to_kkt_point(orc):
+    c, v = _toy()
+    n = c.size
+    x = np.full(n, v)
+    mma = orc.MMA(x, 1)
+    xold = x.copy()
+    f_hist = []
+    for it in range(40):
+        f = (c / x).sum()
+        df = -c / x ** 2
+        g = x.mean() - v
+        dg = np.full(n, 1.0 / n)
+        scale = 10.0 / f_hist[0] if f_hist else 10.0 / f
+        f_hist.append(f)
+        xmin, xmax = mma.SetOuterMovelimit(1e-3, 1.0, 0.2, x)
+        x = mma.Update(x, df * scale, [g], [dg], xmin, xmax)
+        assert (x >= xmin - 1e-15).all() and (x <= xmax + 1e-15).all()
+        ch = mma.DesignChange(x, xold)
+        if ch < 1e-4:
+            break
+    assert f_hist[-1] < f_hist[0]
+    assert abs(x.mean() - v) < 1e-6                      # constraint active
+    # analytic optimum: x_i proportional to sqrt(c_i) (clipped), mean v
+    xs = np.sqrt(c)
+    xs *= v / xs.mean()
+    assert np.abs(x - xs).max() < 5e-3
+    lam, z = mma.state()
+    assert lam[0] > 0 and z == 0.0
+
+
+@pytest.mark.gpu
+def test_device_mma_matches_oracle(orc):
+    import torch
+    import topopt_in_petsc_amd as tp
+    c, v = _toy(12 * 8 * 8)
+    n = c.size
+    grid = tp.Grid(13, 9, 9, 0.125)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    x = np.full(n, v)
+    xd = dev(x)
+    m_o, m_d = orc.MMA(x, 1), tp.MMA(grid, xd, 1)
+    xold_o, xold_d = x.copy(), dev(x)
+    xmin_d, xmax_d = grid.elem_vec(), grid.elem_vec()
+    for it in range(8):
+        f = (c / x).sum()
+        df = -c / x ** 2 * (10.0 / 2000.0)
+        g = x.mean() - v
+        dg = np.full(n, 1.0 / n)
+        xmin, xmax = m_o.SetOuterMovelimit(1e-3, 1.0, 0.2, x)
+        m_d.SetOuterMovelimit(1e-3, 1.0, 0.2, xd, xmin_d, xmax_d)
+        assert np.array_equal(xmin_d.cpu().numpy(), xmin) and np.array_equal(xmax_d.cpu().numpy(), xmax)
+        x = m_o.Update(x, df, [g], [dg], xmin, xmax)
+        m_d.Update(xd, dev(df), [g], [dev(dg)], xmin_d, xmax_d)
+        assert m_d.last_inner == m_o.last_inner
+        xg = xd.cpu().numpy()
+        assert np.abs(xg - x).max() <= 1e-12, (it, np.abs(xg - x).max())
+        assert m_d.state()[0][0] == pytest.approx(m_o.state()[0][0], rel=1e-11)
+        ch_o = m_o.DesignChange(x, xold_o)
+        assert m_d.DesignChange(xd, xold_d) == pytest.approx(ch_o, abs=1e-12)
+        xd.copy_(dev(x))  # identical inputs for the next step
+
+
+@pytest.mark.gpu
+def test_optimisation_loop_matches_oracle_loop(orc):
+    """main.cc's loop on the device vs the same loop driven by the oracle, 48x24x24-like small mesh"""
+    import topopt_in_petsc_amd as tp
+    ex, ey, ez, nlv = 32, 16, 16, 3
+    nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
+    rmin = 2.56 * h
+    opt = tp.TopOpt(nxyz=(nx, ny, nz), xc=(0, 2, 0, 1, 0, 1), nlvls=nlv, rmin=rmin,
+                    solver=tp.SolverOptions(nlvls=nlv, rtol=1e-8))
+    # ---- oracle loop
+    KE = orc.hex8_ke_box(h, h, h, 0.3)
+    N, R = orc.cantilever_bc(nx, ny, nz, h)
+    flt = orc.Filter(nx, ny, nz, h, rmin)
+    mg = orc.MG(nx, ny, nz, 3, nlv)
+    n = ex * ey * ez
+    x = np.full(n, 0.12)
+    xt, xp = flt.project(1, x)
+    mma = orc.MMA(x, 1)
+    xold = x.copy()
+    U = np.zeros(3 * nx * ny * nz)
+    fscale = None
+    for it in range(6):
+        rec = opt.step()
+        mg.assemble(KE, orc.simp(xp), N)
+        U, its, hist = mg.solve(R * N, x0=U, rtol=1e-8)
+        fx, gx, df, dg = orc.compliance_sens(nx, ny, nz, KE, U, xp)
+        if fscale is None:
+            fscale = 10.0 / fx
+        df = flt.gradient(1, x, xt, df * fscale)
+        dg = flt.gradient(1, x, xt, dg)
+        xmin, xmax = mma.SetOuterMovelimit(0.0, 1.0, 0.2, x)
+        x = mma.Update(x, df, [gx], [dg], xmin, xmax)
+        ch = mma.DesignChange(x, xold)
+        xt, xp = flt.project(1, x)
+        assert rec["ksp_its"] == its, (it, rec["ksp_its"], its)
+        assert rec["fx"] == pytest.approx(fx, rel=1e-7)
+        assert rec["gx"] == pytest.approx(gx, abs=1e-10)
+        assert rec["ch"] == pytest.approx(ch, abs=1e-7)
+        assert rec["mnd"] == pytest.approx(orc.mnd(xp), rel=1e-7)
+        assert np.abs(opt.x.cpu().numpy() - x).max() <= 1e-6
+    assert opt.history[-1]["fx"] < opt.history[0]["fx"]

@@ -7,4 +7,5 @@ and torch.distributed for the z-slab halo exchange.
 """
 from .lib import load_library, LibraryMissing  # noqa: F401
 from .partition import SlabPartition  # noqa: F401
-from .api import Grid, LinearElasticity, Filter, SolverOptions, TopOptError  # noqa: F401
+from .api import Grid, LinearElasticity, Filter, MMA, SolverOptions, TopOptError  # noqa: F401
+from .driver import TopOpt  # noqa: F401

@@ -266,3 +266,43 @@ class Filter:
         its, rn = C.c_int(), C.c_double()
         self.L.tp_filter_last_pde_its(self.handle, C.byref(its), C.byref(rn))
         return its.value, rn.value
+
+
+class MMA:
+    """MMA (MMA.h:29-140) on the device: the design vectors stay in HBM."""
+
+    def __init__(self, grid, x, m=1, n_global=None):
+        self.grid, self.L, self.m = grid, grid.L, m
+        self.handle = C.c_void_p()
+        n_loc = x.numel()
+        n_glob = n_global if n_global is not None else grid.part.ex * grid.part.ey * grid.part.ez
+        _chk(self.L.tp_mma_create(C.byref(self.handle), grid.handle, n_loc, n_glob, m, _ptr(x)), "tp_mma_create")
+        self.last_inner = 0
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            self.L.tp_mma_destroy(self.handle)
+            self.handle = None
+
+    def SetOuterMovelimit(self, Xmin, Xmax, movlim, x, xmin, xmax):
+        _chk(self.L.tp_mma_set_outer_movelimit(self.handle, Xmin, Xmax, movlim, _ptr(x), _ptr(xmin), _ptr(xmax)),
+             "tp_mma_set_outer_movelimit")
+
+    def Update(self, x, dfdx, gx, dgdx, xmin, xmax):
+        g = (C.c_double * self.m)(*gx)
+        dg = (C.c_void_p * self.m)(*[_ptr(t) for t in dgdx])
+        it = C.c_int()
+        _chk(self.L.tp_mma_update(self.handle, _ptr(x), _ptr(dfdx), g, dg, _ptr(xmin), _ptr(xmax), C.byref(it)),
+             "tp_mma_update")
+        self.last_inner = it.value
+
+    def DesignChange(self, x, xold):
+        ch = C.c_double()
+        _chk(self.L.tp_mma_design_change(self.handle, _ptr(x), _ptr(xold), C.byref(ch)), "tp_mma_design_change")
+        return ch.value
+
+    def state(self):
+        lam = (C.c_double * self.m)()
+        z, k = C.c_double(), C.c_int()
+        self.L.tp_mma_get_state(self.handle, lam, C.byref(z), C.byref(k))
+        return list(lam), z.value, k.value

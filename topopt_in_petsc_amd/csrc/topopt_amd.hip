@@ -565,3 +565,8 @@ extern "C" int tp_elasticity_last_stats(const tp_elasticity *e, double *alg_byte
 // density / sensitivity filter and Helmholtz PDE filter
 // ===========================================================================
 #include "filter.h"
+
+// ===========================================================================
+// optimizer step around the path (MMA), SURVEY.md 8(f)-1
+// ===========================================================================
+#include "mma.h"

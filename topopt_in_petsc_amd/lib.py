@@ -88,6 +88,12 @@ SYMBOLS = {
     "tp_filter_gradients": (_i, [_vp, _vp, _vp, _vp, _i, C.POINTER(_vp), _i, _d, _d]),
     "tp_filter_mnd": (_i, [_vp, _vp, C.POINTER(_d)]),
     "tp_filter_last_pde_its": (_i, [_vp, C.POINTER(_i), C.POINTER(_d)]),
+    "tp_mma_create": (_i, [C.POINTER(_vp), _vp, _l, _l, _i, _vp]),
+    "tp_mma_destroy": (_i, [_vp]),
+    "tp_mma_set_outer_movelimit": (_i, [_vp, _d, _d, _d, _vp, _vp, _vp]),
+    "tp_mma_update": (_i, [_vp, _vp, _vp, C.POINTER(_d), C.POINTER(_vp), _vp, _vp, C.POINTER(_i)]),
+    "tp_mma_design_change": (_i, [_vp, _vp, _vp, C.POINTER(_d)]),
+    "tp_mma_get_state": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_i)]),
     "tp_vec_scale": (_i, [_vp, _vp, _d, _l]),
     "tp_vec_set": (_i, [_vp, _vp, _d, _l]),
     "tp_synth_density": (_i, [_vp, _vp, C.c_uint64]),
