@@ -15,8 +15,9 @@
 // are redone by a generic kernel.  Coarse element matrices are finally
 // collapsed to the 27-point block stencil (DiaOp) used by the smoothers.
 //
-// Element matrices are stored entry-major ("SoA"): Kel[entry * nE + elem],
-// entry = (3I+r)*24 + 3J+c, so that consecutive threads (elements) coalesce.
+// Element matrices are stored element-major: Kel[elem * 576 + entry], entry = (3I+r)*24 + 3J+c:
+// the kernels that build them work one coarse element per workgroup with the entries spread over
+// the threads, so every load/store of a matrix is one contiguous 4.6 kB stream.
 #pragma once
 #include "common.h"
 
@@ -55,12 +56,10 @@ inline void host_child_matrices(const double *KE, double *M) {
                     }
 }
 
-// ---- level 0 -> 1, fast path: one thread per own coarse element ------------
-__global__ __launch_bounds__(BLK) void k_galerkin_fine_fast(Geom gf, Geom gc, const double *__restrict__ E,
+// ---- level 0 -> 1, fast path: one 192-thread workgroup per own coarse element, 3 entries per thread
+__global__ __launch_bounds__(192) void k_galerkin_fine_fast(Geom gf, Geom gc, const double *__restrict__ E,
                                                             const double *__restrict__ M, double *__restrict__ Kel) {
-    const long nEc = gc.elems_stored();
-    const long t = blockIdx.x * (long)BLK + threadIdx.x;
-    if (t >= gc.own_elems()) return;
+    const long t = blockIdx.x;  // own coarse element
     const int I = (int)(t % gc.ex), J = (int)((t / gc.ex) % gc.ey), K = (int)(t / ((long)gc.ex * gc.ey));
     double Ec[8];
 #pragma unroll
@@ -68,11 +67,13 @@ __global__ __launch_bounds__(BLK) void k_galerkin_fine_fast(Geom gf, Geom gc, co
         const int i = 2 * I + (c & 1), j = 2 * J + ((c >> 1) & 1), k = 2 * K + ((c >> 2) & 1);
         Ec[c] = E[(long)i + (long)gf.ex * (j + (long)gf.ey * k)];
     }
-    for (int e = 0; e < 576; e++) {
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const int e = threadIdx.x + 192 * q;
         double s = 0.0;
 #pragma unroll
         for (int c = 0; c < 8; c++) s = fma(Ec[c], M[c * 576 + e], s);
-        Kel[(long)e * nEc + t] = s;
+        Kel[t * 576 + e] = s;
     }
 }
 
@@ -82,7 +83,6 @@ __global__ __launch_bounds__(64) void k_galerkin_fine_masked(Geom gf, Geom gc, c
                                                              const double *__restrict__ KE,
                                                              const uint8_t *__restrict__ mask,
                                                              const int *__restrict__ list, double *__restrict__ Kel) {
-    const long nEc = gc.elems_stored();
     const long t = list[blockIdx.x];
     const int Ie = (int)(t % gc.ex), Je = (int)((t / gc.ex) % gc.ey), Ke = (int)(t / ((long)gc.ex * gc.ey));
     const int I = threadIdx.x >> 3, J = threadIdx.x & 7;
@@ -120,42 +120,63 @@ __global__ __launch_bounds__(64) void k_galerkin_fine_masked(Geom gf, Geom gc, c
         }
     }
     for (int r = 0; r < 3; r++)
-        for (int cc = 0; cc < 3; cc++) Kel[(long)((3 * I + r) * 24 + 3 * J + cc) * nEc + t] = acc[r * 3 + cc];
+        for (int cc = 0; cc < 3; cc++) Kel[t * 576 + (3 * I + r) * 24 + 3 * J + cc] = acc[r * 3 + cc];
 }
 
-// ---- level l -> l+1 (l >= 1): thread = (coarse element, I, J) ---------------
-__global__ __launch_bounds__(BLK) void k_galerkin_coarse(Geom gf, Geom gc, const double *__restrict__ Kf,
-                                                         double *__restrict__ Kc) {
-    const long nEf = gf.elems_stored(), nEc = gc.elems_stored(), nown = gc.own_elems();
-    const long t = blockIdx.x * (long)BLK + threadIdx.x;
-    if (t >= nown * 64) return;
-    const int IJ = (int)(t / nown);
-    const long el = t % nown;
-    const int I = IJ >> 3, J = IJ & 7;
+// ---- level l -> l+1 (l >= 1): one wave per coarse element.
+// K_E = sum_c W_c^T K_c W_c with W_c a tensor product of per-axis 2x2 weights
+//   child on the low side : w[a][I] = {{1, 0}, {.5, .5}},  high side: {{.5, .5}, {0, 1}}
+// -> six in-LDS contractions (3 row axes, 3 column axes) of the 576-entry child matrix instead of
+// the dense 64x64 triple product (8x fewer flops, and every matrix is read exactly once, coalesced).
+__device__ __constant__ int c_FLIP[3][8] = {{1, 0, 3, 2, 5, 4, 7, 6}, {3, 2, 1, 0, 7, 6, 5, 4}, {4, 5, 6, 7, 0, 1, 2, 3}};
+__global__ __launch_bounds__(64) void k_galerkin_coarse(Geom gf, Geom gc, const double *__restrict__ Kf,
+                                                        double *__restrict__ Kc) {
+    __shared__ double A[576], B[576];
+    const long el = blockIdx.x;  // own coarse element
     const int Ie = (int)(el % gc.ex), Je = (int)((el / gc.ex) % gc.ey), Ke = (int)(el / ((long)gc.ex * gc.ey));
+    const int t = threadIdx.x;
     double acc[9];
 #pragma unroll
     for (int q = 0; q < 9; q++) acc[q] = 0.0;
     for (int c = 0; c < 8; c++) {
         const long ch = (long)(2 * Ie + (c & 1)) + (long)gf.ex * ((2 * Je + ((c >> 1) & 1)) + (long)gf.ey * (2 * Ke + ((c >> 2) & 1)));
-        for (int a = 0; a < 8; a++) {
-            const double wa = c_W[(c * 8 + a) * 8 + I];
-            if (wa == 0.0) continue;
-            for (int b = 0; b < 8; b++) {
-                const double w = wa * c_W[(c * 8 + b) * 8 + J];
-                if (w == 0.0) continue;
+        const double *__restrict__ src = Kf + ch * 576;
 #pragma unroll
-                for (int r = 0; r < 3; r++)
+        for (int q = 0; q < 9; q++) A[t + 64 * q] = src[t + 64 * q];
+        __syncthreads();
+        double *in = A, *out = B;
+        for (int pass = 0; pass < 6; pass++) {
+            const int d = pass % 3;            // axis
+            const bool rows = pass < 3;        // contract the row (a) or the column (b) node index
+            const int hi = (c >> d) & 1;       // child on the high side of this axis
 #pragma unroll
-                    for (int cc = 0; cc < 3; cc++)
-                        acc[r * 3 + cc] = fma(w, Kf[(long)((3 * a + r) * 24 + 3 * b + cc) * nEf + ch], acc[r * 3 + cc]);
+            for (int q = 0; q < 9; q++) {
+                const int o = t + 64 * q;
+                const int row = o / 24, col = o % 24;
+                const int nd = rows ? row / 3 : col / 3;  // node index being contracted (as coarse corner I_d)
+                const int lbit = d == 0 ? c_LX[nd] : (d == 1 ? c_LY[nd] : c_LZ[nd]);
+                const int fl = c_FLIP[d][nd];
+                const int o2 = rows ? (fl * 3 + row % 3) * 24 + col : row * 24 + fl * 3 + col % 3;
+                // in0 = value at fine node bit 0, in1 = at fine node bit 1 (other indices equal)
+                const double v_same = in[o], v_flip = in[o2];
+                const double in0 = lbit ? v_flip : v_same, in1 = lbit ? v_same : v_flip;
+                double r;
+                if (!hi) r = lbit ? 0.5 * in1 : in0 + 0.5 * in1;  // w = {{1,0},{.5,.5}}
+                else r = lbit ? 0.5 * in0 + in1 : 0.5 * in0;      // w = {{.5,.5},{0,1}}
+                out[o] = r;
             }
+            __syncthreads();
+            double *tmp = in;
+            in = out;
+            out = tmp;
         }
+        // after 6 passes the result is back in A (in == A)
+#pragma unroll
+        for (int q = 0; q < 9; q++) acc[q] += in[t + 64 * q];
+        __syncthreads();
     }
 #pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int cc = 0; cc < 3; cc++) Kc[(long)((3 * I + r) * 24 + 3 * J + cc) * nEc + el] = acc[r * 3 + cc];
+    for (int q = 0; q < 9; q++) Kc[el * 576 + t + 64 * q] = acc[q];
 }
 
 // ---- collapse element matrices to the 27-point block stencil ----------------
@@ -163,7 +184,6 @@ __global__ __launch_bounds__(BLK) void k_galerkin_coarse(Geom gf, Geom gc, const
 // Jacobi inverse diagonal from the centre block.
 __global__ __launch_bounds__(BLK) void k_elem_to_dia(Geom g, const double *__restrict__ Kel, double *__restrict__ S,
                                                      double *__restrict__ dinv) {
-    const long nE = g.elems_stored();
     const long nrows = 3 * g.nodes();
     const long plane = g.plane();
     const long t = blockIdx.x * (long)BLK + threadIdx.x;
@@ -188,7 +208,7 @@ __global__ __launch_bounds__(BLK) void k_elem_to_dia(Geom g, const double *__res
 #pragma unroll
         for (int r = 0; r < 3; r++)
 #pragma unroll
-            for (int cc = 0; cc < 3; cc++) acc[r * 3 + cc] += Kel[(long)((3 * I + r) * 24 + 3 * J + cc) * nE + el];
+            for (int cc = 0; cc < 3; cc++) acc[r * 3 + cc] += Kel[el * 576 + (3 * I + r) * 24 + 3 * J + cc];
     }
 #pragma unroll
     for (int cc = 0; cc < 3; cc++)
@@ -203,7 +223,6 @@ __global__ __launch_bounds__(BLK) void k_elem_to_dia(Geom g, const double *__res
 // Jacobi inverse diagonal straight from the coarse element matrices (levels whose
 // operator is applied matrix-free): thread = owned node
 __global__ __launch_bounds__(BLK) void k_elem_diag(Geom g, const double *__restrict__ Kel, double *__restrict__ dinv) {
-    const long nE = g.elems_stored();
     const long plane = g.plane();
     const long t = blockIdx.x * (long)BLK + threadIdx.x;
     if (t >= g.owned_nodes()) return;
@@ -217,7 +236,7 @@ __global__ __launch_bounds__(BLK) void k_elem_diag(Geom g, const double *__restr
         if (ei < 0 || ei >= g.ex || ej < 0 || ej >= g.ey || ek < 0 || ek >= g.ezl) continue;
         const long el = (long)ei + (long)g.ex * (ej + (long)g.ey * ek);
 #pragma unroll
-        for (int r = 0; r < 3; r++) acc[r] += Kel[(long)((3 * I + r) * 25) * nE + el];
+        for (int r = 0; r < 3; r++) acc[r] += Kel[el * 576 + (3 * I + r) * 25];
     }
 #pragma unroll
     for (int r = 0; r < 3; r++) dinv[n * 3 + r] = 1.0 / acc[r];
@@ -231,7 +250,7 @@ __global__ __launch_bounds__(BLK) void k_macro_delta(Geom gf, Geom gc, const dou
                                                      const int *__restrict__ list, int nlist, double *__restrict__ dK) {
     const long t = blockIdx.x * (long)BLK + threadIdx.x;
     if (t >= (long)nlist * 576) return;
-    const int e = (int)(t / nlist), f = (int)(t % nlist);
+    const int f = (int)(t / 576), e = (int)(t % 576);  // e fastest: coalesced reads of Kel
     const long ce = list[f];
     const int I = (int)(ce % gc.ex), J = (int)((ce / gc.ex) % gc.ey), K = (int)(ce / ((long)gc.ex * gc.ey));
     double s = 0.0;
@@ -240,7 +259,7 @@ __global__ __launch_bounds__(BLK) void k_macro_delta(Geom gf, Geom gc, const dou
         const int i = 2 * I + (c & 1), j = 2 * J + ((c >> 1) & 1), k = 2 * K + ((c >> 2) & 1);
         s = fma(E[(long)i + (long)gf.ex * (j + (long)gf.ey * k)], M[c * 576 + e], s);
     }
-    dK[t] = Kel[(long)e * gc.elems_stored() + ce] - s;
+    dK[(long)e * nlist + f] = Kel[ce * 576 + e] - s;
 }
 // tmp[r][f] = dK_E[row r] . x_E ; thread = (row r of 24, flagged element f), coalesced over f
 __global__ __launch_bounds__(BLK) void k_macro_corr_rows(Geom g, const double *__restrict__ dK,

@@ -105,27 +105,25 @@ __global__ __launch_bounds__(BLK) void k_lanczos_init(Geom g, double *__restrict
         dis[n * DOF + c] = sqrt(dinv[n * DOF + c]);
     }
 }
-// partials[q*nb + b] = sum over block b of V_q . w   (q = 0..nv-1; V_q = V + q*stride)
+// partials[q*nb + b] = sum over block b of V_q . w   (grid = (nb, nv); V_q = V + q*stride)
 __global__ __launch_bounds__(BLK) void k_multi_dot(const double *__restrict__ V, long stride, int nv,
                                                    const double *__restrict__ w, long off, long n,
                                                    double *__restrict__ partials) {
-    for (int q = 0; q < nv; q++) {
-        const double *__restrict__ vq = V + (long)q * stride;
-        double s = 0.0;
-        for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) s = fma(vq[off + i], w[off + i], s);
-        s = block_sum(s);
-        if (threadIdx.x == 0) partials[(long)q * gridDim.x + blockIdx.x] = s;
-    }
+    const int q = blockIdx.y;
+    const double *__restrict__ vq = V + (long)q * stride;
+    double s = 0.0;
+    for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) s = fma(vq[off + i], w[off + i], s);
+    s = block_sum(s);
+    if (threadIdx.x == 0) partials[(long)q * gridDim.x + blockIdx.x] = s;
 }
-// out[q] (+)= sum_b partials[q*nb + b]; one workgroup
+// out[q] = sum_b partials[q*nb + b]; one workgroup per value (grid = nv)
 __global__ __launch_bounds__(BLK) void k_reduce_multi(const double *__restrict__ partials, int nb, int nv,
                                                       double *__restrict__ out) {
-    for (int q = 0; q < nv; q++) {
-        double s = 0.0;
-        for (int b = threadIdx.x; b < nb; b += BLK) s += partials[(long)q * nb + b];
-        s = block_sum(s);
-        if (threadIdx.x == 0) out[q] = s;
-    }
+    const int q = blockIdx.x;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nb; b += BLK) s += partials[(long)q * nb + b];
+    s = block_sum(s);
+    if (threadIdx.x == 0) out[q] = s;
 }
 // w -= sum_q h[q] V_q ; acc[q] += h[q]  (device-resident coefficients)
 __global__ __launch_bounds__(BLK) void k_multi_axpy(const double *__restrict__ V, long stride, int nv,
@@ -459,7 +457,7 @@ struct MGSolver {
         Level<DOF> &L = lv[l];
         if (steps > 128) steps = 128;
         const long off = L.own_off(), n = L.own_n(), nd = L.ndof();
-        const int nb = grid_for(n, 1024);
+        const int nb = grid_for(n, 256);
         const int gn = (int)((L.g.owned_nodes() + BLK - 1) / BLK);
         hipStream_t s = grid->stream;
         double *V = nullptr, *coef = nullptr;  // coef: h1[129] h2[129] alpha[128] beta[128] bb[1]
@@ -470,7 +468,7 @@ struct MGSolver {
         double *h1 = coef, *h2 = coef + 129, *al = coef + 258, *be = coef + 386, *bb = coef + 514;
         double *w = L.d, *t = L.x, *dis = L.x2;
         hipLaunchKernelGGL((k_lanczos_init<DOF>), dim3(gn), dim3(BLK), 0, s, L.g, V, dis, L.dinv);
-        hipLaunchKernelGGL(k_multi_dot, dim3(nb), dim3(BLK), 0, s, V, nd, 1, V, off, n, grid->partials);
+        hipLaunchKernelGGL(k_multi_dot, dim3(nb, 1), dim3(BLK), 0, s, V, nd, 1, V, off, n, grid->partials);
         hipLaunchKernelGGL(k_reduce_multi, dim3(1), dim3(BLK), 0, s, grid->partials, nb, 1, bb);
         TP_TRY(allreduce_dev(bb, 1));
         hipLaunchKernelGGL(k_lanczos_next, dim3(grid_for(n)), dim3(BLK), 0, s, V, bb, 0, be, V, off, n);  // normalise v0
@@ -482,13 +480,13 @@ struct MGSolver {
             hipLaunchKernelGGL(k_pw_mult, dim3(grid_for(n)), dim3(BLK), 0, s, w + off, dis + off, w + off, n);
             for (int pass = 0; pass < 2; pass++) {
                 double *h = pass ? h2 : h1;
-                hipLaunchKernelGGL(k_multi_dot, dim3(nb), dim3(BLK), 0, s, V, nd, j + 1, w, off, n, grid->partials);
-                hipLaunchKernelGGL(k_reduce_multi, dim3(1), dim3(BLK), 0, s, grid->partials, nb, j + 1, h);
+                hipLaunchKernelGGL(k_multi_dot, dim3(nb, j + 1), dim3(BLK), 0, s, V, nd, j + 1, w, off, n, grid->partials);
+                hipLaunchKernelGGL(k_reduce_multi, dim3(j + 1), dim3(BLK), 0, s, grid->partials, nb, j + 1, h);
                 TP_TRY(allreduce_dev(h, j + 1));
                 hipLaunchKernelGGL(k_multi_axpy, dim3(grid_for(n)), dim3(BLK), 0, s, V, nd, j + 1, h, w, off, n);
             }
             hipLaunchKernelGGL(k_lanczos_alpha, dim3(1), dim3(64), 0, s, h1, h2, j, al);
-            hipLaunchKernelGGL(k_multi_dot, dim3(nb), dim3(BLK), 0, s, w, nd, 1, w, off, n, grid->partials);
+            hipLaunchKernelGGL(k_multi_dot, dim3(nb, 1), dim3(BLK), 0, s, w, nd, 1, w, off, n, grid->partials);
             hipLaunchKernelGGL(k_reduce_multi, dim3(1), dim3(BLK), 0, s, grid->partials, nb, 1, bb);
             TP_TRY(allreduce_dev(bb, 1));
             hipLaunchKernelGGL(k_lanczos_next, dim3(grid_for(n)), dim3(BLK), 0, s, w, bb, j, be, V + (size_t)(j + 1) * nd,

@@ -174,7 +174,7 @@ struct tp_mma {
 
 static int mma_reduce(tp_mma *M, int nb, int nv, double *host) {
     tp_grid *g = M->grid;
-    hipLaunchKernelGGL(k_reduce_multi, dim3(1), dim3(BLK), 0, g->stream, g->partials, nb, nv, M->red);
+    hipLaunchKernelGGL(k_reduce_multi, dim3(nv), dim3(BLK), 0, g->stream, g->partials, nb, nv, M->red);
     count_launch(g);
     if (g->has_comm)
         for (int o = 0; o < nv; o += 16) {

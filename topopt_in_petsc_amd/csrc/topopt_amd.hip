@@ -399,8 +399,8 @@ extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, dou
         Level<3> &F = mg.lv[l - 1], &C = mg.lv[l];
         const long nEc = C.g.own_elems();
         if (l == 1) {
-            hipLaunchKernelGGL(k_galerkin_fine_fast, dim3((int)((nEc + BLK - 1) / BLK)), dim3(BLK), 0, s, F.g, C.g,
-                               e->d_E, e->d_M, C.Kel);
+            hipLaunchKernelGGL(k_galerkin_fine_fast, dim3((unsigned)nEc), dim3(192), 0, s, F.g, C.g, e->d_E, e->d_M,
+                               C.Kel);
             count_launch(g, 8.0 * nel + 8.0 * 576 * nEc, 2.0 * 8 * 576 * nEc);
             if (e->nflagged) {
                 hipLaunchKernelGGL(k_galerkin_fine_masked, dim3(e->nflagged), dim3(64), 0, s, F.g, C.g, e->d_E, e->d_KE,
@@ -408,13 +408,13 @@ extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, dou
                 count_launch(g);
             }
         } else {
-            hipLaunchKernelGGL(k_galerkin_coarse, dim3((int)((nEc * 64 + BLK - 1) / BLK)), dim3(BLK), 0, s, F.g, C.g,
-                               F.Kel, C.Kel);
+            hipLaunchKernelGGL(k_galerkin_coarse, dim3((unsigned)nEc), dim3(64), 0, s, F.g, C.g, F.Kel, C.Kel);
             count_launch(g, 8.0 * 576 * (9.0 * nEc), 2.0 * 0.18 * 8 * 64 * 64 * 9 * nEc);
         }
         // coarse ghost element layer above <- upper neighbour's first own layer
         const long clay = (long)C.g.ex * C.g.ey;
-        TP_TRY(exchange_segments(g, C.Kel, nullptr, nullptr, C.Kel + clay * C.g.ez_own, clay, 576, C.g.elems_stored()));
+        // (one contiguous block of 576*clay doubles, cut into rows of `clay` so that it fits the staging buffers)
+        TP_TRY(exchange_segments(g, C.Kel, nullptr, nullptr, C.Kel + 576 * clay * C.g.ez_own, clay, 576, clay));
         const int gn = (int)((C.g.owned_nodes() + BLK - 1) / BLK);
         if (C.kind == LV_MACRO) {
             if (e->nflag_all) {
