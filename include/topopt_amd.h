@@ -68,6 +68,9 @@ typedef struct tp_comm {
     int (*exchange)(void *user, long n);
     /* in-place sum over ranks of red[0..n) */
     int (*allreduce_sum)(void *user, int n);
+    /* gather[r*n .. (r+1)*n) <- rank r's send_lo[0..n), for every rank (n <= cap) */
+    double *gather;                                /* [dev] nranks * cap doubles */
+    int (*allgather)(void *user, long n);
 } tp_comm;
 
 /* ---- grid / partition --------------------------------------------------- */

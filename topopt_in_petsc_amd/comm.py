@@ -26,20 +26,24 @@ class SlabComm:
         assert dist.is_initialized(), "torch.distributed must be initialised for nranks > 1"
         self.backend = dist.get_backend(group)
         # staging: large enough for one 3-dof node plane and a few filter layers
-        self.cap = int(cap or max(3 * part.plane, 4 * part.ex * part.ey))
+        self.cap = int(cap or max(3 * part.plane, 4 * part.ex * part.ey, 1 << 20))
         mk = lambda n: torch.zeros(n, dtype=torch.float64, device=self.device)
         self.send_lo, self.send_hi, self.recv_lo, self.recv_hi = mk(self.cap), mk(self.cap), mk(self.cap), mk(self.cap)
         self.red = mk(16)
+        self.gather = mk(self.cap * self.nranks)   # replicated coarsest level: all-gather target
+        self.n_allgathers = 0
         self.n_exchanges = 0
+        self._ops_cache = {}
         self.n_allreduces = 0
         self.bytes_sent = 0
         self._via_host = self.device.type == "cuda" and self.backend != "nccl"
         # keep the callbacks alive for the lifetime of the object
         self._ex_cb = _lib.EXCHANGE_FN(self._exchange_cb)
         self._ar_cb = _lib.ALLREDUCE_FN(self._allreduce_cb)
+        self._ag_cb = _lib.EXCHANGE_FN(self._allgather_cb)
         p = lambda t: t.data_ptr()
         self.c_struct = _lib.Comm(None, p(self.send_lo), p(self.send_hi), p(self.recv_lo), p(self.recv_hi),
-                                  p(self.red), self.cap, self._ex_cb, self._ar_cb)
+                                  p(self.red), self.cap, self._ex_cb, self._ar_cb, p(self.gather), self._ag_cb)
 
     # ---- python-level API (also used directly by the CPU tests) -----------
     def exchange(self, n):
@@ -51,11 +55,15 @@ class SlabComm:
             r_lo, r_hi = torch.empty(n, dtype=torch.float64), torch.empty(n, dtype=torch.float64)
         else:
             s_lo, s_hi, r_lo, r_hi = self.send_lo[:n], self.send_hi[:n], self.recv_lo[:n], self.recv_hi[:n]
-        ops = []
-        if has_lo:
-            ops += [dist.P2POp(dist.isend, s_lo, self._g(lo), self.group), dist.P2POp(dist.irecv, r_lo, self._g(lo), self.group)]
-        if has_hi:
-            ops += [dist.P2POp(dist.isend, s_hi, self._g(hi), self.group), dist.P2POp(dist.irecv, r_hi, self._g(hi), self.group)]
+        ops = None if self._via_host else self._ops_cache.get(n)
+        if ops is None:
+            ops = []
+            if has_lo:
+                ops += [dist.P2POp(dist.isend, s_lo, self._g(lo), self.group), dist.P2POp(dist.irecv, r_lo, self._g(lo), self.group)]
+            if has_hi:
+                ops += [dist.P2POp(dist.isend, s_hi, self._g(hi), self.group), dist.P2POp(dist.irecv, r_hi, self._g(hi), self.group)]
+            if not self._via_host:
+                self._ops_cache[n] = ops   # the staging tensors never move: the op list can be reused
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
@@ -76,6 +84,21 @@ class SlabComm:
             dist.all_reduce(self.red[:n], op=dist.ReduceOp.SUM, group=self.group)
         self.n_allreduces += 1
 
+    def allgather(self, n):
+        """gather[r*n:(r+1)*n] <- rank r's send_lo[:n]"""
+        out = self.gather[: n * self.nranks]
+        if self._via_host:
+            src = self.send_lo[:n].cpu()
+            parts = [torch.empty(n, dtype=torch.float64) for _ in range(self.nranks)]
+            dist.all_gather(parts, src, group=self.group)
+            out.copy_(torch.cat(parts))
+        elif self.backend == "nccl":
+            dist.all_gather_into_tensor(out, self.send_lo[:n], group=self.group)
+        else:
+            parts = list(out.view(self.nranks, n).unbind(0))
+            dist.all_gather(parts, self.send_lo[:n].contiguous(), group=self.group)
+        self.n_allgathers += 1
+
     def _g(self, r):
         """group rank -> global rank"""
         return r if self.group is None else dist.get_global_rank(self.group, r)
@@ -87,6 +110,14 @@ class SlabComm:
             return 0
         except Exception as e:  # never let an exception cross the C boundary
             print("SlabComm.exchange failed: %r" % (e,), flush=True)
+            return 1
+
+    def _allgather_cb(self, _user, n):
+        try:
+            self.allgather(int(n))
+            return 0
+        except Exception as e:
+            print("SlabComm.allgather failed: %r" % (e,), flush=True)
             return 1
 
     def _allreduce_cb(self, _user, n):

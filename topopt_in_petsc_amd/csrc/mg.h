@@ -26,6 +26,7 @@ struct Level {
     double lam;             // estimate / bound of lambda_max(D^-1 A)
     double lam_min = 0.0;   // coarsest level: smallest Ritz value (coarse-solve window)
     double *b, *x, *x2, *r, *d;
+    bool no_comm = false;   // replicated (global) copy of the coarsest level: no halo, no reductions over ranks
     bool use_tile = false;  // DOF == 3 matrix-free level with a box-symmetric KE: tuned kernel
     int sym_slot = -1;                // slot of the packed SymKE in constant memory
     // LV_MACRO (level 1 applied from the fine densities)
@@ -244,7 +245,9 @@ template <int DOF>
 struct MGSolver {
     tp_grid *grid = nullptr;
     int nlv = 0;
-    Level<DOF> lv[TP_MAX_LEVELS];
+    Level<DOF> lv[TP_MAX_LEVELS + 1];  // [nlv] = replicated global copy of the coarsest level (nranks > 1)
+    bool replicate = false;
+    bool allow_replicate = false;  // set by the owner when the coarsest level is a stored stencil (elasticity)
     tp_solver_opts opt;
     double *cg_r = nullptr, *cg_p = nullptr, *cg_w = nullptr;
     bool ready = false;
@@ -254,8 +257,17 @@ struct MGSolver {
     // Chebyshev windows of the stencil / coarse levels (and of the fine level if opt.fine_eig)
     int estimate_spectra(int first_level) {
         for (int l = first_level; l < nlv; l++) {
-            if (l == nlv - 1 && l > 0) TP_TRY(lanczos(l, NLANCZOS_COARSE, &lv[l].lam, &lv[l].lam_min));
-            else TP_TRY(lanczos(l, opt.nlanczos, &lv[l].lam));
+            if (l == nlv - 1 && l > 0) {
+                if (replicate) {  // same operator, same hashed start vector, no communication
+                    TP_TRY(lanczos(nlv, NLANCZOS_COARSE, &lv[nlv].lam, &lv[nlv].lam_min));
+                    lv[l].lam = lv[nlv].lam;
+                    lv[l].lam_min = lv[nlv].lam_min;
+                } else {
+                    TP_TRY(lanczos(l, NLANCZOS_COARSE, &lv[l].lam, &lv[l].lam_min));
+                }
+            } else {
+                TP_TRY(lanczos(l, opt.nlanczos, &lv[l].lam));
+            }
         }
         return TP_OK;
     }
@@ -270,6 +282,30 @@ struct MGSolver {
                 TP_HIP(hipMemsetAsync(*p, 0, nb, grid->stream));
             }
         }
+        lv[nlv] = Level<DOF>();
+        lv[nlv].b = lv[nlv].x = lv[nlv].x2 = lv[nlv].r = lv[nlv].d = lv[nlv].dinv = lv[nlv].S = lv[nlv].Kel = nullptr;
+        static const bool no_rep = getenv("TP_NO_REPLICATE") != nullptr;
+        replicate = allow_replicate && grid->has_comm && nlv > 1 && !no_rep;
+        if (replicate) {
+            Level<DOF> &R = lv[nlv];
+            const Geom &c = lv[nlv - 1].g;
+            R.g = c;
+            R.g.nzl = c.nz_glob;
+            R.g.ez_own = R.g.ezl = c.nz_glob - 1;
+            R.g.own_lo = 0;
+            R.g.own_hi = c.nz_glob - 1;
+            R.g.gz0 = 0;
+            R.g.has_lo = R.g.has_hi = 0;
+            R.kind = LV_DIA;
+            R.no_comm = true;
+            size_t rb = sizeof(double) * (size_t)R.ndof();
+            for (double **p : {&R.b, &R.x, &R.x2, &R.r, &R.d, &R.dinv}) {
+                TP_HIP(hipMalloc((void **)p, rb));
+                TP_HIP(hipMemsetAsync(*p, 0, rb, grid->stream));
+            }
+            TP_HIP(hipMalloc((void **)&R.S, rb * 27 * DOF));
+            TP_HIP(hipMemsetAsync(R.S, 0, rb * 27 * DOF, grid->stream));
+        }
         size_t nb = sizeof(double) * (size_t)lv[0].ndof();
         for (double **p : {&cg_r, &cg_p, &cg_w}) {
             TP_HIP(hipMalloc((void **)p, nb));
@@ -278,7 +314,7 @@ struct MGSolver {
         return TP_OK;
     }
     void free_levels() {
-        for (int l = 0; l < nlv; l++) {
+        for (int l = 0; l <= nlv; l++) {
             Level<DOF> &L = lv[l];
             for (double *p : {L.b, L.x, L.x2, L.r, L.d, L.dinv, L.S, L.Kel}) (void)hipFree(p);
         }
@@ -348,7 +384,7 @@ struct MGSolver {
         count_launch(grid, bytes, flops);
         return TP_OK;
     }
-    int halo(int l, double *v) { return halo_nodes(grid, lv[l].g, v, DOF); }
+    int halo(int l, double *v) { return lv[l].no_comm ? TP_OK : halo_nodes(grid, lv[l].g, v, DOF); }
 
     // y = A_l u (ghost planes of u refreshed first)
     int apply(int l, double *u, double *y) {
@@ -361,10 +397,22 @@ struct MGSolver {
 
     // Chebyshev(k)-Jacobi; the iterate ping-pongs between L.x and L.x2, on exit L.x holds it
     int smooth(int l, const double *b, int k, bool zero_guess) {
+        if (replicate && l == nlv - 1) {
+            // coarsest level replicated on every rank: one all-gather of the right-hand side instead of a
+            // halo exchange per Chebyshev step; the result comes back with its ghost planes filled
+            Level<DOF> &R = lv[nlv];
+            TP_TRY(gather_owned(lv[l], b, R, R.b, 1));
+            TP_TRY(smooth(nlv, R.b, k, zero_guess));
+            Level<DOF> &L = lv[l];
+            TP_HIP(hipMemcpyAsync(L.x, R.x + (long)DOF * L.g.plane() * L.g.gz0, sizeof(double) * (size_t)L.ndof(),
+                                  hipMemcpyDeviceToDevice, grid->stream));
+            return TP_OK;
+        }
         Level<DOF> &L = lv[l];
         // the coarsest level is a SOLVE (the reference runs a Krylov method there,
         // LinearElasticity.cc:720-731): its window spans the whole spectrum
-        const double lmin = (l == nlv - 1 && l > 0) ? L.lam_min : opt.cheb_lo * L.lam, lmax = opt.cheb_hi * L.lam;
+        const bool coarsest = (l == nlv - 1 && l > 0) || l == nlv;
+        const double lmin = coarsest ? L.lam_min : opt.cheb_lo * L.lam, lmax = opt.cheb_hi * L.lam;
         const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
         double rho = 1.0 / sigma;
         int it = 0;
@@ -397,6 +445,42 @@ struct MGSolver {
         return TP_OK;
     }
 
+    // every rank's owned rows of `nseg` consecutive level vectors (stride src_stride / dst_stride) -> the
+    // replicated global arrays.  Rank q owns global planes q*ez + (q>0) .. (q+1)*ez.
+    int gather_owned(Level<DOF> &L, const double *src, Level<DOF> &R, double *dst, int nseg, long src_stride = 0,
+                     long dst_stride = 0) {
+        const tp_comm &c = grid->comm;
+        const long pl = (long)DOF * L.g.plane();
+        const long pad = pl * (L.g.ez_own + 1);  // rank 0 owns one plane more than the others
+        const int per = (int)(c.cap / pad);
+        if (per < 1) return TP_ERR_ARG;
+        hipStream_t s = grid->stream;
+        for (int s0 = 0; s0 < nseg; s0 += per) {
+            const int ns = nseg - s0 < per ? nseg - s0 : per;
+            for (int q = 0; q < ns; q++)
+                TP_HIP(hipMemcpyAsync(c.send_lo + (long)q * pad, src + (long)(s0 + q) * src_stride + L.own_off(),
+                                      sizeof(double) * (size_t)L.own_n(), hipMemcpyDeviceToDevice, s));
+            if (c.allgather(c.user, (long)ns * pad)) return TP_ERR_COMM;
+            for (int rk = 0; rk < grid->nranks; rk++) {
+                const long p0 = (long)rk * L.g.ez_own + (rk > 0 ? 1 : 0), np = L.g.ez_own + (rk == 0 ? 1 : 0);
+                for (int q = 0; q < ns; q++)
+                    TP_HIP(hipMemcpyAsync(dst + (long)(s0 + q) * dst_stride + pl * p0,
+                                          c.gather + (long)rk * ns * pad + (long)q * pad, sizeof(double) * (size_t)(pl * np),
+                                          hipMemcpyDeviceToDevice, s));
+            }
+        }
+        return TP_OK;
+    }
+
+    // (re)build the replicated coarsest level from the ranks' owned stencil rows
+    int setup_replicated() {
+        if (!replicate) return TP_OK;
+        Level<DOF> &L = lv[nlv - 1], &R = lv[nlv];
+        TP_TRY(gather_owned(L, L.S, R, R.S, 27 * DOF, L.ndof(), R.ndof()));
+        TP_TRY(gather_owned(L, L.dinv, R, R.dinv, 1));
+        return TP_OK;
+    }
+
     // PCMG multiplicative V-cycle with zero initial guesses; result in lv[l].x
     int vcycle(int l, const double *b) {
         Level<DOF> &L = lv[l];
@@ -416,7 +500,7 @@ struct MGSolver {
                            grid->stream, C.g, L.g, L.r, C.b);
         count_launch(grid, 8.0 * DOF * (L.g.owned_nodes() + C.g.owned_nodes()), 2.0 * 27 * DOF * C.g.owned_nodes());
         TP_TRY(vcycle(l + 1, C.b));
-        TP_TRY(halo(l + 1, C.x));
+        if (!(replicate && l + 1 == nlv - 1)) TP_TRY(halo(l + 1, C.x));  // the replicated solve returns its ghosts
         hipLaunchKernelGGL((k_prolong_add<DOF>), dim3((int)((L.g.owned_nodes() + BLK - 1) / BLK)), dim3(BLK), 0,
                            grid->stream, C.g, L.g, C.x, L.x);
         count_launch(grid, 8.0 * DOF * (2 * L.g.owned_nodes() + C.g.owned_nodes()), 2.0 * 8 * DOF * L.g.owned_nodes());
@@ -438,8 +522,8 @@ struct MGSolver {
     }
 
     // sum over ranks of n device doubles (chunks of the 16-double framework buffer)
-    int allreduce_dev(double *p, int n) {
-        if (!grid->has_comm) return TP_OK;
+    int allreduce_dev(double *p, int n, bool local_only = false) {
+        if (!grid->has_comm || local_only) return TP_OK;
         for (int o = 0; o < n; o += 16) {
             const int c = n - o < 16 ? n - o : 16;
             TP_HIP(hipMemcpyAsync(grid->comm.red, p + o, sizeof(double) * c, hipMemcpyDeviceToDevice, grid->stream));
@@ -470,7 +554,7 @@ struct MGSolver {
         hipLaunchKernelGGL((k_lanczos_init<DOF>), dim3(gn), dim3(BLK), 0, s, L.g, V, dis, L.dinv);
         hipLaunchKernelGGL(k_multi_dot, dim3(nb, 1), dim3(BLK), 0, s, V, nd, 1, V, off, n, grid->partials);
         hipLaunchKernelGGL(k_reduce_multi, dim3(1), dim3(BLK), 0, s, grid->partials, nb, 1, bb);
-        TP_TRY(allreduce_dev(bb, 1));
+        TP_TRY(allreduce_dev(bb, 1, L.no_comm));
         hipLaunchKernelGGL(k_lanczos_next, dim3(grid_for(n)), dim3(BLK), 0, s, V, bb, 0, be, V, off, n);  // normalise v0
         int m = 0;
         for (int j = 0; j < steps; j++) {
@@ -482,13 +566,13 @@ struct MGSolver {
                 double *h = pass ? h2 : h1;
                 hipLaunchKernelGGL(k_multi_dot, dim3(nb, j + 1), dim3(BLK), 0, s, V, nd, j + 1, w, off, n, grid->partials);
                 hipLaunchKernelGGL(k_reduce_multi, dim3(j + 1), dim3(BLK), 0, s, grid->partials, nb, j + 1, h);
-                TP_TRY(allreduce_dev(h, j + 1));
+                TP_TRY(allreduce_dev(h, j + 1, L.no_comm));
                 hipLaunchKernelGGL(k_multi_axpy, dim3(grid_for(n)), dim3(BLK), 0, s, V, nd, j + 1, h, w, off, n);
             }
             hipLaunchKernelGGL(k_lanczos_alpha, dim3(1), dim3(64), 0, s, h1, h2, j, al);
             hipLaunchKernelGGL(k_multi_dot, dim3(nb, 1), dim3(BLK), 0, s, w, nd, 1, w, off, n, grid->partials);
             hipLaunchKernelGGL(k_reduce_multi, dim3(1), dim3(BLK), 0, s, grid->partials, nb, 1, bb);
-            TP_TRY(allreduce_dev(bb, 1));
+            TP_TRY(allreduce_dev(bb, 1, L.no_comm));
             hipLaunchKernelGGL(k_lanczos_next, dim3(grid_for(n)), dim3(BLK), 0, s, w, bb, j, be, V + (size_t)(j + 1) * nd,
                                off, n);
             grid->launches += 12;

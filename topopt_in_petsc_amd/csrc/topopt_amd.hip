@@ -190,6 +190,7 @@ extern "C" int tp_elasticity_create(tp_elasticity **out, tp_grid *g, const tp_so
     e->mg.grid = g;
     e->mg.nlv = o->nlvls;
     e->mg.opt = *o;
+    e->mg.allow_replicate = true;
     e->have_bc = e->assembled = false;
     e->d_flagged = nullptr;
     e->nflagged = 0;
@@ -430,6 +431,7 @@ extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, dou
         }
     }
     mg.ready = true;
+    TP_TRY(mg.setup_replicated());
     TP_TRY(mg.estimate_spectra(mg.opt.fine_eig ? 0 : 1));
     e->assembled = true;
     return TP_OK;
