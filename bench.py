@@ -143,37 +143,54 @@ def main():
         dt = float(tt[0])
     t_step = dt / max(a.steps, 1)
 
-    # ---- roofline of the dominant kernel: fine-level matrix-free hex8 SpMV ----
-    # algorithmic bytes: read u 24 B/node + E 8 B/element, write y 24 B/node
+    # ---- roofline ---------------------------------------------------------------------------------
+    # Dominant kernel of the step (rocprofv3: profiles/): k_matfree_tile<EPI_CHEB,0>, the fine-level matrix-free
+    # hex8 operator fused with the Chebyshev-Jacobi update.  Algorithmic bytes per launch:
+    # SpMV part 24 B/node read x + 8 B/element E, vector part b, d, dinv read + d, x written (24 B/node each).
     part = grid.part
     n_nd_own, n_el_own = part.n_owned_nodes, part.n_own_elems
     spmv_bytes = 48.0 * n_nd_own + 8.0 * n_el_own
+    cheb_bytes = 144.0 * n_nd_own + 8.0 * n_el_own
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def timed(fn, reps):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(reps):
+            fn()
+        ev1.record()
+        torch.cuda.synchronize()
+        return ev0.elapsed_time(ev1) / reps
+
     u = le.grid.node_vec(3).normal_()
     y = torch.zeros_like(u)
-    for _ in range(5):
-        le.MatMult(u, y)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    ev0.record()
-    for _ in range(a.spmv_reps):
-        le.MatMult(u, y)
-    ev1.record()
-    torch.cuda.synchronize()
-    spmv_ms = ev0.elapsed_time(ev1) / a.spmv_reps
-    achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9
-    # HBM traffic per launch from the rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, see
+    ksm = 8
+    # k fused steps per call (non-zero guess: every step is one launch of the fused kernel) + two device copies
+    t_smooth = timed(lambda: le.smooth(0, u, y, ksm, False), max(a.spmv_reps // 4, 2))
+    t_copy = timed(lambda: (le.smooth(0, u, y, 0, False)), max(a.spmv_reps // 4, 2))
+    cheb_ms = (t_smooth - t_copy) / ksm
+    spmv_ms = timed(lambda: le.MatMult(u, y), a.spmv_reps)
+    achieved = cheb_bytes / (cheb_ms * 1e-3) / 1e9
+    # HBM traffic per launch of the plain SpMV from the rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
     # profiles/README.md); only valid for the mesh it was measured on
     traffic = None
     tj = os.path.join(ROOT, "profiles", "spmv_traffic.json")
     if os.path.exists(tj):
         rec = json.load(open(tj)).get("%dx%dx%d" % (ex, ey, part.ez_own))
         if rec:
-            traffic = rec["hbm_bytes_per_launch"] / 1e9
-    roofline = {"bound": "hbm", "kernel": "k_matfree_tile<EPI_APPLY,0> (fine-level matrix-free hex8 SpMV)",
-                "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                "traffic_unit": "GB per launch (PMC)",
-                "alg_bytes_per_launch": spmv_bytes, "avg_launch_ms": spmv_ms,
-                "fp64_tflops": 1152.0 * n_el_own / (spmv_ms * 1e-3) / 1e12}
+            traffic = rec
+    roofline = {"bound": "hbm", "kernel": "k_matfree_tile<EPI_CHEB,0> (fine-level matrix-free hex8 operator fused with "
+                                          "the Chebyshev-Jacobi update)",
+                "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                "traffic": (traffic or {}).get("cheb_hbm_bytes_per_launch", None) and traffic["cheb_hbm_bytes_per_launch"] / 1e9,
+                "traffic_unit": "GB per launch (PMC)", "alg_bytes_per_launch": cheb_bytes, "avg_launch_ms": cheb_ms,
+                "spmv": {"kernel": "k_matfree_tile<EPI_APPLY,0> (plain y = K u)", "alg_bytes_per_launch": spmv_bytes,
+                         "avg_launch_ms": spmv_ms, "achieved": spmv_bytes / (spmv_ms * 1e-3) / 1e9,
+                         "frac": spmv_bytes / (spmv_ms * 1e-3) / 1e9 / 8000.0,
+                         "traffic": (traffic or {}).get("hbm_bytes_per_launch", None) and traffic["hbm_bytes_per_launch"] / 1e9,
+                         "fp64_tflops_dense_equiv": 1152.0 * n_el_own / (spmv_ms * 1e-3) / 1e12}}
 
     out = {
         "metric": "DOF-updates/s per design iter (assembly+PCG+filter)",

@@ -150,6 +150,8 @@ double tp_elasticity_level_lambda(const tp_elasticity *e, int level);
 int tp_elasticity_level_apply(tp_elasticity *e, int level, const double *u, double *y); /* [dev, level local dofs] */
 int tp_elasticity_level_diag(tp_elasticity *e, int level, double *d);
 int tp_elasticity_precond(tp_elasticity *e, const double *r, double *z); /* one V-cycle */
+/* k Chebyshev-Jacobi steps on a level (the fused operator+update kernel): x <- smooth(b, x) */
+int tp_elasticity_smooth(tp_elasticity *e, int level, const double *b, double *x, int k, int zero_guess);
 int tp_elasticity_restrict(tp_elasticity *e, int level, const double *rf, double *rc);
 int tp_elasticity_prolong_add(tp_elasticity *e, int level, const double *xc, double *xf);
 /* bytes moved / flops of the last call, by the algorithmic model of DESIGN.md */

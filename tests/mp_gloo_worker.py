@@ -93,6 +93,11 @@ def cpu_mode(rank, world):
     Uref = spla.spsolve(mg.csr(0).tocsc(), b)
     assert np.abs(xk[own] - Uref[gs][own]).max() <= 1e-7 * np.abs(Uref).max(), np.abs(xk[own] - Uref[gs][own]).max()
     assert comm.n_exchanges > 0 and comm.n_allreduces > 0
+    # all-gather hook (replicated coarsest level): every rank sees every rank's block, in rank order
+    comm.send_lo[:5] = torch.arange(5, dtype=torch.float64) + 10 * rank
+    comm.allgather(5)
+    want = torch.cat([torch.arange(5, dtype=torch.float64) + 10 * r for r in range(world)])
+    assert torch.equal(comm.gather[: 5 * world], want)
     # multigrid level partitions are consistent
     for l in range(2):
         pl = part.level(l)

@@ -272,3 +272,62 @@ def test_full_size_properties(tp):
     fx, gx = le.Objective(xp, 1e-9, 1.0, 3.0, 0.12)
     assert fx == pytest.approx(float(torch.dot(b, le.U)), rel=1e-7)
     assert gx == pytest.approx(float(xp.mean()) - 0.12, abs=1e-12)
+
+
+def test_chebyshev_smoother(tp, orc):
+    """the fused operator + Chebyshev-Jacobi update kernels on every level vs the oracle's smoother"""
+    grid, le, mg, x, KE, N, R = make(tp, orc, 16, 8, 8, 3)
+    rng = np.random.default_rng(11)
+    for l in range(3):
+        b, x0 = rng.standard_normal(mg.size(l)), rng.standard_normal(mg.size(l))
+        for k, zero in [(4, True), (4, False), (1, False), (7, True)]:
+            xs = host(le.smooth(l, dev(b), dev(x0), k, zero))
+            xo = mg.smooth(l, b, x0, k, zero)
+            assert rel(xs, xo) <= 1e-12, (l, k, zero)
+
+
+def test_anisotropic_box_elements(tp, orc):
+    """dx != dy != dz: the block-diagonal form of KE, the Galerkin levels and the filter radius logic"""
+    ex, ey, ez, nlv = 16, 8, 8, 2
+    nx, ny, nz = ex + 1, ey + 1, ez + 1
+    h = (1.0 / 16, 1.0 / 12, 1.0 / 20)
+    grid = tp.Grid(nx, ny, nz, h)
+    le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=nlv, rtol=1e-9))
+    assert np.array_equal(le.KE, orc.hex8_ke_box(*h, 0.3))
+    le.SetUpLoadAndBC()
+    x = orc.synth_density(ex, ey, ez, h[1])
+    N, R = orc.cantilever_bc(nx, ny, nz, h)
+    assert np.array_equal(host(le.N), N) and np.array_equal(host(le.RHS), R)
+    mg = orc.MG(nx, ny, nz, 3, nlv)
+    mg.assemble(orc.hex8_ke_box(*h, 0.3), orc.simp(x), N)
+    le.AssembleStiffnessMatrix(dev(x), 1e-9, 1.0, 3.0)
+    u = np.random.default_rng(2).standard_normal(mg.n)
+    for l in range(nlv):
+        ul = u[: mg.size(l)]
+        assert rel(host(le.level_apply(l, dev(ul))), mg.apply(l, ul)) <= 1e-13
+    its = le.KSPSolve(hist_cap=300)
+    Uo, its_o, hist_o = mg.solve(R * N, rtol=1e-9, maxit=200)
+    assert its == its_o and rel(host(le.U), Uo) <= 1e-8
+    of = orc.Filter(nx, ny, nz, h, 0.15)
+    f = tp.Filter(grid, 1, 0.15)
+    assert f.ElemConn == of.conn == 2
+    assert rel(host(f.Hs()), of.hs()) <= 1e-14
+
+
+def test_error_codes(tp):
+    """PetscErrorCode-style behaviour of the boundary"""
+    grid = tp.Grid(17, 9, 9, 0.125)
+    with pytest.raises(tp.TopOptError, match="TP_ERR_ARG"):      # TopOpt.cc:183-201: not coarsenable
+        tp.LinearElasticity(grid, tp.SolverOptions(nlvls=5))
+    le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=2))
+    with pytest.raises(tp.TopOptError, match="TP_ERR_STATE"):    # assemble before the boundary conditions
+        le.AssembleStiffnessMatrix(grid.elem_vec(0.5), 1e-9, 1.0, 3.0)
+    le.SetUpLoadAndBC()
+    with pytest.raises(tp.TopOptError, match="TP_ERR_STATE"):    # solve before assemble
+        le.KSPSolve()
+    le.AssembleStiffnessMatrix(grid.elem_vec(0.5), 1e-9, 1.0, 3.0)
+    le.opts.max_it = 1
+    le2 = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=2, max_it=2, rtol=1e-14))
+    le2.SetUpLoadAndBC()
+    le2.AssembleStiffnessMatrix(grid.elem_vec(0.5), 1e-9, 1.0, 3.0)
+    assert le2.KSPSolve() == 2 and le2.last_rnorm > 1e-14 * le2.last_bnorm   # max_it reached: returns like KSP does

@@ -26,6 +26,8 @@ u = grid.node_vec(3).normal_()
 y = torch.zeros_like(u)
 for _ in range(5):
     le.MatMult(u, y)
+b = grid.node_vec(3).normal_()
+le.smooth(0, b, y, 5, False)   # 5 launches of the fused Chebyshev kernel k_matfree_tile<2,0>
 torch.cuda.synchronize()
 print("calibration bytes read=%d written=%d ; spmv algorithmic bytes=%d" %
       (8 * n, 8 * n, 48 * (ex + 1) * (ey + 1) * (ez + 1) + 8 * ex * ey * ez))

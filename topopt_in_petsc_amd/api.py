@@ -206,6 +206,10 @@ class LinearElasticity:
         _chk(self.L.tp_elasticity_precond(self.handle, _ptr(r), _ptr(z)), "tp_elasticity_precond")
         return z
 
+    def smooth(self, l, b, x, k, zero_guess=False):
+        _chk(self.L.tp_elasticity_smooth(self.handle, l, _ptr(b), _ptr(x), k, int(zero_guess)), "tp_elasticity_smooth")
+        return x
+
     def restrict(self, l, rf):
         rc = self.level_vec(l + 1)
         _chk(self.L.tp_elasticity_restrict(self.handle, l, _ptr(rf), _ptr(rc)), "tp_elasticity_restrict")

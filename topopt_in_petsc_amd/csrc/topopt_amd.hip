@@ -538,6 +538,15 @@ extern "C" int tp_elasticity_precond(tp_elasticity *e, const double *r, double *
                           e->grid->stream));
     return TP_OK;
 }
+extern "C" int tp_elasticity_smooth(tp_elasticity *e, int l, const double *b, double *x, int k, int zero_guess) {
+    if (!e->assembled || l < 0 || l >= e->mg.nlv) return TP_ERR_STATE;
+    Level<3> &L = e->mg.lv[l];
+    const size_t nb = sizeof(double) * (size_t)L.ndof();
+    if (!zero_guess) TP_HIP(hipMemcpyAsync(L.x, x, nb, hipMemcpyDeviceToDevice, e->grid->stream));
+    TP_TRY(e->mg.smooth(l, b, k, zero_guess != 0));
+    TP_HIP(hipMemcpyAsync(x, L.x, nb, hipMemcpyDeviceToDevice, e->grid->stream));
+    return TP_OK;
+}
 extern "C" int tp_elasticity_restrict(tp_elasticity *e, int l, const double *rf, double *rc) {
     MGSolver<3> &mg = e->mg;
     if (l < 0 || l + 1 >= mg.nlv) return TP_ERR_ARG;

@@ -77,6 +77,7 @@ SYMBOLS = {
     "tp_elasticity_level_apply": (_i, [_vp, _i, _vp, _vp]),
     "tp_elasticity_level_diag": (_i, [_vp, _i, _vp]),
     "tp_elasticity_precond": (_i, [_vp, _vp, _vp]),
+    "tp_elasticity_smooth": (_i, [_vp, _i, _vp, _vp, _i, _i]),
     "tp_elasticity_restrict": (_i, [_vp, _i, _vp, _vp]),
     "tp_elasticity_prolong_add": (_i, [_vp, _i, _vp, _vp]),
     "tp_elasticity_last_stats": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_l)]),
