@@ -956,8 +956,9 @@ ORC_API void orc_mg_level_csr(orc_mg_t *s, int l, long *rp, int *ci, double *v) 
 ORC_API void orc_mg_prolong(orc_mg_t *s, int l, const double *xc, double *xf) { csr_spmv(s->P[l], xc, xf); }
 ORC_API void orc_mg_restrict(orc_mg_t *s, int l, const double *rf, double *rc) { csr_spmv_t(s->P[l], rf, rc); }
 ORC_API void orc_mg_smooth(orc_mg_t *s, int l, const double *b, double *x, int k, int zero_guess) {
-    cheb_smooth(s->A[l], s->dinv[l], b, x, s->r[l], s->d[l], k, s->cheb_lo * s->lam[l], s->cheb_hi * s->lam[l],
-                zero_guess);
+    /* same windows as the V-cycle: the coarsest level spans the whole spectrum */
+    double lmin = (l == s->nlv - 1 && l > 0) ? s->lam_min[l] : s->cheb_lo * s->lam[l];
+    cheb_smooth(s->A[l], s->dinv[l], b, x, s->r[l], s->d[l], k, lmin, s->cheb_hi * s->lam[l], zero_guess);
 }
 
 /* ------------------------------------------------------------------------- */

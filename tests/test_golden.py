@@ -63,7 +63,7 @@ def test_gpu_matches_golden_files():
         assert fx == pytest.approx(float(g["fx"]), rel=1e-8) and gx == pytest.approx(float(g["gx"]), abs=1e-13)
         assert np.allclose([le.level_lambda(l) for l in range(nlv)], g["lam"], rtol=1e-9)
         if "dfdx" in g:
-            assert np.array_equal(x.cpu().numpy(), g["x"])
+            assert np.abs(x.cpu().numpy() - g["x"]).max() < 1e-15   # device sin() vs libm: last bits
             assert np.allclose(xt.cpu().numpy(), g["xTilde"], rtol=1e-13)
             assert np.allclose(df.cpu().numpy(), g["dfdx"], rtol=1e-6, atol=1e-11)
             v = torch.from_numpy(g["v"]).cuda()
