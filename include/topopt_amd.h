@@ -71,6 +71,10 @@ typedef struct tp_comm {
     /* gather[r*n .. (r+1)*n) <- rank r's send_lo[0..n), for every rank (n <= cap) */
     double *gather;                                /* [dev] nranks * cap doubles */
     int (*allgather)(void *user, long n);
+    /* optional zero-copy halo of contiguous planes (may be NULL -> staged `exchange` is used):
+     * to_lo[0..n) -> rank-1, to_hi[0..n) -> rank+1, from_lo <- rank-1, from_hi <- rank+1, all [dev] */
+    int (*exchange_direct)(void *user, const double *to_lo, double *from_lo, const double *to_hi, double *from_hi,
+                           long n);
 } tp_comm;
 
 /* ---- grid / partition --------------------------------------------------- */

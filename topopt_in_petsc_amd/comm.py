@@ -41,9 +41,14 @@ class SlabComm:
         self._ex_cb = _lib.EXCHANGE_FN(self._exchange_cb)
         self._ar_cb = _lib.ALLREDUCE_FN(self._allreduce_cb)
         self._ag_cb = _lib.EXCHANGE_FN(self._allgather_cb)
+        self._dx_cb = _lib.DIRECT_FN(self._direct_cb)
+        self._raw_cache = {}
+        self._direct_cache = {}
+        self.n_direct = 0
         p = lambda t: t.data_ptr()
         self.c_struct = _lib.Comm(None, p(self.send_lo), p(self.send_hi), p(self.recv_lo), p(self.recv_hi),
-                                  p(self.red), self.cap, self._ex_cb, self._ar_cb, p(self.gather), self._ag_cb)
+                                  p(self.red), self.cap, self._ex_cb, self._ar_cb, p(self.gather), self._ag_cb,
+                                  self._dx_cb if self.device.type == "cuda" else _lib.DIRECT_FN(0))
 
     # ---- python-level API (also used directly by the CPU tests) -----------
     def exchange(self, n):
@@ -74,6 +79,71 @@ class SlabComm:
                 self.recv_hi[:n].copy_(r_hi)
         self.n_exchanges += 1
         self.bytes_sent += 8 * n * (int(has_lo) + int(has_hi))
+
+    # ---- zero-copy halo: the library's own vectors wrapped as tensors (no staging copies) ----
+    def _raw(self, ptr, n):
+        """a float64 tensor view of n doubles of device memory owned by the HIP library"""
+        key = (ptr, n)
+        t = self._raw_cache.get(key)
+        if t is None:
+            class _Arr:
+                pass
+            a = _Arr()
+            a.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2,
+                                          "strides": None}
+            t = torch.as_tensor(a, device=self.device)
+            assert t.data_ptr() == ptr and t.numel() == n and t.dtype == torch.float64
+            self._raw_cache[key] = t
+        return t
+
+    def exchange_direct(self, to_lo, from_lo, to_hi, from_hi, n):
+        lo, hi = self.rank - 1, self.rank + 1
+        has_lo, has_hi = lo >= 0, hi < self.nranks
+        key = (to_lo, from_lo, to_hi, from_hi, n)
+        ent = self._direct_cache.get(key)
+        if ent is None:
+            ts = [self._raw(p, n) if (p and ok) else None
+                  for p, ok in ((to_lo, has_lo), (from_lo, has_lo), (to_hi, has_hi), (from_hi, has_hi))]
+            ops = []
+            if not self._via_host:
+                if has_lo:
+                    ops += [dist.P2POp(dist.isend, ts[0], self._g(lo), self.group),
+                            dist.P2POp(dist.irecv, ts[1], self._g(lo), self.group)]
+                if has_hi:
+                    ops += [dist.P2POp(dist.isend, ts[2], self._g(hi), self.group),
+                            dist.P2POp(dist.irecv, ts[3], self._g(hi), self.group)]
+            ent = (ts, ops)
+            self._direct_cache[key] = ent
+        ts, ops = ent
+        if self._via_host:  # gloo with GPU memory: same tensors, staged through the host
+            hops, r_lo, r_hi = [], None, None
+            if has_lo:
+                r_lo = torch.empty(n, dtype=torch.float64)
+                hops += [dist.P2POp(dist.isend, ts[0].cpu(), self._g(lo), self.group),
+                         dist.P2POp(dist.irecv, r_lo, self._g(lo), self.group)]
+            if has_hi:
+                r_hi = torch.empty(n, dtype=torch.float64)
+                hops += [dist.P2POp(dist.isend, ts[2].cpu(), self._g(hi), self.group),
+                         dist.P2POp(dist.irecv, r_hi, self._g(hi), self.group)]
+            for w in dist.batch_isend_irecv(hops):
+                w.wait()
+            if has_lo:
+                ts[1].copy_(r_lo)
+            if has_hi:
+                ts[3].copy_(r_hi)
+        elif ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        self.n_direct += 1
+        self.bytes_sent += 8 * n * (int(has_lo) + int(has_hi))
+
+    def _direct_cb(self, _user, to_lo, from_lo, to_hi, from_hi, n):
+        try:
+            self.exchange_direct(to_lo or 0, from_lo or 0, to_hi or 0, from_hi or 0, int(n))
+            return 0
+        except Exception as e:
+            print("SlabComm.exchange_direct failed: %r" % (e,), flush=True)
+            return 1
 
     def allreduce_sum(self, n):
         if self._via_host:
