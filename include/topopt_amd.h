@@ -194,6 +194,10 @@ int tp_mma_update(tp_mma *mma, double *x, const double *dfdx, const double *gx, 
 /* DesignChange (MMA.cc:407-426): ch = max |x - xold| over all ranks, then xold <- x */
 int tp_mma_design_change(tp_mma *mma, const double *x, double *xold, double *ch);
 int tp_mma_get_state(const tp_mma *mma, double *lam, double *z, int *k);
+/* MMA::Restart (MMA.cc:319-360): copy out the iterates/asymptotes a restart needs (device arrays, n_local each);
+ * restart_set = the restart constructor (MMA.cc:22-106): continue at outer iteration k with these. */
+int tp_mma_restart_get(const tp_mma *mma, double *xo1, double *xo2, double *U, double *L);
+int tp_mma_restart_set(tp_mma *mma, int k, const double *xo1, const double *xo2, const double *U, const double *L);
 
 /* ---- streaming helpers used by the driver (main.cc:68-73, TopOpt.cc) ----- */
 int tp_vec_scale(tp_grid *g, double *x, double a, long n);

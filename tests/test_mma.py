@@ -1,5 +1,6 @@
 """MMA: the oracle restatement on CPU (properties), and the device implementation
 against it (GPU)."""
+import os
 import numpy as np
 import pytest
 
@@ -114,3 +115,32 @@ def test_optimisation_loop_matches_oracle_loop(orc):
         assert rec["mnd"] == pytest.approx(orc.mnd(xp), rel=1e-7)
         assert np.abs(opt.x.cpu().numpy() - x).max() <= 1e-6
     assert opt.history[-1]["fx"] < opt.history[0]["fx"]
+
+
+@pytest.mark.gpu
+def test_restart_files_continue_the_run(tmp_path):
+    """TopOpt.cc:474-570 / LinearElasticity.cc:447-478: stop after 6 iterations, restart from the files, and the next
+    iterations are those of the uninterrupted run; the result container holds every dump of main.cc:114-129"""
+    from topopt_in_petsc_amd.driver import TopOpt
+    from topopt_in_petsc_amd.mpiio import read_output
+    kw = dict(nxyz=(33, 17, 17), nlvls=3, rmin=0.1, volfrac=0.3)
+    ref = TopOpt(**kw)
+    ref.run(max_itr=8)
+    wd = str(tmp_path)
+    a = TopOpt(workdir=wd, **kw)
+    a.run(max_itr=6)
+    out = read_output(os.path.join(wd, "output_00000.dat"))
+    assert [d[0] for d in out["dumps"]] == [1, 2, 3, 4, 5, 6, 7]
+    assert np.allclose(out["dumps"][-1][2][2], a.xPhys.cpu().numpy(), atol=1e-7)
+    assert np.allclose(out["dumps"][-1][1].T.ravel(), a.physics.U.cpu().numpy(), atol=1e-5 * float(a.physics.U.abs().max()))
+    b = TopOpt(restartFileVec=os.path.join(wd, "Restart00.dat"), restartFileItr=os.path.join(wd, "Restart00_itr_f0.dat"),
+               restartFileVecSol=os.path.join(wd, "RestartSol00.dat"), **kw)
+    assert b.itr == 6 and b.fscale == pytest.approx(a.fscale, rel=1e-6)
+    b.fscale = a.fscale        # the "%e" companion keeps 7 digits (TopOpt.cc:548); compare the loop itself
+    b.run(max_itr=8)
+    for r0, r1 in zip(ref.history[6:], b.history):
+        assert r0["itr"] == r1["itr"]
+        assert r1["fx"] == pytest.approx(r0["fx"], rel=1e-9)
+    # like the reference, xold is not part of the restart set (TopOpt.cc:380-381): the first ch is against volfrac
+    assert b.history[1]["ch"] == pytest.approx(ref.history[7]["ch"], rel=1e-7, abs=1e-12)
+    assert float((b.x - ref.x).abs().max()) < 1e-9

@@ -305,6 +305,14 @@ class MMA:
         _chk(self.L.tp_mma_design_change(self.handle, _ptr(x), _ptr(xold), C.byref(ch)), "tp_mma_design_change")
         return ch.value
 
+    def Restart(self, xo1, xo2, U, L):
+        """MMA::Restart (MMA.cc:319-360): copy the two previous iterates and the asymptotes out"""
+        _chk(self.L.tp_mma_restart_get(self.handle, _ptr(xo1), _ptr(xo2), _ptr(U), _ptr(L)), "tp_mma_restart_get")
+
+    def SetRestart(self, k, xo1, xo2, U, L):
+        """the restart constructor MMA::MMA(n, m, k, xo1, xo2, U, L, ...) (MMA.cc:22-106)"""
+        _chk(self.L.tp_mma_restart_set(self.handle, int(k), _ptr(xo1), _ptr(xo2), _ptr(U), _ptr(L)), "tp_mma_restart_set")
+
     def state(self):
         lam = (C.c_double * self.m)()
         z, k = C.c_double(), C.c_int()

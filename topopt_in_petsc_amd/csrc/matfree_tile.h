@@ -22,6 +22,7 @@
 // layer per z-chunk.  Results are bitwise reproducible run to run.
 #pragma once
 #include "operators.h"
+#include "macro_pattern.h"
 
 // Non-zero pattern of the blocks (structural for any box element: q = 0 and 7 are
 // full; a single-bit class only couples the two components other than that bit
@@ -120,6 +121,51 @@ __device__ inline void wht4(double v[4]) {
 constexpr int SYMKE_SLOTS = 16, SYMKE_STRIDE = 40;
 __constant__ double c_symB[SYMKE_SLOTS * SYMKE_STRIDE];
 
+// level-1 operator constants (MACG_N packed values of G_sigma, macro_pattern.h), same slot numbering
+constexpr int MACG_STRIDE = 280;
+static_assert(MACG_N <= MACG_STRIDE, "stride");
+__constant__ double c_macG[SYMKE_SLOTS * MACG_STRIDE];
+
+// G_sigma = H (1/8 sum_c chi_sigma(c) M_c) H^T / 64 at the pattern positions; M = the 8 child matrices W_c^T KE W_c
+// (galerkin.h: host_child_matrices, reference corner numbering).  Returns the largest dropped entry (relative).
+inline double make_macro_tensor(const double *M, double *out) {
+    static double G[8][24][24];
+    double maxabs = 0.0;
+    for (int sg = 0; sg < 8; sg++)
+        for (int p = 0; p < 8; p++)
+            for (int r = 0; r < 3; r++)
+                for (int p2 = 0; p2 < 8; p2++)
+                    for (int s = 0; s < 3; s++) {
+                        double acc = 0.0;
+                        for (int c = 0; c < 8; c++) {
+                            double a2 = 0.0;
+                            for (int m = 0; m < 8; m++)
+                                for (int m2 = 0; m2 < 8; m2++) {
+                                    const int sgn = (__builtin_popcount(p & m) + __builtin_popcount(p2 & m2)) & 1;
+                                    const double v = M[c * 576 + (3 * h_M2A[m] + r) * 24 + 3 * h_M2A[m2] + s];
+                                    a2 += sgn ? -v : v;
+                                }
+                            acc += (__builtin_popcount(sg & c) & 1) ? -a2 : a2;
+                        }
+                        G[sg][3 * p + r][3 * p2 + s] = acc / 512.0;
+                        maxabs = fmax(maxabs, fabs(acc / 512.0));
+                    }
+    for (int k = 0; k < MACG_N; k++) {
+        double &g = G[MACG_SIG[k]][MACG_ROW[k]][MACG_COL[k]];
+        out[k] = g;
+        g = 0.0;
+    }
+    double dropped = 0.0;
+    for (int sg = 0; sg < 8; sg++)
+        for (int i = 0; i < 24; i++)
+            for (int j = 0; j < 24; j++) dropped = fmax(dropped, fabs(G[sg][i][j]));
+    return maxabs > 0 ? dropped / maxabs : 0.0;
+}
+inline int macro_slot_upload(int slot, const double *vals) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_macG), vals, sizeof(double) * MACG_N, sizeof(double) * slot * MACG_STRIDE) ==
+                   hipSuccess ? 0 : -1;
+}
+
 struct SymSlots {
     double key[SYMKE_SLOTS][SYMKE_N];
     int refs[SYMKE_SLOTS];
@@ -188,15 +234,16 @@ struct TileArgs {
     int fex, fey;              // FINE element counts per row / column (children indexing)
     const double *corr;        // [level-1 dofs] Dirichlet correction added to y (k_macro_corr), or null
     int xcd_remap;             // 1: contiguous tile ranges per XCD
+    int macg_off;              // offset of the level-1 constants inside c_macG
 };
 
 // MACRO = 0: fine level, one element per thread and step.
-// MACRO = 1: level 1.  The Galerkin operator P^T A_0 P is never stored: inside a
-//   coarse element the interpolated field is trilinear, so in the Walsh-Hadamard
-//   basis the 8 children see  uhat_child = R_c D uhat  with D = diag(2^-|p|) and R_c a
-//   product of per-axis maps (a0, a1) -> (a0 - s a1, a1), s = +-1 the child's side:
-//       y = T^T D [ sum_c R_c^T E_c B R_c ] D T u
-//   (12 adds per component in, 45 block ops, 12 adds out per child).  Bytes per
+// MACRO = 1: level 1.  The Galerkin operator P^T A_0 P is never stored: a coarse element's matrix is linear in its 8
+//   child moduli, K_E = sum_c E_c W_c^T KE W_c, and the child matrices are reflections of each other.  In the
+//   Walsh-Hadamard basis of the 8 corners AND of the 8 children
+//       y = T^T [ sum_sigma ehat_sigma G_sigma ] T u,      ehat = H8 E_children,
+//   with constant G_sigma that couple mode class q only to q ^ sigma: 279 structurally non-zero values in total
+//   (macro_pattern.h, generated) instead of 8 dense child products -> ~430 fma per coarse element.  Bytes per
 //   apply drop from 1944 B per coarse node (stored stencil) to the 8 child densities.
 //   This kernel applies the operator WITHOUT Dirichlet conditions; the (few) coarse
 //   elements that contain a clamped fine node differ from it by a stored 24x24
@@ -345,55 +392,24 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
         } else {
             const bool eok = elem_ok && el >= 0 && el < t.ezl;
             Ee = eok ? 1.0 : 0.0;  // children moduli are applied inside
-            {
-                // D: scale mode p by 2^-|p|
+            double eh[8];
 #pragma unroll
-                for (int c = 0; c < 3; c++)
+            for (int ch = 0; ch < 8; ch++)
+                eh[ch] = eok ? t.E[(long)(2 * ei + (ch & 1)) + (long)t.fex * ((2 * ej + ((ch >> 1) & 1)) + (long)t.fey * (2 * el + (ch >> 2)))]
+                             : 0.0;
+            {   // Walsh-Hadamard transform of the 8 child moduli
+                double lo[4] = {eh[0], eh[1], eh[2], eh[3]}, hi[4] = {eh[4], eh[5], eh[6], eh[7]};
+                wht4(lo);
+                wht4(hi);
 #pragma unroll
-                    for (int p = 1; p < 8; p++) u[c][p] *= (p == 7 ? 0.125 : ((p == 3 || p == 5 || p == 6) ? 0.25 : 0.5));
-#pragma unroll
-                for (int c = 0; c < 3; c++)
-#pragma unroll
-                    for (int p = 0; p < 8; p++) f[c][p] = 0.0;
-#pragma unroll 1
-                for (int ch = 0; ch < 8; ch++) {
-                    const double sx = (ch & 1) ? 1.0 : -1.0, sy = (ch & 2) ? 1.0 : -1.0, sz = (ch & 4) ? 1.0 : -1.0;
-                    double Ec = 0.0;
-                    if (eok)
-                        Ec = t.E[(long)(2 * ei + (ch & 1)) + (long)t.fex * ((2 * ej + ((ch >> 1) & 1)) + (long)t.fey * (2 * el + (ch >> 2)))];
-                    double w[3][8], g[3][8];
-#pragma unroll
-                    for (int c = 0; c < 3; c++) {
-#pragma unroll
-                        for (int p = 0; p < 8; p++) w[c][p] = u[c][p];
-#pragma unroll
-                        for (int p = 0; p < 8; p += 2) w[c][p] -= sx * w[c][p + 1];
-#pragma unroll
-                        for (int p = 0; p < 8; p++)
-                            if (!(p & 2)) w[c][p] -= sy * w[c][p + 2];
-#pragma unroll
-                        for (int p = 0; p < 4; p++) w[c][p] -= sz * w[c][p + 4];
-                    }
-                    sym_ke_blocks(c_symB + boff, w, g);
-#pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        // R_c^T: (f0, f1) -> (f0, f1 - s f0) per axis, then accumulate with the child's modulus
-#pragma unroll
-                        for (int p = 0; p < 4; p++) g[c][p + 4] -= sz * g[c][p];
-#pragma unroll
-                        for (int p = 0; p < 8; p++)
-                            if (!(p & 2)) g[c][p + 2] -= sy * g[c][p];
-#pragma unroll
-                        for (int p = 0; p < 8; p += 2) g[c][p + 1] -= sx * g[c][p];
-#pragma unroll
-                        for (int p = 0; p < 8; p++) f[c][p] = fma(Ec, g[c][p], f[c][p]);
-                    }
+                for (int m = 0; m < 4; m++) {
+                    eh[m] = lo[m] + hi[m];
+                    eh[m + 4] = lo[m] - hi[m];
                 }
-#pragma unroll
-                for (int c = 0; c < 3; c++)
-#pragma unroll
-                    for (int p = 1; p < 8; p++) f[c][p] *= (p == 7 ? 0.125 : ((p == 3 || p == 5 || p == 6) ? 0.25 : 0.5));
             }
+            int goff;
+            asm volatile("s_mov_b32 %0, %1" : "=s"(goff) : "s"(t.macg_off));
+            macg_apply(c_macG + goff, u, eh, f);
         }
         // ---- back to the two planes; the upper plane's part is carried (still transformed)
         double P[3][4];

@@ -339,7 +339,7 @@ struct MGSolver {
             const int tz = (planes + kz - 1) / kz;
             last_nblocks = tx * ty * tz;
             TileArgs ta{L.g.nx, L.g.ny, L.g.nzl, L.g.ex, L.g.ey, L.g.ezl, L.g.own_lo, L.g.own_hi, kz,
-                        L.E, L.mask, L.colmask, L.sym_slot * SYMKE_STRIDE, 0, 0, nullptr, xcd_remap()};
+                        L.E, L.mask, L.colmask, L.sym_slot * SYMKE_STRIDE, 0, 0, nullptr, xcd_remap(), 0};
             hipLaunchKernelGGL((k_matfree_tile<EPI, 0>), dim3(tx, ty, tz), dim3(TILE * TILE), 0, grid->stream, ta, a);
             bytes = 16.0 * DOF * nown + 8.0 * L.g.own_elems();
             flops = 2.0 * 576 * (double)L.g.own_elems();
@@ -362,7 +362,7 @@ struct MGSolver {
             }
             TileArgs ta{L.g.nx, L.g.ny, L.g.nzl, L.g.ex, L.g.ey, L.g.ezl, L.g.own_lo, L.g.own_hi, kz,
                         L.E, nullptr, nullptr, L.sym_slot * SYMKE_STRIDE, L.fex, L.fey,
-                        L.ncorr_nodes ? L.corr : nullptr, xcd_remap()};
+                        L.ncorr_nodes ? L.corr : nullptr, xcd_remap(), L.sym_slot * MACG_STRIDE};
             hipLaunchKernelGGL((k_matfree_tile<EPI, 1>), dim3(tx, ty, tz), dim3(TILE * TILE), 0, grid->stream, ta, a);
             bytes = 16.0 * DOF * nown + 8.0 * 8.0 * L.g.own_elems();
             flops = 2.0 * 576 * 8.0 * (double)L.g.own_elems();

@@ -392,3 +392,26 @@ extern "C" int tp_mma_get_state(const tp_mma *M, double *lam, double *z, int *k)
     if (k) *k = M->k;
     return TP_OK;
 }
+
+extern "C" int tp_mma_restart_get(const tp_mma *M, double *xo1, double *xo2, double *U, double *L) {
+    if (!M || !xo1 || !xo2 || !U || !L) return TP_ERR_ARG;
+    hipStream_t st = M->grid->stream;
+    const size_t nb = sizeof(double) * M->n;
+    TP_HIP(hipMemcpyAsync(xo1, M->xo1, nb, hipMemcpyDeviceToDevice, st));
+    TP_HIP(hipMemcpyAsync(xo2, M->xo2, nb, hipMemcpyDeviceToDevice, st));
+    TP_HIP(hipMemcpyAsync(U, M->U, nb, hipMemcpyDeviceToDevice, st));
+    TP_HIP(hipMemcpyAsync(L, M->L, nb, hipMemcpyDeviceToDevice, st));
+    return TP_OK;
+}
+extern "C" int tp_mma_restart_set(tp_mma *M, int k, const double *xo1, const double *xo2, const double *U,
+                                  const double *L) {
+    if (!M || k < 0 || !xo1 || !xo2 || !U || !L) return TP_ERR_ARG;
+    hipStream_t st = M->grid->stream;
+    const size_t nb = sizeof(double) * M->n;
+    TP_HIP(hipMemcpyAsync(M->xo1, xo1, nb, hipMemcpyDeviceToDevice, st));
+    TP_HIP(hipMemcpyAsync(M->xo2, xo2, nb, hipMemcpyDeviceToDevice, st));
+    TP_HIP(hipMemcpyAsync(M->U, U, nb, hipMemcpyDeviceToDevice, st));
+    TP_HIP(hipMemcpyAsync(M->L, L, nb, hipMemcpyDeviceToDevice, st));
+    M->k = k;
+    return TP_OK;
+}

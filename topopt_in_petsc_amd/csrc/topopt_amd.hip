@@ -235,6 +235,11 @@ extern "C" int tp_elasticity_create(tp_elasticity **out, tp_grid *g, const tp_so
             L.kind = LV_MACRO;
             L.use_tile = true;
             L.sym_slot = e->mg.lv[0].sym_slot;
+            {
+                double gv[MACG_N];
+                const double dropped = make_macro_tensor(M.data(), gv);
+                if (dropped > 1e-12 || macro_slot_upload(L.sym_slot, gv)) return TP_ERR_STATE;
+            }
             L.fex = q.ex;
             L.fey = q.ey;
             TP_HIP(hipMalloc((void **)&e->d_corr, sizeof(double) * (size_t)L.ndof()));

@@ -6,11 +6,14 @@ scaling -> Filter::Gradients -> move limits -> MMA -> design change -> (beta
 continuation) -> FilterProject -> MND, printing the reference's per-iteration line.
 Everything stays on the device; the host sees scalars only.
 """
+import os
 import time
 from dataclasses import dataclass, field
 
+import numpy as np
 import torch
 
+from . import mpiio
 from .api import Filter, Grid, LinearElasticity, MMA, SolverOptions
 
 
@@ -40,6 +43,14 @@ class TopOpt:
     rank: int = 0
     nranks: int = 1
     solver: SolverOptions = None
+    # I/O around the loop (main.cc:40, :113-129; TopOpt.cc:400-512): off unless a workdir is given
+    workdir: str = None
+    output: bool = True            # output_00000.dat (MPIIO container)
+    restart: bool = True           # Restart0x.dat / Restart0x_itr_f0.dat / RestartSol0x.dat, alternating
+    restartFileVec: str = None     # -restartFileVec / -restartFileItr: continue from these
+    restartFileItr: str = None
+    restartFileVecSol: str = None  # -restartFileVecSol: the state U (LinearElasticity.cc:590-606)
+    onlyLoadDesign: bool = False
     history: list = field(default_factory=list)
 
     def __post_init__(self):
@@ -60,6 +71,16 @@ class TopOpt:
         self.mma = MMA(g, self.x, self.m)
         self.fscale = 1.0
         self.itr = 0
+        self._flip = True
+        self._out = None
+        if self.workdir is not None:
+            os.makedirs(self.workdir, exist_ok=True)
+            if self.output:
+                self._out = mpiio.MPIIO(g.part, h, filename=os.path.join(self.workdir, "output_00000.dat"),
+                                        xc0=(self.xc[0], self.xc[2], self.xc[4]))
+        if self.restartFileVec and self.restartFileItr and os.path.exists(self.restartFileVec) \
+                and os.path.exists(self.restartFileItr):
+            self.ReadRestartFiles(self.restartFileVec, self.restartFileItr, self.restartFileVecSol)
         # main.cc:48
         self.filt.FilterProject(self.x, self.xTilde, self.xPhys, self.projectionFilter, self.beta, self.eta)
 
@@ -92,6 +113,58 @@ class TopOpt:
                   % (self.itr, fx, fxs, gx, ch, mnd, t2 - t1), flush=True)                        # :108-111
         return rec
 
+    # ---- restart / output (host-side I/O; vectors gathered in natural = rank order) ----
+    def _gather(self, t):
+        a = t.detach().cpu().numpy()
+        if self.nranks == 1:
+            return a
+        import torch.distributed as dist
+        parts = [None] * self.nranks
+        dist.all_gather_object(parts, a)
+        return np.concatenate(parts)
+
+    def _own(self, a):
+        n = self.grid.part.n_own_elems
+        return torch.from_numpy(np.ascontiguousarray(a[self.rank * n:(self.rank + 1) * n])).to(self.x.device)
+
+    def WriteRestartFiles(self):
+        """TopOpt::WriteRestartFiles (TopOpt.cc:514-570) + LinearElasticity::WriteRestartFiles (:447-478)"""
+        if self.workdir is None or not self.restart:
+            return None
+        self._flip = not self._flip
+        tag = "01" if self._flip else "00"
+        g = self.grid
+        xo1, xo2, U, L = g.elem_vec(), g.elem_vec(), g.elem_vec(), g.elem_vec()
+        self.mma.Restart(xo1, xo2, U, L)
+        vecs = [self._gather(v) for v in (self.x, self.xPhys, xo1, xo2, U, L)]
+        sol = self._gather(self.physics.U[self.grid.part.owned_slice(3)])
+        prefix = os.path.join(self.workdir, "Restart" + tag)
+        if self.rank == 0:
+            mpiio.write_restart(prefix, self.itr, self.fscale, *vecs)
+            mpiio.write_petsc_vecs(os.path.join(self.workdir, "RestartSol%s.dat" % tag), [sol])
+        return prefix
+
+    def ReadRestartFiles(self, vecfile, itrfile, solfile=None):
+        """TopOpt::AllocateMMAwithRestart (TopOpt.cc:474-507); solfile = -restartFileVecSol (LinearElasticity.cc:590-606)"""
+        x, xPhys, xo1, xo2, U, L = mpiio.read_petsc_vecs(vecfile)
+        itr, fscale = open(itrfile).read().split()
+        self.x.copy_(self._own(x))
+        self.xPhys.copy_(self._own(xPhys))
+        self.fscale = float(fscale)
+        self.itr = int(itr)
+        if not self.onlyLoadDesign:
+            self.mma.SetRestart(self.itr, self._own(xo1), self._own(xo2), self._own(U), self._own(L))
+        if solfile and os.path.exists(solfile):
+            sol, = mpiio.read_petsc_vecs(solfile)
+            self.physics.U.zero_()
+            sl = self.grid.part.owned_slice(3)
+            n0 = 3 * self.grid.part.plane * (self.grid.part.node_z0 + self.grid.part.own_lo)
+            self.physics.U[sl] = torch.from_numpy(sol[n0:n0 + (sl.stop - sl.start)].copy()).to(self.x.device)
+
+    def WriteVTK(self, itr):
+        if self._out is not None:
+            self._out.WriteVTK(self.physics.U, self.x, self.xTilde, self.xPhys, itr)
+
     def _increase_beta(self, gx, ch):
         """Filter::IncreaseBeta, Filter.cc:268-288"""
         if (ch < 0.01 or self.itr % 10 == 0) and self.beta < self.betaFinal and gx < 0.000001:
@@ -102,5 +175,12 @@ class TopOpt:
         ch = 1.0
         n = self.maxItr if max_itr is None else max_itr
         while self.itr < n and ch > 0.01:                                                        # main.cc:54
+            beta0 = self.beta
             ch = self.step(verbose)["ch"]
+            if self.itr < 11 or self.itr % 20 == 0 or self.beta != beta0:                        # :114-116
+                self.WriteVTK(self.itr)
+            if self.itr % 10 == 0:                                                               # :119-122
+                self.WriteRestartFiles()
+        self.WriteRestartFiles()                                                                 # :125-126
+        self.WriteVTK(self.itr + 1)                                                              # :129
         return self.history

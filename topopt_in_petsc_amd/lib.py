@@ -97,6 +97,8 @@ SYMBOLS = {
     "tp_mma_update": (_i, [_vp, _vp, _vp, C.POINTER(_d), C.POINTER(_vp), _vp, _vp, C.POINTER(_i)]),
     "tp_mma_design_change": (_i, [_vp, _vp, _vp, C.POINTER(_d)]),
     "tp_mma_get_state": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_i)]),
+    "tp_mma_restart_get": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "tp_mma_restart_set": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "tp_vec_scale": (_i, [_vp, _vp, _d, _l]),
     "tp_vec_set": (_i, [_vp, _vp, _d, _l]),
     "tp_synth_density": (_i, [_vp, _vp, C.c_uint64]),
