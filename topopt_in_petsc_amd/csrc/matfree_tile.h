@@ -332,12 +332,15 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
     const unsigned own_cm = (node_ok && t.colmask) ? t.colmask[ncol] : 0u;
 
     double pre[4];
-    load_plane(kz0 - 1, pre);
-    store_plane(0, pre);
-    load_plane(kz0, pre);
-    store_plane(1, pre);
-    load_plane(kz0 + 1, pre);
-    store_plane(2, pre);
+    {   // all three planes in flight at once: one memory round trip instead of three
+        double p0[4], p1[4];
+        load_plane(kz0 - 1, p0);
+        load_plane(kz0, p1);
+        load_plane(kz0 + 1, pre);
+        store_plane(0, p0);
+        store_plane(1, p1);
+        store_plane(2, pre);
+    }
     __syncthreads();
     double Ub[3][4];
     read_plane_wht(0, Ub);
@@ -347,6 +350,19 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
 #pragma unroll
         for (int m = 0; m < 4; m++) Cy[c][m] = 0.0;
     double pdot = 0.0;
+    // MACRO: moduli of the 8 children of this thread's coarse element in layer l (0 outside the domain)
+    auto load_children = [&](int l, double e8[8]) {
+        const bool eok = elem_ok && l >= 0 && l < t.ezl;
+#pragma unroll
+        for (int ch = 0; ch < 8; ch += 2) {  // the x-pair of children is one aligned 16-byte load (fex is even)
+            double2 v = make_double2(0.0, 0.0);
+            if (eok) v = *(const double2 *)(t.E + ((long)(2 * ei) + (long)t.fex * ((2 * ej + ((ch >> 1) & 1)) + (long)t.fey * (2 * l + (ch >> 2)))));
+            e8[ch] = v.x;
+            e8[ch + 1] = v.y;
+        }
+    };
+    double en[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (MACRO) load_children(kz0 - 1, en);
 
     for (int s = 0; s < nsteps; s++) {
         const int el = kz0 - 1 + s;  // element layer; bottom node plane el, top plane el+1
@@ -394,9 +410,8 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
             Ee = eok ? 1.0 : 0.0;  // children moduli are applied inside
             double eh[8];
 #pragma unroll
-            for (int ch = 0; ch < 8; ch++)
-                eh[ch] = eok ? t.E[(long)(2 * ei + (ch & 1)) + (long)t.fex * ((2 * ej + ((ch >> 1) & 1)) + (long)t.fey * (2 * el + (ch >> 2)))]
-                             : 0.0;
+            for (int ch = 0; ch < 8; ch++) eh[ch] = en[ch];
+            if (more) load_children(el + 1, en);  // one step ahead: the latency hides behind this step's arithmetic
             {   // Walsh-Hadamard transform of the 8 child moduli
                 double lo[4] = {eh[0], eh[1], eh[2], eh[3]}, hi[4] = {eh[4], eh[5], eh[6], eh[7]};
                 wht4(lo);
@@ -407,6 +422,7 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
                     eh[m + 4] = lo[m] - hi[m];
                 }
             }
+            // constants through the scalar cache (an LDS copy read with broadcast ds_read_b64 measured 15 % slower)
             int goff;
             asm volatile("s_mov_b32 %0, %1" : "=s"(goff) : "s"(t.macg_off));
             macg_apply(c_macG + goff, u, eh, f);

@@ -348,7 +348,7 @@ struct MGSolver {
             const int planes = L.g.own_hi - L.g.own_lo + 1;
             static const int kz_env = getenv("TP_MACRO_KZ") ? atoi(getenv("TP_MACRO_KZ")) : 0;
             int kz = kz_env > 0 ? kz_env : (int)((long)planes * tx * ty / 768);
-            kz = kz < 4 ? 4 : (kz > 64 ? 64 : kz);
+            if (kz_env <= 0) kz = kz < 4 ? 4 : (kz > 64 ? 64 : kz);
             if (kz > planes) kz = planes;
             const int tz = (planes + kz - 1) / kz;
             last_nblocks = tx * ty * tz;
