@@ -146,11 +146,12 @@ def main():
     # ---- roofline ---------------------------------------------------------------------------------
     # Dominant kernel of the step (rocprofv3: profiles/): k_matfree_tile<EPI_CHEB,0>, the fine-level matrix-free
     # hex8 operator fused with the Chebyshev-Jacobi update.  Algorithmic bytes per launch:
-    # SpMV part 24 B/node read x + 8 B/element E, vector part b, d, dinv read + d, x written (24 B/node each).
+    # reads 24 B/node each of the iterate u, the previous iterate u- and the right-hand side b, 8 B/element of E;
+    # writes 24 B/node of the new iterate (3-term Chebyshev; the Jacobi diagonal is rebuilt from E in the kernel).
     part = grid.part
     n_nd_own, n_el_own = part.n_owned_nodes, part.n_own_elems
     spmv_bytes = 48.0 * n_nd_own + 8.0 * n_el_own
-    cheb_bytes = 144.0 * n_nd_own + 8.0 * n_el_own
+    cheb_bytes = 96.0 * n_nd_own + 8.0 * n_el_own
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def timed(fn, reps):

@@ -29,7 +29,7 @@ n_nd, n_el = (ex + 1) * (ey + 1) * (ez + 1), ex * ey * ez
 res = {"mesh": "%dx%dx%d" % (ex, ey, ez), "launches_counted": {"fetch": nf, "write": nw},
        "calibration_kscale_2^27_doubles": {"fetch_size_kb": f["calib"], "write_size_kb": w["calib"], "true_kb_each": 8 * (1 << 27) / 1024},
        "fetch_correction": 2.0}
-for k, alg in (("spmv", 48 * n_nd + 8 * n_el), ("cheb", 144 * n_nd + 8 * n_el)):
+for k, alg in (("spmv", 48 * n_nd + 8 * n_el), ("cheb", 96 * n_nd + 8 * n_el)):
     if f[k] is None or w[k] is None:
         continue
     res[k] = {"fetch_size_kb": f[k], "write_size_kb": w[k], "hbm_bytes_per_launch": 1024.0 * (2.0 * f[k] + w[k]),

@@ -55,8 +55,9 @@ __host__ __device__ constexpr int symke_idx(int q, int r, int s) {
 constexpr int SYMKE_N = 33;
 static_assert(symke_idx(7, 2, 2) == SYMKE_N - 1, "packed size");
 
+constexpr int SYMKE_NTOT = SYMKE_N + 3;  // + 1 / KE[c][c]: the nodal diagonal is KE[c][c] * (sum of the 8 adjacent moduli)
 struct SymKE {
-    double a[SYMKE_N];
+    double a[SYMKE_NTOT];
 };
 
 // natural index m = lx + 2 ly + 4 lz  ->  reference corner number
@@ -96,6 +97,11 @@ inline double make_sym_ke(const double *KE, SymKE *out) {
                 const double b = D[(q ^ (1 << s)) * 3 + s][(q ^ (1 << r)) * 3 + r];
                 out->a[id] = 0.5 * (a + b);  // KE itself is symmetric only to rounding
             }
+    for (int c = 0; c < 3; c++) {
+        out->a[SYMKE_N + c] = 1.0 / KE[c * 24 + c];
+        for (int m = 1; m < 8; m++)  // equal at all 8 corners for a box element
+            dropped = fmax(dropped, fabs(KE[(3 * m + c) * 24 + 3 * m + c] - KE[c * 24 + c]));
+    }
     return maxabs > 0 ? dropped / maxabs : 0.0;
 }
 
@@ -119,6 +125,7 @@ __device__ inline void wht4(double v[4]) {
 // loads (s_load -> SGPR operands of v_fma_f64: no vector registers, no LDS).  A
 // small pool of slots lets several solver contexts (different KE) coexist.
 constexpr int SYMKE_SLOTS = 16, SYMKE_STRIDE = 40;
+static_assert(SYMKE_N + 3 <= SYMKE_STRIDE, "stride");
 __constant__ double c_symB[SYMKE_SLOTS * SYMKE_STRIDE];
 
 // level-1 operator constants (MACG_N packed values of G_sigma, macro_pattern.h), same slot numbering
@@ -167,7 +174,7 @@ inline int macro_slot_upload(int slot, const double *vals) {
 }
 
 struct SymSlots {
-    double key[SYMKE_SLOTS][SYMKE_N];
+    double key[SYMKE_SLOTS][SYMKE_NTOT];
     int refs[SYMKE_SLOTS];
 };
 inline SymSlots &sym_slots() {
@@ -252,6 +259,11 @@ template <int EPI, int MACRO>
 __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(TileArgs t, NodeArgs a) {
     __shared__ double s_u[3][STG_N];          // node-plane ring: bottom, top, next
     __shared__ double s_y[2][TILE * TILE * 3];  // y-combination, double buffered -> one barrier per step
+    // fine-level CHEB streams 4 node vectors instead of 6: the Jacobi diagonal is rebuilt from the moduli (KE[c][c] * sum
+    // of the 8 adjacent E, combined in x/y/z like the operator itself), and the recurrence runs in its 3-term form
+    // u+ = u + c1 (u - u-) + c2 D^-1 (b - K u) with u- read from, and u+ written to, the same output slot
+    constexpr bool DIAG_FLY = (EPI == EPI_CHEB && !MACRO);
+    __shared__ double s_e[DIAG_FLY ? 2 : 1][DIAG_FLY ? TILE * TILE : 1];
     const int tid = threadIdx.x;
     const int tx = tid & (TILE - 1), ty = tid / TILE;
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (private L2 each); give every XCD a
@@ -350,6 +362,7 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
 #pragma unroll
         for (int m = 0; m < 4; m++) Cy[c][m] = 0.0;
     double pdot = 0.0;
+    double Elow = 0.0;  // DIAG_FLY: in-plane modulus sum of the previous element layer
     // MACRO: moduli of the 8 children of this thread's coarse element in layer l (0 outside the domain)
     auto load_children = [&](int l, double e8[8]) {
         const bool eok = elem_ok && l >= 0 && l < t.ezl;
@@ -383,8 +396,13 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
                 if (EPI != EPI_RESID || own_cm) xo[c] = own_cm ? x[nq + c] : s_u[b0][o00 + c];
                 if (EPI == EPI_RESID || EPI == EPI_CHEB) bo[c] = a.b[nq + c];
                 if (EPI == EPI_CHEB) {
-                    dd[c] = a.d[nq + c];
-                    di[c] = a.dinv[nq + c];
+                    if (!DIAG_FLY) {
+                        dd[c] = a.d[nq + c];
+                        di[c] = a.dinv[nq + c];
+                    } else {
+                        // 3-term form: the previous iterate lives in the output buffer (c1 = 0: first step, not read)
+                        dd[c] = (a.c1 != 0.0 && !a.prev_zero) ? a.out[nq + c] : 0.0;
+                    }
                 }
                 if (MACRO && t.corr) co[c] = t.corr[nq + c];
             }
@@ -445,10 +463,22 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
             s1[c] = P[c][2] + dpp_row_shr1(P[c][3]);  // node (ei, ej+1)
             s_y[s & 1][tid * 3 + c] = s1[c];
         }
+        double ex2 = 0.0;
+        if (DIAG_FLY) {
+            ex2 = Ee + dpp_row_shr1(Ee);  // this element + its left neighbour
+            s_e[s & 1][tid] = ex2;
+        }
         __syncthreads();
+        double e4 = 0.0;  // DIAG_FLY: the 4 elements of this layer around the node
+        if (DIAG_FLY && node_ok) e4 = ex2 + s_e[s & 1][tid - TILE];
         if (outp) {
             unsigned m = 0;
             if (own_cm) m = t.mask[ncol + plane * el];
+            if (DIAG_FLY) {
+                const double rinv = 1.0 / (e4 + Elow);
+#pragma unroll
+                for (int c = 0; c < 3; c++) di[c] = ((m >> c) & 1u) ? 1.0 : rinv * c_symB[boff + SYMKE_N + c];
+            }
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 double y = s0[c] + s_y[s & 1][(tid - TILE) * 3 + c];
@@ -459,6 +489,9 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
                     a.out[q] = y;
                 } else if (EPI == EPI_RESID) {
                     a.out[q] = bo[c] - y;
+                } else if (EPI == EPI_CHEB && DIAG_FLY) {
+                    const double dprev = a.c1 != 0.0 ? xo[c] - dd[c] : 0.0;  // prev_zero: dd = 0
+                    a.out[q] = xo[c] + (a.c1 * dprev + a.c2 * (di[c] * (bo[c] - y)));
                 } else if (EPI == EPI_CHEB) {
                     const double dn = a.c1 * dd[c] + a.c2 * (di[c] * (bo[c] - y));
                     a.d[q] = dn;
@@ -469,6 +502,7 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
                 }
             }
         }
+        if (DIAG_FLY) Elow = e4;
         // slot b0 was last read before the barrier above; its next reader (step s+2) is behind the next one
         if (more) store_plane(b0, pre);
     }

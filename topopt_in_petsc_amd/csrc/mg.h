@@ -380,10 +380,14 @@ struct MGSolver {
             flops = 2.0 * 27 * DOF * DOF * (double)nown;
         }
         if (EPI == EPI_RESID) bytes += 8.0 * DOF * nown;
-        if (EPI == EPI_CHEB) bytes += 4.0 * 8.0 * DOF * nown;
+        // d (r/w), b, dinv -- the fine tile kernel instead reads b and the previous iterate (3-term form, diagonal on the fly)
+        if (EPI == EPI_CHEB) bytes += (three_term(L) ? 2.0 : 4.0) * 8.0 * DOF * nown;
         count_launch(grid, bytes, flops);
         return TP_OK;
     }
+    // Fine tile kernel: Chebyshev in its 3-term form  u+ = u + c1 (u - u-) + c2 D^-1 (b - A u); u- sits in the output
+    // buffer (read and overwritten by the same thread), so no direction vector is streamed.
+    static bool three_term(const Level<DOF> &L) { return DOF == 3 && L.kind == LV_MATFREE && L.use_tile; }
     int halo(int l, double *v) { return lv[l].no_comm ? TP_OK : halo_nodes(grid, lv[l].g, v, DOF); }
 
     // y = A_l u (ghost planes of u refreshed first)
@@ -417,8 +421,8 @@ struct MGSolver {
         double rho = 1.0 / sigma;
         int it = 0;
         if (zero_guess) {
-            hipLaunchKernelGGL(k_cheb_first, dim3(grid_for(L.own_n())), dim3(BLK), 0, grid->stream, L.x, L.d, b, L.dinv,
-                               1.0 / theta, L.own_off(), L.own_n());
+            hipLaunchKernelGGL(k_cheb_first, dim3(grid_for(L.own_n())), dim3(BLK), 0, grid->stream, L.x,
+                               three_term(L) ? nullptr : L.d, b, L.dinv, 1.0 / theta, L.own_off(), L.own_n());
             count_launch(grid, 32.0 * L.own_n(), 2.0 * L.own_n());
             it = 1;
         }
@@ -429,6 +433,7 @@ struct MGSolver {
             a.b = b;
             a.d = L.d;
             a.dinv = L.dinv;
+            a.prev_zero = (zero_guess && it == 1) ? 1 : 0;
             if (it == 0) {
                 a.c1 = 0.0;
                 a.c2 = 1.0 / theta;

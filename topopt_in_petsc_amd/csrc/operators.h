@@ -110,6 +110,7 @@ struct NodeArgs {
     double *d;           // CHEB direction (in/out)
     const double *dinv;  // CHEB Jacobi
     double c1, c2;       // CHEB recurrence coefficients
+    int prev_zero;       // CHEB, 3-term form: the previous iterate is the zero guess (not read)
     double *partials;    // APPLY_DOT: per-block partial of x . (A x)
 };
 
@@ -150,13 +151,14 @@ __global__ __launch_bounds__(BLK) void k_node(Op op, NodeArgs a) {
     }
 }
 
-// first Chebyshev step with a zero initial guess: d = dinv*b/theta, x = d (owned range)
+// first Chebyshev step with a zero initial guess: x = dinv*b/theta, d = x (owned range; d = null in the 3-term
+// form, whose next step is told that the previous iterate is zero)
 __global__ __launch_bounds__(BLK) void k_cheb_first(double *__restrict__ x, double *__restrict__ d,
                                                     const double *__restrict__ b, const double *__restrict__ dinv,
                                                     double inv_theta, long off, long n) {
     for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
         const double v = dinv[off + i] * b[off + i] * inv_theta;
-        d[off + i] = v;
+        if (d) d[off + i] = v;
         x[off + i] = v;
     }
 }
