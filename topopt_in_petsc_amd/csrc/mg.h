@@ -373,9 +373,19 @@ struct MGSolver {
             flops = 2.0 * (8 * DOF) * (8 * DOF) * (double)L.g.own_elems();
         } else {
             DiaOp<DOF> o{L.S, L.ndof(), L.g};
-            const int nbr = (int)((nown * DOF + BLK - 1) / BLK);
+            int nbr = (int)((nown * DOF + BLK - 1) / BLK);
+            static const int split_env = getenv("TP_DIA_SPLIT") ? atoi(getenv("TP_DIA_SPLIT")) : -1;
+            const int split = split_env >= 0 ? split_env : (nbr < 128 ? 9 : (nbr < 512 ? 3 : 1));
+            if (split == 9) {
+                nbr = (int)((nown * DOF + BLK / 9 - 1) / (BLK / 9));
+                hipLaunchKernelGGL((k_dia_row_split<DOF, EPI, 9>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
+            } else if (split == 3) {
+                nbr = (int)((nown * DOF + BLK / 3 - 1) / (BLK / 3));
+                hipLaunchKernelGGL((k_dia_row_split<DOF, EPI, 3>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
+            } else {
+                hipLaunchKernelGGL((k_dia_row<DOF, EPI>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
+            }
             last_nblocks = nbr;
-            hipLaunchKernelGGL((k_dia_row<DOF, EPI>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
             bytes = (27.0 * DOF * DOF + 2.0 * DOF) * 8.0 * nown;
             flops = 2.0 * 27 * DOF * DOF * (double)nown;
         }

@@ -313,3 +313,65 @@ __global__ __launch_bounds__(BLK) void k_dia_row(DiaOp<DOF> op, NodeArgs a) {
         if (threadIdx.x == 0) a.partials[blockIdx.x] = pdot;
     }
 }
+
+// The same operator for the SMALLEST levels (17^3 nodes: 58 workgroups of rows would leave 3/4 of the chip idle and
+// queue 162 loads per thread behind one CU's address unit): a row is split over SPLIT threads -- by z-offset (3) or
+// (z, y)-offset (9) of the neighbour -- whose partial sums meet in LDS in a fixed order.
+template <int DOF, int EPI, int SPLIT>
+__global__ __launch_bounds__(BLK) void k_dia_row_split(DiaOp<DOF> op, NodeArgs a) {
+    constexpr int RPB = BLK / SPLIT;  // rows per workgroup
+    __shared__ double s_part[SPLIT][RPB];
+    const Geom &g = op.g;
+    const long plane = g.plane();
+    const int part = threadIdx.x / RPB, r = threadIdx.x % RPB;
+    const long t = blockIdx.x * (long)RPB + r;
+    const bool valid = part < SPLIT && t < g.owned_nodes() * DOF;
+    const long q = t + plane * g.own_lo * DOF;  // row
+    const double *__restrict__ u = a.x;
+    if (valid) {
+        const long n = q / DOF;
+        const int k = (int)(n / plane);
+        const int rem = (int)(n % plane);
+        const int j = rem / g.nx, i = rem % g.nx;
+        double y = 0.0;
+        const int dk = (SPLIT == 3 ? part : part / 3) - 1;
+        const bool okk = k + dk >= 0 && k + dk < g.nzl;
+#pragma unroll
+        for (int djj = 0; djj < (SPLIT == 9 ? 1 : 3); djj++) {
+            const int dj = (SPLIT == 9 ? part % 3 : djj) - 1;
+            const bool okj = okk && j + dj >= 0 && j + dj < g.ny;
+#pragma unroll
+            for (int di = -1; di <= 1; di++) {
+                const bool ok = okj && i + di >= 0 && i + di < g.nx;
+                const int blk = (dk + 1) * 9 + (dj + 1) * 3 + (di + 1);
+                const long nb = ok ? n + di + (long)g.nx * (dj + (long)g.ny * dk) : n;
+#pragma unroll
+                for (int c = 0; c < DOF; c++) y = fma(op.S[(long)(blk * DOF + c) * op.nrows + q], u[nb * DOF + c], y);
+            }
+        }
+        s_part[part][r] = y;
+    }
+    __syncthreads();
+    double pdot = 0.0;
+    if (valid && part == 0) {
+        double y = s_part[0][r];
+#pragma unroll
+        for (int p = 1; p < SPLIT; p++) y += s_part[p][r];
+        if (EPI == EPI_APPLY) {
+            a.out[q] = y;
+        } else if (EPI == EPI_RESID) {
+            a.out[q] = a.b[q] - y;
+        } else if (EPI == EPI_CHEB) {
+            const double dn = a.c1 * a.d[q] + a.c2 * (a.dinv[q] * (a.b[q] - y));
+            a.d[q] = dn;
+            a.out[q] = u[q] + dn;
+        } else {
+            a.out[q] = y;
+            pdot = u[q] * y;
+        }
+    }
+    if (EPI == EPI_APPLY_DOT) {
+        pdot = block_sum(pdot);
+        if (threadIdx.x == 0) a.partials[blockIdx.x] = pdot;
+    }
+}
