@@ -72,7 +72,9 @@ typedef struct tp_comm {
     double *gather;                                /* [dev] nranks * cap doubles */
     int (*allgather)(void *user, long n);
     /* optional zero-copy halo of contiguous planes (may be NULL -> staged `exchange` is used):
-     * to_lo[0..n) -> rank-1, to_hi[0..n) -> rank+1, from_lo <- rank-1, from_hi <- rank+1, all [dev] */
+     * to_lo[0..n) -> rank-1, to_hi[0..n) -> rank+1, from_lo <- rank-1, from_hi <- rank+1, all [dev].
+     * Returns 0, or 2 = "cannot address these pointers, nothing was sent": the library then uses `exchange`
+     * from now on (same message sizes and order, so ranks may differ in their choice); else error. */
     int (*exchange_direct)(void *user, const double *to_lo, double *from_lo, const double *to_hi, double *from_hi,
                            long n);
 } tp_comm;

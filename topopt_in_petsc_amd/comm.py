@@ -37,6 +37,8 @@ class SlabComm:
         self.n_allreduces = 0
         self.bytes_sent = 0
         self._via_host = self.device.type == "cuda" and self.backend != "nccl"
+        # the first collective of a group must involve all its ranks (the later neighbour exchanges do not)
+        dist.all_reduce(self.red[:1] if not self._via_host else torch.zeros(1, dtype=torch.float64), group=self.group)
         # keep the callbacks alive for the lifetime of the object
         self._ex_cb = _lib.EXCHANGE_FN(self._exchange_cb)
         self._ar_cb = _lib.ALLREDUCE_FN(self._allreduce_cb)
@@ -96,24 +98,28 @@ class SlabComm:
             self._raw_cache[key] = t
         return t
 
+    def _direct_prepare(self, to_lo, from_lo, to_hi, from_hi, n):
+        lo, hi = self.rank - 1, self.rank + 1
+        has_lo, has_hi = lo >= 0, hi < self.nranks
+        ts = [self._raw(p, n) if (p and ok) else None
+              for p, ok in ((to_lo, has_lo), (from_lo, has_lo), (to_hi, has_hi), (from_hi, has_hi))]
+        ops = []
+        if not self._via_host:
+            if has_lo:
+                ops += [dist.P2POp(dist.isend, ts[0], self._g(lo), self.group),
+                        dist.P2POp(dist.irecv, ts[1], self._g(lo), self.group)]
+            if has_hi:
+                ops += [dist.P2POp(dist.isend, ts[2], self._g(hi), self.group),
+                        dist.P2POp(dist.irecv, ts[3], self._g(hi), self.group)]
+        ent = (ts, ops)
+        self._direct_cache[(to_lo, from_lo, to_hi, from_hi, n)] = ent
+        return ent
+
     def exchange_direct(self, to_lo, from_lo, to_hi, from_hi, n):
         lo, hi = self.rank - 1, self.rank + 1
         has_lo, has_hi = lo >= 0, hi < self.nranks
-        key = (to_lo, from_lo, to_hi, from_hi, n)
-        ent = self._direct_cache.get(key)
-        if ent is None:
-            ts = [self._raw(p, n) if (p and ok) else None
-                  for p, ok in ((to_lo, has_lo), (from_lo, has_lo), (to_hi, has_hi), (from_hi, has_hi))]
-            ops = []
-            if not self._via_host:
-                if has_lo:
-                    ops += [dist.P2POp(dist.isend, ts[0], self._g(lo), self.group),
-                            dist.P2POp(dist.irecv, ts[1], self._g(lo), self.group)]
-                if has_hi:
-                    ops += [dist.P2POp(dist.isend, ts[2], self._g(hi), self.group),
-                            dist.P2POp(dist.irecv, ts[3], self._g(hi), self.group)]
-            ent = (ts, ops)
-            self._direct_cache[key] = ent
+        ent = self._direct_cache.get((to_lo, from_lo, to_hi, from_hi, n)) or \
+            self._direct_prepare(to_lo, from_lo, to_hi, from_hi, n)
         ts, ops = ent
         if self._via_host:  # gloo with GPU memory: same tensors, staged through the host
             hops, r_lo, r_hi = [], None, None
@@ -138,8 +144,15 @@ class SlabComm:
         self.bytes_sent += 8 * n * (int(has_lo) + int(has_hi))
 
     def _direct_cb(self, _user, to_lo, from_lo, to_hi, from_hi, n):
+        args = (to_lo or 0, from_lo or 0, to_hi or 0, from_hi or 0, int(n))
+        if args not in self._direct_cache:
+            try:  # wrapping the library's pointers happens before any communication: a failure here is recoverable
+                self._direct_prepare(*args)
+            except Exception as e:
+                print("SlabComm: zero-copy halo unavailable (%r); staging buffers are used instead" % (e,), flush=True)
+                return 2   # the library falls back to exchange() for good (same message sizes and order)
         try:
-            self.exchange_direct(to_lo or 0, from_lo or 0, to_hi or 0, from_hi or 0, int(n))
+            self.exchange_direct(*args)
             return 0
         except Exception as e:
             print("SlabComm.exchange_direct failed: %r" % (e,), flush=True)

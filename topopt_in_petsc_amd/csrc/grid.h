@@ -114,10 +114,11 @@ inline int halo_nodes(tp_grid *g, const Geom &q, double *v, int dof) {
     long pl = q.plane() * dof;
     if (g->comm.exchange_direct) {  // zero-copy: the framework sends/receives the planes in place
         const bool lo = g->rank > 0, hi = g->rank < g->nranks - 1;
-        if (g->comm.exchange_direct(g->comm.user, lo ? v + pl * q.own_lo : nullptr, lo ? v : nullptr,
-                                    hi ? v + pl * q.own_hi : nullptr, hi ? v + pl * (q.nzl - 1) : nullptr, pl))
-            return TP_ERR_COMM;
-        return TP_OK;
+        const int rc = g->comm.exchange_direct(g->comm.user, lo ? v + pl * q.own_lo : nullptr, lo ? v : nullptr,
+                                               hi ? v + pl * q.own_hi : nullptr, hi ? v + pl * (q.nzl - 1) : nullptr, pl);
+        if (rc == 0) return TP_OK;
+        if (rc != 2) return TP_ERR_COMM;
+        g->comm.exchange_direct = nullptr;  // 2: the host cannot address our memory in place -> staging from now on
     }
     return exchange_segments(g, v + pl * q.own_lo, v /*plane 0*/, v + pl * q.own_hi, v + pl * (q.nzl - 1), pl, 1, pl);
 }
