@@ -112,9 +112,18 @@ __global__ __launch_bounds__(BLK) void k_multi_dot(const double *__restrict__ V,
                                                    double *__restrict__ partials) {
     const int q = blockIdx.y;
     const double *__restrict__ vq = V + (long)q * stride;
-    double s = 0.0;
-    for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) s = fma(vq[off + i], w[off + i], s);
-    s = block_sum(s);
+    // 4 independent chains: with one workgroup per vector (small levels) the loop is latency bound
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const long st = (long)gridDim.x * BLK;
+    long i = blockIdx.x * (long)BLK + threadIdx.x;
+    for (; i + 3 * st < n; i += 4 * st) {
+        s0 = fma(vq[off + i], w[off + i], s0);
+        s1 = fma(vq[off + i + st], w[off + i + st], s1);
+        s2 = fma(vq[off + i + 2 * st], w[off + i + 2 * st], s2);
+        s3 = fma(vq[off + i + 3 * st], w[off + i + 3 * st], s3);
+    }
+    for (; i < n; i += st) s0 = fma(vq[off + i], w[off + i], s0);
+    double s = block_sum((s0 + s1) + (s2 + s3));
     if (threadIdx.x == 0) partials[(long)q * gridDim.x + blockIdx.x] = s;
 }
 // out[q] = sum_b partials[q*nb + b]; one workgroup per value (grid = nv)
@@ -129,7 +138,9 @@ __global__ __launch_bounds__(BLK) void k_reduce_multi(const double *__restrict__
 // w -= sum_q h[q] V_q ; acc[q] += h[q]  (device-resident coefficients)
 __global__ __launch_bounds__(BLK) void k_multi_axpy(const double *__restrict__ V, long stride, int nv,
                                                     const double *__restrict__ h, double *__restrict__ w, long off,
-                                                    long n) {
+                                                    long n, const double *__restrict__ hprev, double *__restrict__ alpha) {
+    // Lanczos, second Gram-Schmidt pass: alpha[j] = h1[j] + h2[j] with j = nv - 1
+    if (hprev && blockIdx.x == 0 && threadIdx.x == 0) alpha[nv - 1] = hprev[nv - 1] + h[nv - 1];
     for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
         double acc = w[off + i];
         for (int q = 0; q < nv; q++) acc = fma(-h[q], V[(long)q * stride + off + i], acc);
@@ -318,8 +329,12 @@ struct MGSolver {
             Level<DOF> &L = lv[l];
             for (double *p : {L.b, L.x, L.x2, L.r, L.d, L.dinv, L.S, L.Kel}) (void)hipFree(p);
         }
-        for (double *p : {cg_r, cg_p, cg_w}) (void)hipFree(p);
+        for (double *p : {cg_r, cg_p, cg_w, lan_V, lan_coef}) (void)hipFree(p);
+        lan_V = lan_coef = nullptr;
+        lan_cap = 0;
     }
+    double *lan_V = nullptr, *lan_coef = nullptr;  // Lanczos basis / coefficients, kept across design iterations
+    size_t lan_cap = 0;
 
     // ---- operator application with one of the epilogues -------------------
     template <int EPI>
@@ -556,19 +571,32 @@ struct MGSolver {
         Level<DOF> &L = lv[l];
         if (steps > 128) steps = 128;
         const long off = L.own_off(), n = L.own_n(), nd = L.ndof();
-        const int nb = grid_for(n, 256);
+        // small levels: one workgroup per dot product writes its result directly (no second reduction stage)
+        const int nb = n <= 65536 ? 1 : grid_for(n, 256);
         const int gn = (int)((L.g.owned_nodes() + BLK - 1) / BLK);
+        auto multi_dot = [&](const double *A, int nv, const double *wv, double *out) {
+            hipLaunchKernelGGL(k_multi_dot, dim3(nb, nv), dim3(BLK), 0, grid->stream, A, nd, nv, wv, off, n,
+                               nb == 1 ? out : grid->partials);
+            if (nb > 1) hipLaunchKernelGGL(k_reduce_multi, dim3(nv), dim3(BLK), 0, grid->stream, grid->partials, nb, nv, out);
+        };
         hipStream_t s = grid->stream;
-        double *V = nullptr, *coef = nullptr;  // coef: h1[129] h2[129] alpha[128] beta[128] bb[1]
-        TP_HIP(hipMalloc((void **)&V, sizeof(double) * (size_t)nd * (size_t)(steps + 1)));
-        TP_HIP(hipMalloc((void **)&coef, sizeof(double) * 520));
+        // coef: h1[129] h2[129] alpha[128] beta[128] bb[1]
+        const size_t need = (size_t)nd * (size_t)(steps + 1);
+        if (need > lan_cap) {
+            (void)hipFree(lan_V);
+            lan_V = nullptr;
+            lan_cap = 0;
+            TP_HIP(hipMalloc((void **)&lan_V, sizeof(double) * need));
+            lan_cap = need;
+        }
+        if (!lan_coef) TP_HIP(hipMalloc((void **)&lan_coef, sizeof(double) * 520));
+        double *V = lan_V, *coef = lan_coef;
         TP_HIP(hipMemsetAsync(V, 0, sizeof(double) * (size_t)nd * (size_t)(steps + 1), s));
         TP_HIP(hipMemsetAsync(coef, 0, sizeof(double) * 520, s));
         double *h1 = coef, *h2 = coef + 129, *al = coef + 258, *be = coef + 386, *bb = coef + 514;
         double *w = L.d, *t = L.x, *dis = L.x2;
         hipLaunchKernelGGL((k_lanczos_init<DOF>), dim3(gn), dim3(BLK), 0, s, L.g, V, dis, L.dinv);
-        hipLaunchKernelGGL(k_multi_dot, dim3(nb, 1), dim3(BLK), 0, s, V, nd, 1, V, off, n, grid->partials);
-        hipLaunchKernelGGL(k_reduce_multi, dim3(1), dim3(BLK), 0, s, grid->partials, nb, 1, bb);
+        multi_dot(V, 1, V, bb);
         TP_TRY(allreduce_dev(bb, 1, L.no_comm));
         hipLaunchKernelGGL(k_lanczos_next, dim3(grid_for(n)), dim3(BLK), 0, s, V, bb, 0, be, V, off, n);  // normalise v0
         int m = 0;
@@ -579,25 +607,22 @@ struct MGSolver {
             hipLaunchKernelGGL(k_pw_mult, dim3(grid_for(n)), dim3(BLK), 0, s, w + off, dis + off, w + off, n);
             for (int pass = 0; pass < 2; pass++) {
                 double *h = pass ? h2 : h1;
-                hipLaunchKernelGGL(k_multi_dot, dim3(nb, j + 1), dim3(BLK), 0, s, V, nd, j + 1, w, off, n, grid->partials);
-                hipLaunchKernelGGL(k_reduce_multi, dim3(j + 1), dim3(BLK), 0, s, grid->partials, nb, j + 1, h);
+                multi_dot(V, j + 1, w, h);
                 TP_TRY(allreduce_dev(h, j + 1, L.no_comm));
-                hipLaunchKernelGGL(k_multi_axpy, dim3(grid_for(n)), dim3(BLK), 0, s, V, nd, j + 1, h, w, off, n);
+                // the second pass also records alpha[j] = h1[j] + h2[j]
+                hipLaunchKernelGGL(k_multi_axpy, dim3(grid_for(n)), dim3(BLK), 0, s, V, nd, j + 1, h, w, off, n,
+                                   pass ? h1 : nullptr, al);
             }
-            hipLaunchKernelGGL(k_lanczos_alpha, dim3(1), dim3(64), 0, s, h1, h2, j, al);
-            hipLaunchKernelGGL(k_multi_dot, dim3(nb, 1), dim3(BLK), 0, s, w, nd, 1, w, off, n, grid->partials);
-            hipLaunchKernelGGL(k_reduce_multi, dim3(1), dim3(BLK), 0, s, grid->partials, nb, 1, bb);
+            multi_dot(w, 1, w, bb);
             TP_TRY(allreduce_dev(bb, 1, L.no_comm));
             hipLaunchKernelGGL(k_lanczos_next, dim3(grid_for(n)), dim3(BLK), 0, s, w, bb, j, be, V + (size_t)(j + 1) * nd,
                                off, n);
-            grid->launches += 12;
+            grid->launches += nb == 1 ? 9 : 12;
             m++;
         }
         double hc[520];
         TP_HIP(hipMemcpyAsync(hc, coef, sizeof(hc), hipMemcpyDeviceToHost, s));
         TP_HIP(hipStreamSynchronize(s));
-        (void)hipFree(V);
-        (void)hipFree(coef);
         const double *ha = hc + 258, *hb = hc + 386;
         for (int j = 0; j < m; j++)  // breakdown (invariant subspace): truncate like the CPU path
             if (!(hb[j] > 1e-14 * fabs(ha[j]))) {
