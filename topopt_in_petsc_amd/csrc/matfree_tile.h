@@ -257,7 +257,7 @@ struct TileArgs {
 //   matrix dK_E whose action k_macro_corr precomputes into `corr`.
 template <int EPI, int MACRO>
 __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(TileArgs t, NodeArgs a) {
-    __shared__ double s_u[3][STG_N];          // node-plane ring: bottom, top, next
+    __shared__ double s_u[3][4 * TILE * TILE];  // node-plane ring: bottom, top, next (STG_N used, padded: unconditional stores)
     __shared__ double s_y[2][TILE * TILE * 3];  // y-combination, double buffered -> one barrier per step
     // fine-level CHEB streams 4 node vectors instead of 6: the Jacobi diagonal is rebuilt from the moduli (KE[c][c] * sum
     // of the 8 adjacent E, combined in x/y/z like the operator itself), and the recurrence runs in its 3-term form
@@ -287,47 +287,52 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
     const bool node_ok = tx >= 1 && ty >= 1 && ei < t.nx && ej < t.ny;
     const long plane = (long)t.nx * t.ny;
     const double *__restrict__ x = a.x;
+    const unsigned eoff = elem_ok ? (unsigned)(ei + t.ex * ej) : 0u;  // always a valid element column
+    const double emul = elem_ok ? 1.0 : 0.0;
 
-    // ---- staging slots of this thread: flat index f -> (row, node column, component)
-    int st_off[4];        // offset inside a node plane (doubles), -1 = outside the domain
+    // ---- staging slots of this thread: flat index f -> (row, node column, component).
+    // Branch-free hot path: every slot holds a VALID offset (columns outside the domain are clamped onto the
+    // boundary column; their values only reach elements outside the domain, whose modulus is 0), the fourth slot
+    // of the threads beyond STG_N duplicates the last entry into LDS padding, and the Dirichlet mask is only
+    // consulted in tiles that contain a clamped column at all (workgroup-uniform flag).
+    unsigned st_off[4];   // offset inside a node plane (doubles)
     unsigned st_cm = 0;   // bit s set: slot s belongs to a column with a clamped dof somewhere
+    const long ncol = node_ok ? (long)ei + (long)t.nx * ej : 0;   // own output node column
+    const unsigned own_cm = (node_ok && t.colmask) ? t.colmask[ncol] : 0u;
 #pragma unroll
     for (int s = 0; s < 4; s++) {
-        const int f = tid + s * TILE * TILE;
-        st_off[s] = -1;
-        if (f < STG_N) {
-            const int r = f / (TSTG * 3), c = f % (TSTG * 3);
-            const int gi = bx - 1 + c / 3, gj = by - 1 + r;
-            if (gi >= 0 && gi < t.nx && gj >= 0 && gj < t.ny) {
-                st_off[s] = 3 * (gi + t.nx * gj) + c % 3;
-                if (t.colmask && ((t.colmask[gi + t.nx * gj] >> (c % 3)) & 1u)) st_cm |= 1u << s;
-            }
-        }
+        const int f = min(tid + s * TILE * TILE, STG_N - 1);
+        const int r = f / (TSTG * 3), c = f % (TSTG * 3);
+        const int gi0 = bx - 1 + c / 3, gj0 = by - 1 + r;
+        const int gi = min(max(gi0, 0), t.nx - 1), gj = min(max(gj0, 0), t.ny - 1);
+        st_off[s] = 3u * (unsigned)(gi + t.nx * gj) + (unsigned)(c % 3);
+        if (t.colmask && gi == gi0 && gj == gj0 && ((t.colmask[gi + t.nx * gj] >> (c % 3)) & 1u)) st_cm |= 1u << s;
     }
+    const bool tile_masked = t.colmask ? (__syncthreads_or((st_cm | own_cm) != 0u) != 0) : false;
     auto load_plane = [&](int p, double v[4]) {
-        const bool pok = p >= 0 && p < t.nzl;
+        if (p < 0 || p >= t.nzl) {  // uniform
+#pragma unroll
+            for (int s = 0; s < 4; s++) v[s] = 0.0;
+            return;
+        }
         const double *__restrict__ xp = x + 3 * plane * p;
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-            double w = 0.0;
-            if (pok && st_off[s] >= 0) {
-                w = xp[st_off[s]];
-                if ((st_cm >> s) & 1u) {  // rare: only columns that carry a Dirichlet condition
-                    if ((t.mask[plane * p + st_off[s] / 3] >> (st_off[s] % 3)) & 1u) w = 0.0;
+        for (int s = 0; s < 4; s++) v[s] = xp[st_off[s]];
+        if (tile_masked) {  // uniform, rare
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+                if ((st_cm >> s) & 1u) {
+                    if ((t.mask[plane * p + st_off[s] / 3u] >> (st_off[s] % 3u)) & 1u) v[s] = 0.0;
                 }
-            }
-            v[s] = w;
         }
     };
     auto store_plane = [&](int buf, const double v[4]) {
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-            const int f = tid + s * TILE * TILE;
-            if (f < STG_N) s_u[buf][f] = v[s];
-        }
+        for (int s = 0; s < 4; s++) s_u[buf][tid + s * TILE * TILE] = v[s];
     };
     // the 4 in-plane nodes of this thread's element, natural order (lx + 2 ly), 2-D transformed
     const int o00 = (ty * TSTG + tx) * 3, o10 = o00 + 3, o01 = o00 + TSTG * 3, o11 = o01 + 3;
+    double pre[4] = {0, 0, 0, 0};
     auto read_plane_wht = [&](int buf, double U[3][4]) {
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -339,11 +344,7 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
         }
     };
 
-    // own output node column: epilogue operands are prefetched one step ahead
-    const long ncol = node_ok ? (long)ei + (long)t.nx * ej : 0;
-    const unsigned own_cm = (node_ok && t.colmask) ? t.colmask[ncol] : 0u;
 
-    double pre[4];
     {   // all three planes in flight at once: one memory round trip instead of three
         double p0[4], p1[4];
         load_plane(kz0 - 1, p0);
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
         const int b0 = s % 3, b1 = (s + 1) % 3;  // ring slots of the bottom / top plane of this step
         if (more) load_plane(el + 3, pre);      // lands in slot b0 once this step is done with it
         double Ee = 0.0;
-        if (!MACRO && elem_ok && el >= 0 && el < t.ezl) Ee = t.E[(long)ei + (long)t.ex * (ej + (long)t.ey * el)];
+        if (!MACRO && el >= 0 && el < t.ezl) Ee = t.E[(long)t.ex * t.ey * el + eoff] * emul;  // uniform branch
         const long nq = 3 * (ncol + plane * el);
         double xo[3] = {0, 0, 0}, bo[3] = {0, 0, 0}, dd[3] = {0, 0, 0}, di[3] = {0, 0, 0}, co[3] = {0, 0, 0};
         if (outp) {
@@ -393,7 +394,8 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
             for (int c = 0; c < 3; c++) {
                 // own input value: the staged (masked) copy in LDS is exact unless the column carries a
                 // Dirichlet condition (rare) -> no second trip to memory for x
-                if (EPI != EPI_RESID || own_cm) xo[c] = own_cm ? x[nq + c] : s_u[b0][o00 + c];
+                xo[c] = s_u[b0][o00 + c];
+                if (tile_masked && own_cm) xo[c] = x[nq + c];
                 if (EPI == EPI_RESID || EPI == EPI_CHEB) bo[c] = a.b[nq + c];
                 if (EPI == EPI_CHEB) {
                     if (!DIAG_FLY) {
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
         if (DIAG_FLY && node_ok) e4 = ex2 + s_e[s & 1][tid - TILE];
         if (outp) {
             unsigned m = 0;
-            if (own_cm) m = t.mask[ncol + plane * el];
+            if (tile_masked && own_cm) m = t.mask[ncol + plane * el];
             if (DIAG_FLY) {
                 const double rinv = 1.0 / (e4 + Elow);
 #pragma unroll

@@ -349,7 +349,12 @@ struct MGSolver {
             const int planes = L.g.own_hi - L.g.own_lo + 1;
             static const int kz_env = getenv("TP_TILE_KZ") ? atoi(getenv("TP_TILE_KZ")) : 0;
             int kz = kz_env > 0 ? kz_env : (int)((long)planes * tx * ty / 5120);  // ~5k workgroups
-            kz = kz < 8 ? 8 : (kz > 32 ? 32 : kz);
+            if (kz_env <= 0) {
+                kz = kz < 8 ? 8 : (kz > 32 ? 32 : kz);
+                // small grids: shorter chunks until the 768 workgroup slots of the chip are filled once
+                if ((long)tx * ty * ((planes + 7) / 8) < 768) kz = (int)((long)planes * tx * ty / 768);
+                if (kz < 4) kz = 4;
+            }
             if (kz > planes) kz = planes;
             const int tz = (planes + kz - 1) / kz;
             last_nblocks = tx * ty * tz;
