@@ -203,7 +203,7 @@ def main():
                                "filtered synthetic density seed 12345" % (a.workload, ex, ey, ez, ndof, world, nlv, a.nsmooth, a.ncoarse, a.rtol,
                                                                          "Lanczos(10)" if a.fine_eig else "element bound"),
                    "n_dof": ndof, "cg_its": info.get("its"), "rel_residual": info.get("rel_res"), "fx": info.get("fx"),
-                   "parallelism": "zslab%d" % world, "kernel_launches_per_step": launches / max(a.steps, 1),
+                   "parallelism": "zslab%d" % world, "comm": grid.comm_kind, "kernel_launches_per_step": launches / max(a.steps, 1),
                    "alg_GB_per_step": alg_bytes / max(a.steps, 1) / 1e9,
                    "hot_path_alg_GBps": alg_bytes / dt / 1e9},
         "roofline": roofline,

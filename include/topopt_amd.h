@@ -99,6 +99,21 @@ long tp_grid_owned_nodes(const tp_grid *g);
 int tp_grid_node_z0(const tp_grid *g);          /* global z index of local node plane 0 */
 int tp_grid_elem_z0(const tp_grid *g);          /* global z index of local element layer 0 */
 
+/* ---- optional: the slab exchange issued directly to RCCL -------------------------------------
+ * The reference exchanges ghost layers with MPI inside PETSc (DMGlobalToLocal, VecDot; e.g.
+ * LinearElasticity.cc:249-250).  By default the library calls the tp_comm hooks of the host framework; on one
+ * node it can instead issue grouped ncclSend/ncclRecv, ncclAllReduce and ncclAllGather itself on the solver's
+ * stream (xGMI, no host round trip per halo).  RCCL is not linked: pass the path of the librccl.so the process
+ * already uses.  tp_grid_use_rccl is collective over the ranks of the grid (rank 0 creates the id, the host
+ * broadcasts the 128 bytes); on failure the tp_comm hooks given at creation stay in place. */
+int tp_rccl_load(const char *librccl_path);
+int tp_rccl_unique_id(void *id128);
+int tp_grid_use_rccl(tp_grid *g, const void *id128);
+int tp_grid_comm_stats(const tp_grid *g, long *exchanges, long *reductions);   /* RCCL path only, else zeros */
+/* one-rank loop-back check of the RCCL call sequence (the rank is its own lower and upper neighbour):
+ * returns TP_OK and the largest deviation in *max_err */
+int tp_rccl_selftest(int device, void *stream, long n, double *max_err);
+
 /* ---- device memory helpers (for hosts without a GPU framework) ---------- */
 int tp_malloc(void **p, size_t bytes);
 int tp_free(void *p);

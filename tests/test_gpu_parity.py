@@ -331,3 +331,21 @@ def test_error_codes(tp):
     le2.SetUpLoadAndBC()
     le2.AssembleStiffnessMatrix(grid.elem_vec(0.5), 1e-9, 1.0, 3.0)
     assert le2.KSPSolve() == 2 and le2.last_rnorm > 1e-14 * le2.last_bnorm   # max_it reached: returns like KSP does
+
+
+@pytest.mark.gpu
+def test_rccl_call_sequence_loopback():
+    """The in-library RCCL exchange (csrc/rccl_comm.h) on a one-rank communicator whose rank is its own lower and
+    upper neighbour: grouped send/recv through the staging buffers and in place, all-reduce, all-gather."""
+    import ctypes as C
+    import os
+    import torch
+    from topopt_in_petsc_amd import lib
+    L = lib.load_library()
+    path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    assert os.path.exists(path)
+    assert L.tp_rccl_load(path.encode()) == 0
+    err = C.c_double(-1.0)
+    st = torch.cuda.current_stream().cuda_stream
+    assert L.tp_rccl_selftest(torch.cuda.current_device(), C.c_void_p(st), 150000, C.byref(err)) == 0
+    assert err.value == 0.0

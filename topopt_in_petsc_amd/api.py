@@ -7,6 +7,7 @@ vectors are 1-D float64 torch tensors on the GPU standing in for PETSc Vecs
 libtopopt_amd.so.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import torch
@@ -77,6 +78,33 @@ class Grid:
                                    self.stream.cuda_stream, comm_p)
         self.handle = C.c_void_p()
         _chk(self.L.tp_grid_create(C.byref(self.handle), C.byref(self._opts)), "tp_grid_create")
+        self.comm_kind = "none" if nranks == 1 else "torch.distributed hooks"
+        if nranks > 1 and self.comm.backend == "nccl" and os.environ.get("TP_COMM", "rccl") != "torch":
+            self._use_rccl(group)
+
+    def _use_rccl(self, group):
+        """Hand the slab exchange to RCCL inside the library (tp_grid_use_rccl): same RCCL instance as
+        torch.distributed's nccl backend, no Python round trip per halo.  Every rank takes the same decision."""
+        import torch.distributed as dist
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        ok = os.path.exists(path) and self.L.tp_rccl_load(path.encode()) == 0
+        idbuf = C.create_string_buffer(128)
+        if ok and self.part.rank == 0:
+            ok = self.L.tp_rccl_unique_id(idbuf) == 0
+        flag = torch.tensor([1 if ok else 0], device=self.device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag[0]) == 0:
+            return
+        obj = [idbuf.raw if self.part.rank == 0 else None]
+        src = 0 if group is None else dist.get_global_rank(group, 0)
+        dist.broadcast_object_list(obj, src=src, group=group)
+        idb = C.create_string_buffer(obj[0], 128)
+        rc = self.L.tp_grid_use_rccl(self.handle, idb)
+        flag = torch.tensor([1 if rc == 0 else 0], device=self.device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag[0]) == 0:
+            raise TopOptError(rc or 4, "tp_grid_use_rccl (some rank could not create its communicator)")
+        self.comm_kind = "rccl (in-library)"
 
     def __del__(self):
         if getattr(self, "handle", None):

@@ -8,6 +8,7 @@ struct tp_grid {
     hipStream_t stream;
     tp_comm comm;
     bool has_comm;
+    struct RcclComm *rccl = nullptr;  // set by tp_grid_use_rccl: the hooks above then point into it
     int ex, ey, ez_glob, ez_own;  // fine level element counts
     int rank, nranks;
     double *partials;   // [dev] MAX_RED_BLOCKS * 4

@@ -2,6 +2,7 @@
 // hot path.  gfx950 only; no CPU fallback anywhere in this library.
 #include "elements.h"
 #include "mg.h"
+#include "rccl_comm.h"
 
 // ===========================================================================
 // grid
@@ -41,9 +42,87 @@ extern "C" int tp_grid_create(tp_grid **out, const tp_grid_opts *o) {
     *out = g;
     return TP_OK;
 }
+extern "C" int tp_rccl_load(const char *path) { return rccl_load(path); }
+extern "C" int tp_rccl_unique_id(void *id128) {
+    if (!rccl_api().handle || !id128) return TP_ERR_STATE;
+    ncclUniqueId id;
+    if (rccl_api().GetUniqueId(&id) != ncclSuccess) return TP_ERR_COMM;
+    memcpy(id128, &id, sizeof(id));
+    return TP_OK;
+}
+extern "C" int tp_grid_use_rccl(tp_grid *g, const void *id128) {
+    if (!g || !id128 || !g->has_comm || g->rccl) return TP_ERR_ARG;
+    if (!rccl_api().handle) return TP_ERR_STATE;
+    RcclComm *c = nullptr;
+    const int rc = rccl_comm_create(&c, id128, g->rank, g->nranks, g->o.device, g->stream, g->comm.cap);
+    if (rc) return rc;
+    g->rccl = c;
+    g->comm = c->hooks;
+    return TP_OK;
+}
+extern "C" int tp_grid_comm_stats(const tp_grid *g, long *ex, long *red) {
+    if (!g) return TP_ERR_ARG;
+    if (ex) *ex = g->rccl ? g->rccl->n_exchanges : 0;
+    if (red) *red = g->rccl ? g->rccl->n_reductions : 0;
+    return TP_OK;
+}
+__global__ void k_selftest_fill(double *p, long n, double base) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = base + (double)i;
+}
+extern "C" int tp_rccl_selftest(int device, void *stream, long n, double *max_err) {
+    if (!rccl_api().handle || n < 1 || !max_err) return TP_ERR_STATE;
+    ncclUniqueId id;
+    if (rccl_api().GetUniqueId(&id) != ncclSuccess) return TP_ERR_COMM;
+    RcclComm *c = nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = rccl_comm_create(&c, &id, 0, 1, device, st, n < 16 ? 16 : n);
+    if (rc) return rc;
+    c->periodic = true;
+    tp_comm &h = c->hooks;
+    std::vector<double> a(n), b(n);
+    double err = 0.0;
+    // staged exchange: send_hi arrives in recv_lo, send_lo in recv_hi
+    hipLaunchKernelGGL(k_selftest_fill, dim3(64), dim3(256), 0, st, h.send_lo, n, 1000.0);
+    hipLaunchKernelGGL(k_selftest_fill, dim3(64), dim3(256), 0, st, h.send_hi, n, 5000.0);
+    rc = h.exchange(h.user, n);
+    if (!rc) {
+        (void)hipMemcpyAsync(a.data(), h.recv_lo, sizeof(double) * n, hipMemcpyDeviceToHost, st);
+        (void)hipMemcpyAsync(b.data(), h.recv_hi, sizeof(double) * n, hipMemcpyDeviceToHost, st);
+        (void)hipStreamSynchronize(st);
+        for (long i = 0; i < n; i++) err = fmax(err, fmax(fabs(a[i] - (5000.0 + i)), fabs(b[i] - (1000.0 + i))));
+        // in-place variant on other buffers (gather area as scratch: 1 rank -> cap doubles)
+        hipLaunchKernelGGL(k_selftest_fill, dim3(64), dim3(256), 0, st, h.recv_lo, n, 7000.0);
+        hipLaunchKernelGGL(k_selftest_fill, dim3(64), dim3(256), 0, st, h.recv_hi, n, 9000.0);
+        rc = h.exchange_direct(h.user, h.recv_lo, h.send_lo, h.recv_hi, h.send_hi, n);  // to_lo, from_lo, to_hi, from_hi
+    }
+    if (!rc) {
+        (void)hipMemcpyAsync(a.data(), h.send_lo, sizeof(double) * n, hipMemcpyDeviceToHost, st);  // from_lo <- to_hi
+        (void)hipMemcpyAsync(b.data(), h.send_hi, sizeof(double) * n, hipMemcpyDeviceToHost, st);  // from_hi <- to_lo
+        (void)hipStreamSynchronize(st);
+        for (long i = 0; i < n; i++) err = fmax(err, fmax(fabs(a[i] - (9000.0 + i)), fabs(b[i] - (7000.0 + i))));
+        hipLaunchKernelGGL(k_selftest_fill, dim3(1), dim3(64), 0, st, h.red, 16, 3.0);
+        rc = h.allreduce_sum(h.user, 16);
+    }
+    if (!rc) {
+        hipLaunchKernelGGL(k_selftest_fill, dim3(64), dim3(256), 0, st, h.send_lo, n, 11000.0);
+        rc = h.allgather(h.user, n);
+    }
+    if (!rc) {
+        double r16[16];
+        (void)hipMemcpyAsync(r16, h.red, sizeof(r16), hipMemcpyDeviceToHost, st);
+        (void)hipMemcpyAsync(a.data(), h.gather, sizeof(double) * n, hipMemcpyDeviceToHost, st);
+        (void)hipStreamSynchronize(st);
+        for (int i = 0; i < 16; i++) err = fmax(err, fabs(r16[i] - (3.0 + i)));
+        for (long i = 0; i < n; i++) err = fmax(err, fabs(a[i] - (11000.0 + i)));
+    }
+    rccl_comm_destroy(c);
+    *max_err = err;
+    return rc ? TP_ERR_COMM : TP_OK;
+}
 extern "C" int tp_grid_destroy(tp_grid *g) {
     if (!g) return TP_OK;
     (void)hipStreamSynchronize(g->stream);
+    rccl_comm_destroy(g->rccl);
     (void)hipFree(g->partials);
     (void)hipFree(g->scal);
     (void)hipHostFree(g->h_scal);

@@ -52,6 +52,11 @@ _vp, _i, _d, _l = C.c_void_p, C.c_int, C.c_double, C.c_long
 SYMBOLS = {
     "tp_grid_create": (_i, [C.POINTER(_vp), C.POINTER(GridOpts)]),
     "tp_grid_destroy": (_i, [_vp]),
+    "tp_rccl_load": (_i, [C.c_char_p]),
+    "tp_rccl_unique_id": (_i, [_vp]),
+    "tp_grid_use_rccl": (_i, [_vp, _vp]),
+    "tp_grid_comm_stats": (_i, [_vp, C.POINTER(_l), C.POINTER(_l)]),
+    "tp_rccl_selftest": (_i, [_i, _vp, _l, C.POINTER(_d)]),
     "tp_grid_local_nodes": (_l, [_vp]),
     "tp_grid_local_elems": (_l, [_vp]),
     "tp_grid_owned_node_offset": (_l, [_vp]),
