@@ -382,20 +382,17 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
         const int el = kz0 - 1 + s;  // element layer; bottom node plane el, top plane el+1
         const bool more = s + 1 < nsteps;
         const bool outp = s >= 1 && node_ok;
-        // ---- issue the long-latency loads of this step first
+        // ---- issue the long-latency loads of this step first, in the order in which they are consumed (the
+        // vector-memory counter retires in order): modulus (needed after the block products), epilogue operands
+        // (after the barrier), next plane (end of the step)
         const int b0 = s % 3, b1 = (s + 1) % 3;  // ring slots of the bottom / top plane of this step
-        if (more) load_plane(el + 3, pre);      // lands in slot b0 once this step is done with it
-        double Ee = 0.0;
-        if (!MACRO && el >= 0 && el < t.ezl) Ee = t.E[(long)t.ex * t.ey * el + eoff] * emul;  // uniform branch
+        double Eraw = 0.0;
+        if (!MACRO && el >= 0 && el < t.ezl) Eraw = t.E[(long)t.ex * t.ey * el + eoff];  // uniform branch
         const long nq = 3 * (ncol + plane * el);
         double xo[3] = {0, 0, 0}, bo[3] = {0, 0, 0}, dd[3] = {0, 0, 0}, di[3] = {0, 0, 0}, co[3] = {0, 0, 0};
         if (outp) {
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                // own input value: the staged (masked) copy in LDS is exact unless the column carries a
-                // Dirichlet condition (rare) -> no second trip to memory for x
-                xo[c] = s_u[b0][o00 + c];
-                if (tile_masked && own_cm) xo[c] = x[nq + c];
                 if (EPI == EPI_RESID || EPI == EPI_CHEB) bo[c] = a.b[nq + c];
                 if (EPI == EPI_CHEB) {
                     if (!DIAG_FLY) {
@@ -409,6 +406,16 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
                 if (MACRO && t.corr) co[c] = t.corr[nq + c];
             }
         }
+        if (more) load_plane(el + 3, pre);      // lands in slot b0 once this step is done with it
+        if (outp) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                // own input value: the staged (masked) copy in LDS is exact unless the column carries a
+                // Dirichlet condition (rare) -> no second trip to memory for x
+                xo[c] = s_u[b0][o00 + c];
+                if (tile_masked && own_cm) xo[c] = x[nq + c];
+            }
+        }
         // ---- element in the Walsh-Hadamard basis
         double Ut[3][4], u[3][8], f[3][8];
         read_plane_wht(b1, Ut);
@@ -420,11 +427,14 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
                 u[c][m + 4] = Ub[c][m] - Ut[c][m];
                 Ub[c][m] = Ut[c][m];
             }
-        // opaque offset: keeps the 33 scalar loads inside the loop instead of 66 live SGPRs
+        // opaque offset: keeps the 33 scalar loads inside the loop instead of 66 live SGPRs (hoisting them to the
+        // top of the step measured no gain: the compiler spills the SGPRs to lanes)
         int boff;
         asm volatile("s_mov_b32 %0, %1" : "=s"(boff) : "s"(t.slot_off));
+        double Ee = 0.0;
         if (!MACRO) {
             sym_ke_blocks(c_symB + boff, u, f);
+            Ee = Eraw * emul;
         } else {
             const bool eok = elem_ok && el >= 0 && el < t.ezl;
             Ee = eok ? 1.0 : 0.0;  // children moduli are applied inside
