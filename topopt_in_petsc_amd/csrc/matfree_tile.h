@@ -129,7 +129,7 @@ static_assert(SYMKE_N + 3 <= SYMKE_STRIDE, "stride");
 __constant__ double c_symB[SYMKE_SLOTS * SYMKE_STRIDE];
 
 // level-1 operator constants (MACG_N packed values of G_sigma, macro_pattern.h), same slot numbering
-constexpr int MACG_STRIDE = 280;
+constexpr int MACG_STRIDE = 80;
 static_assert(MACG_N <= MACG_STRIDE, "stride");
 __constant__ double c_macG[SYMKE_SLOTS * MACG_STRIDE];
 
@@ -157,15 +157,22 @@ inline double make_macro_tensor(const double *M, double *out) {
                         G[sg][3 * p + r][3 * p2 + s] = acc / 512.0;
                         maxabs = fmax(maxabs, fabs(acc / 512.0));
                     }
-    for (int k = 0; k < MACG_N; k++) {
-        double &g = G[MACG_SIG[k]][MACG_ROW[k]][MACG_COL[k]];
-        out[k] = g;
-        g = 0.0;
+    double asym = 0.0;
+    for (int c = 0; c < MACG_N; c++) {  // class representatives
+        const int k = MACG_REP[c];
+        out[c] = G[MACG_M_SIG[k]][MACG_M_ROW[k]][MACG_M_COL[k]];
+    }
+    for (int k = 0; k < MACG_M; k++) {  // every listed entry (and its mirror image) must be +-its class constant
+        double &g = G[MACG_M_SIG[k]][MACG_M_ROW[k]][MACG_M_COL[k]], &gt = G[MACG_M_SIG[k]][MACG_M_COL[k]][MACG_M_ROW[k]];
+        const double ref = MACG_M_SGN[k] * out[MACG_M_CLS[k]];
+        asym = fmax(asym, fmax(fabs(g - ref), fabs(gt - ref)));
+        g = gt = 0.0;
     }
     double dropped = 0.0;
     for (int sg = 0; sg < 8; sg++)
         for (int i = 0; i < 24; i++)
             for (int j = 0; j < 24; j++) dropped = fmax(dropped, fabs(G[sg][i][j]));
+    dropped = fmax(dropped, asym);
     return maxabs > 0 ? dropped / maxabs : 0.0;
 }
 inline int macro_slot_upload(int slot, const double *vals) {
@@ -249,8 +256,9 @@ struct TileArgs {
 //   child moduli, K_E = sum_c E_c W_c^T KE W_c, and the child matrices are reflections of each other.  In the
 //   Walsh-Hadamard basis of the 8 corners AND of the 8 children
 //       y = T^T [ sum_sigma ehat_sigma G_sigma ] T u,      ehat = H8 E_children,
-//   with constant G_sigma that couple mode class q only to q ^ sigma: 279 structurally non-zero values in total
-//   (macro_pattern.h, generated) instead of 8 dense child products -> ~430 fma per coarse element.  Bytes per
+//   with constant SYMMETRIC G_sigma that couple mode class q only to q ^ sigma: 279 structurally non-zero entries,
+//   150 in the upper triangles, 78 distinct constants for any box (macro_pattern.h, generated: entries that are
+//   equal up to sign share one scalar load; per entry one scaling by ehat and two fma) instead of 8 dense child products -> ~430 FP64 ops per coarse element.  Bytes per
 //   apply drop from 1944 B per coarse node (stored stencil) to the 8 child densities.
 //   This kernel applies the operator WITHOUT Dirichlet conditions; the (few) coarse
 //   elements that contain a clamped fine node differ from it by a stored 24x24
