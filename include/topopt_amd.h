@@ -165,6 +165,8 @@ int tp_elasticity_solve(tp_elasticity *e, const double *RHS, double *U, int *its
 int tp_elasticity_objective(tp_elasticity *e, const double *U, const double *xPhys, double Emin, double Emax,
                             double penal, double volfrac, double *fx, double *gx, double *dfdx, double *dgdx);
 /* introspection for parity tests */
+/* KSPSetTolerances (LinearElasticity.cc:646); a negative value keeps the current one (PETSC_DEFAULT) */
+int tp_elasticity_set_tolerances(tp_elasticity *le, double rtol, double atol, double dtol, int max_it);
 int tp_elasticity_level_count(const tp_elasticity *e);
 long tp_elasticity_level_nodes(const tp_elasticity *e, int level);
 double tp_elasticity_level_lambda(const tp_elasticity *e, int level);
@@ -183,6 +185,8 @@ typedef struct tp_filter tp_filter;
 /* Filter::Filter + SetUp (Filter.cc:25-38, :290-463).  filterType 0 = sensitivity,
  * 1 = density, 2 = PDE (Helmholtz), other = none; rmin is an absolute length. */
 int tp_filter_create(tp_filter **f, tp_grid *g, int filterType, double rmin, const tp_solver_opts *pde_opts);
+/* y = H x, the un-normalised cone filter: MatMult(H, x, y) of Filter.cc:68, :173, :181 (types 0, 1) */
+int tp_filter_mult_h(tp_filter *f, const double *x, double *y);
 int tp_filter_destroy(tp_filter *f);
 int tp_filter_stencil_width(const tp_filter *f);        /* ElemConn, Filter.cc:326 */
 int tp_filter_get_hs(tp_filter *f, double *Hs);          /* [dev, own elements] */
@@ -219,6 +223,11 @@ int tp_mma_restart_set(tp_mma *mma, int k, const double *xo1, const double *xo2,
 /* ---- streaming helpers used by the driver (main.cc:68-73, TopOpt.cc) ----- */
 int tp_vec_scale(tp_grid *g, double *x, double a, long n);
 int tp_vec_set(tp_grid *g, double *x, double a, long n);
+/* BLAS-1 surface behind the PETSc-named adapter (petsc_shim.h): VecAXPY/VecAXPBY, VecPointwiseMult/Divide,
+ * VecDot/VecSum (n = the caller's OWNED range; the result is summed over the ranks of the grid) */
+int tp_vec_axpby(tp_grid *g, double *y, double a, const double *x, double b, long n);
+int tp_vec_pointwise(tp_grid *g, double *w, const double *x, const double *y, int divide, long n);
+int tp_vec_dot(tp_grid *g, const double *x, const double *y /* NULL: sum of x */, long n, double *out);
 /* synthetic density of SURVEY.md 8(d), indexed by GLOBAL element id */
 int tp_synth_density(tp_grid *g, double *x, uint64_t seed);
 

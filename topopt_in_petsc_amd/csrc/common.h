@@ -125,6 +125,14 @@ __global__ __launch_bounds__(BLK) void k_pw_mult(double *__restrict__ y, const d
     for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) y[i] = x[i] * z[i];
 }
 // partial dot products: partials[0*nb+b] = sum a*b
+// y = a x + b y ;  w = x (.*|./) y
+__global__ __launch_bounds__(BLK) void k_axpby(double *__restrict__ y, double a, const double *__restrict__ x, double b, long n) {
+    for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) y[i] = a * x[i] + b * y[i];
+}
+__global__ __launch_bounds__(BLK) void k_pw_div(double *__restrict__ w, const double *__restrict__ x,
+                                                const double *__restrict__ y, long n) {
+    for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) w[i] = x[i] / y[i];
+}
 __global__ __launch_bounds__(BLK) void k_dot(const double *__restrict__ a, const double *__restrict__ b, long n,
                                              double *__restrict__ partials) {
     double s = 0.0;

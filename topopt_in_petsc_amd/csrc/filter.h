@@ -168,6 +168,12 @@ static int pde_apply(tp_filter *f, const double *in, double *out) {
     return TP_OK;
 }
 
+// y = H x, the un-normalised cone filter (MatMult(H, x, y) of Filter.cc:68, :173, :181); types 0 and 1
+extern "C" int tp_filter_mult_h(tp_filter *f, const double *x, double *y) {
+    if (!f || !x || !y || f->type > 1) return TP_ERR_ARG;
+    TP_TRY(filter_fill(f, x, nullptr, 0));
+    return filter_conv(f, y, nullptr, nullptr);
+}
 extern "C" int tp_filter_create(tp_filter **out, tp_grid *g, int filterType, double rmin, const tp_solver_opts *po) {
     if (!out || !g) return TP_ERR_ARG;
     tp_filter *f = new tp_filter();

@@ -164,6 +164,26 @@ extern "C" int tp_vec_scale(tp_grid *g, double *x, double a, long n) {
     count_launch(g, 16.0 * n, 1.0 * n);
     return TP_OK;
 }
+// BLAS-1 surface of the PETSc-named adapter (include/petsc_shim.h): Vec operations of LinearElasticity.cc / Filter.cc
+extern "C" int tp_vec_axpby(tp_grid *g, double *y, double a, const double *x, double b, long n) {
+    hipLaunchKernelGGL(k_axpby, dim3(grid_for(n)), dim3(BLK), 0, g->stream, y, a, x, b, n);
+    count_launch(g, 24.0 * n, 3.0 * n);
+    return TP_OK;
+}
+extern "C" int tp_vec_pointwise(tp_grid *g, double *w, const double *x, const double *y, int divide, long n) {
+    if (divide)
+        hipLaunchKernelGGL(k_pw_div, dim3(grid_for(n)), dim3(BLK), 0, g->stream, w, x, y, n);
+    else
+        hipLaunchKernelGGL(k_pw_mult, dim3(grid_for(n)), dim3(BLK), 0, g->stream, w, x, y, n);
+    count_launch(g, 24.0 * n, 1.0 * n);
+    return TP_OK;
+}
+// sum over ranks of x.y (y = NULL: of x) over n local entries -- the caller passes OWNED ranges only
+extern "C" int tp_vec_dot(tp_grid *g, const double *x, const double *y, long n, double *out) {
+    if (!g || !x || !out) return TP_ERR_ARG;
+    TP_TRY(y ? dot_to_slot(g, x, y, n, S_TMP) : sum_to_slot(g, x, n, S_TMP));
+    return read_scal(g, S_TMP, 1, out);
+}
 extern "C" int tp_vec_set(tp_grid *g, double *x, double a, long n) {
     hipLaunchKernelGGL(k_set, dim3(grid_for(n)), dim3(BLK), 0, g->stream, x, a, n);
     count_launch(g, 8.0 * n, 0.0);
@@ -601,6 +621,14 @@ extern "C" int tp_elasticity_objective(tp_elasticity *e, const double *U, const 
     return TP_OK;
 }
 
+extern "C" int tp_elasticity_set_tolerances(tp_elasticity *e, double rtol, double atol, double dtol, int max_it) {
+    if (!e) return TP_ERR_ARG;   // KSPSetTolerances (LinearElasticity.cc:646); negative = keep (PETSC_DEFAULT)
+    if (rtol >= 0) e->mg.opt.rtol = rtol;
+    if (atol >= 0) e->mg.opt.atol = atol;
+    if (dtol >= 0) e->mg.opt.dtol = dtol;
+    if (max_it >= 0) e->mg.opt.max_it = max_it;
+    return TP_OK;
+}
 extern "C" int tp_elasticity_level_count(const tp_elasticity *e) { return e->mg.nlv; }
 extern "C" long tp_elasticity_level_nodes(const tp_elasticity *e, int l) { return e->mg.lv[l].g.nodes(); }
 extern "C" double tp_elasticity_level_lambda(const tp_elasticity *e, int l) { return e->mg.lv[l].lam; }

@@ -102,6 +102,11 @@ SYMBOLS = {
     "tp_mma_update": (_i, [_vp, _vp, _vp, C.POINTER(_d), C.POINTER(_vp), _vp, _vp, C.POINTER(_i)]),
     "tp_mma_design_change": (_i, [_vp, _vp, _vp, C.POINTER(_d)]),
     "tp_mma_get_state": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_i)]),
+    "tp_vec_axpby": (_i, [_vp, _vp, _d, _vp, _d, _l]),
+    "tp_vec_pointwise": (_i, [_vp, _vp, _vp, _vp, _i, _l]),
+    "tp_vec_dot": (_i, [_vp, _vp, _vp, _l, C.POINTER(_d)]),
+    "tp_elasticity_set_tolerances": (_i, [_vp, _d, _d, _d, _i]),
+    "tp_filter_mult_h": (_i, [_vp, _vp, _vp]),
     "tp_mma_restart_get": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "tp_mma_restart_set": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "tp_vec_scale": (_i, [_vp, _vp, _d, _l]),
