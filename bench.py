@@ -27,6 +27,8 @@ WORKLOADS = {
     "c2": (128, 64, 64, 3),                # configs[1]
     "c1": (48, 24, 24, 4),                 # configs[0]
     "cube256": (256, 256, 256, 4),         # north-star SpMV target mesh
+    "c3": (256, 128, 128, 4),              # configs[2] on ONE GPU (12.8 M DOF); with --gpus 8: 256x128x(128*8)
+    "c4": (192, 64, 64, 3, 2, "mbb"),      # configs[3]: MBB beam, Helmholtz (PDE) filter
     "tiny": (32, 16, 16, 3),
 }
 
@@ -99,15 +101,16 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    ex, ey, ezg, nlv = WORKLOADS[a.workload]
+    ex, ey, ezg, nlv = WORKLOADS[a.workload][:4]
+    ftype, bc = (WORKLOADS[a.workload] + (1, "cantilever"))[4:6]
     nlv = a.nlvls or nlv
     ez = ezg * world  # weak scaling: fixed slab per GPU
     nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
     ndof = 3 * nx * ny * nz
     grid = tp.Grid(nx, ny, nz, h, rank=rank, nranks=world)
     le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=nlv, rtol=a.rtol, fine_eig=a.fine_eig, ncoarse=a.ncoarse, nsmooth=a.nsmooth))
-    flt = tp.Filter(grid, 1, 2.56 * h)
-    le.SetUpLoadAndBC()
+    flt = tp.Filter(grid, ftype, 2.56 * h)
+    le.SetUpLoadAndBC_MBB() if bc == "mbb" else le.SetUpLoadAndBC()
     x = grid.synth_density(12345)
     xt, xp, df, dg = grid.elem_vec(), grid.elem_vec(), grid.elem_vec(), grid.elem_vec()
     Emin, Emax, penal, volfrac = 1e-9, 1.0, 3.0, 0.12
@@ -198,9 +201,10 @@ def main():
         "value": ndof / t_step, "unit": "DOF-updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": t_step * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "%s: cantilever %dx%dx%d elements (%d DOF), z-slabs over %d GPU(s), rmin=2.56h density "
+        "config": {"workload": "%s: %s %dx%dx%d elements (%d DOF), z-slabs over %d GPU(s), rmin=2.56h %s "
                                "filter, CG + %d-level GMG (Chebyshev(%d)-Jacobi, coarse Chebyshev(%d), Galerkin), rtol %g, fine-level eig %s, cold start, "
-                               "filtered synthetic density seed 12345" % (a.workload, ex, ey, ez, ndof, world, nlv, a.nsmooth, a.ncoarse, a.rtol,
+                               "filtered synthetic density seed 12345" % (a.workload, "MBB beam" if bc == "mbb" else "cantilever", ex, ey, ez, ndof, world,
+                                                                         "Helmholtz (PDE)" if ftype == 2 else "density", nlv, a.nsmooth, a.ncoarse, a.rtol,
                                                                          "Lanczos(10)" if a.fine_eig else "element bound"),
                    "n_dof": ndof, "cg_its": info.get("its"), "rel_residual": info.get("rel_res"), "fx": info.get("fx"),
                    "parallelism": "zslab%d" % world, "comm": grid.comm_kind, "kernel_launches_per_step": launches / max(a.steps, 1),

@@ -349,3 +349,31 @@ def test_rccl_call_sequence_loopback():
     st = torch.cuda.current_stream().cuda_stream
     assert L.tp_rccl_selftest(torch.cuda.current_device(), C.c_void_p(st), 150000, C.byref(err)) == 0
     assert err.value == 0.0
+
+
+@pytest.mark.gpu
+def test_mbb_load_case_componentwise_masks(tp, orc):
+    """Dirichlet conditions on single components (symmetry plane, roller edge): the Galerkin levels, the level-1
+    correction for partially clamped elements and the solve against the oracle with the same N and RHS"""
+    ex, ey, ez, nlv = 24, 8, 8, 3
+    nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
+    grid = tp.Grid(nx, ny, nz, h)
+    le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=nlv, rtol=1e-9))
+    le.SetUpLoadAndBC_MBB()
+    N, R = host(le.N), host(le.RHS)
+    assert N.sum() == N.size - ny * nz - ny - 1 and np.isclose(R.sum(), -0.001 * (ny - 1))
+    x = orc.synth_density(ex, ey, ez, h)
+    KE = orc.hex8_ke_box(h, h, h, 0.3)
+    mg = orc.MG(nx, ny, nz, 3, nlv)
+    mg.assemble(KE, orc.simp(x), N)
+    le.AssembleStiffnessMatrix(dev(x), 1e-9, 1.0, 3.0)
+    u = np.random.default_rng(3).standard_normal(mg.n)
+    for l in range(nlv):
+        ul = u[: mg.size(l)]
+        assert rel(host(le.level_apply(l, dev(ul))), mg.apply(l, ul)) <= 1e-13
+    its = le.KSPSolve(hist_cap=300)
+    Uo, its_o, hist_o = mg.solve(R * N, rtol=1e-9, maxit=300)
+    assert its == its_o
+    assert rel(host(le.U), Uo) <= 1e-8
+    k = min(10, its)
+    assert np.abs(le.last_hist[:k] / hist_o[:k] - 1).max() <= 1e-9

@@ -165,6 +165,26 @@ class LinearElasticity:
         """cantilever load case, LinearElasticity.cc:143-171"""
         _chk(self.L.tp_elasticity_cantilever(self.handle, _ptr(self.N), _ptr(self.RHS)), "tp_elasticity_cantilever")
 
+    def SetUpLoadAndBC_MBB(self, load=-0.001):
+        """Half MBB beam (BASELINE config 4; SURVEY D5: the reference ships only the cantilever, so this load case is
+        data defined by the build): symmetry plane x = xmin (u_x = 0), roller along the edge x = xmax, z = zmin
+        (u_z = 0, one node also u_y = 0), line load in -z along the edge x = xmin, z = zmax with half loads at the
+        two end nodes.  Single rank or z-slabs (global z index decides)."""
+        p = self.grid.part
+        nx, ny, nzl = p.nx, p.ny, p.nz_local
+        N = torch.ones(nzl, ny, nx, 3, dtype=torch.float64)
+        R = torch.zeros(nzl, ny, nx, 3, dtype=torch.float64)
+        kz = torch.arange(nzl) + p.node_z0
+        N[:, :, 0, 0] = 0.0
+        bot, top = kz == 0, kz == p.nz - 1
+        N[bot, :, nx - 1, 2] = 0.0
+        if bool(bot.any()):
+            N[int(torch.nonzero(bot)[0]), 0, nx - 1, 1] = 0.0
+        R[top, :, 0, 2] = load
+        R[top, 0, 0, 2] = 0.5 * load
+        R[top, ny - 1, 0, 2] = 0.5 * load
+        self.SetBC(N.reshape(-1).to(self.U.device), R.reshape(-1).to(self.U.device))
+
     def SetBC(self, N, RHS):
         self.N.copy_(N)
         self.RHS.copy_(RHS)
