@@ -215,8 +215,16 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.cpu_sample, a.rtol, a.fine_eig)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        # orderly teardown: solver objects (and the library's own RCCL communicator) go before the process group,
+        # on all ranks together
+        import gc
+        torch.cuda.synchronize()
+        dist.barrier()
+        le = flt = grid = None
+        gc.collect()
+        dist.barrier()
         dist.destroy_process_group()
 
 
