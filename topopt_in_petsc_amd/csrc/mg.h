@@ -402,7 +402,11 @@ struct MGSolver {
                 hipLaunchKernelGGL((k_dia_row_split<DOF, EPI, 9>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
             } else if (split == 3) {
                 nbr = (int)((nown * DOF + BLK / 3 - 1) / (BLK / 3));
-                hipLaunchKernelGGL((k_dia_row_split<DOF, EPI, 3>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
+                static const bool sym = getenv("TP_NO_DIA_SYM") == nullptr;
+                if (sym)
+                    hipLaunchKernelGGL((k_dia_row_split<DOF, EPI, 3, true>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
+                else
+                    hipLaunchKernelGGL((k_dia_row_split<DOF, EPI, 3>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
             } else {
                 hipLaunchKernelGGL((k_dia_row<DOF, EPI>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
             }

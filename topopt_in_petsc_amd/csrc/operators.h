@@ -317,14 +317,21 @@ __global__ __launch_bounds__(BLK) void k_dia_row(DiaOp<DOF> op, NodeArgs a) {
 // The same operator for the SMALLEST levels (17^3 nodes: 58 workgroups of rows would leave 3/4 of the chip idle and
 // queue 162 loads per thread behind one CU's address unit): a row is split over SPLIT threads -- by z-offset (3) or
 // (z, y)-offset (9) of the neighbour -- whose partial sums meet in LDS in a fixed order.
-template <int DOF, int EPI, int SPLIT>
+// SYM: the matrix is symmetric, so the coefficient towards a neighbour in the "upper" half of the stencil is also
+// stored in that neighbour's own row (opposite offset, transposed block).  Reading it from there makes every stored
+// value serve two rows; with the workgroups of an XCD covering a contiguous run of rows both uses meet in one L2.
+// Only rows whose neighbour row is owned take the mirrored address (ghost rows are not assembled).
+template <int DOF, int EPI, int SPLIT, bool SYM = false>
 __global__ __launch_bounds__(BLK) void k_dia_row_split(DiaOp<DOF> op, NodeArgs a) {
     constexpr int RPB = BLK / SPLIT;  // rows per workgroup
     __shared__ double s_part[SPLIT][RPB];
     const Geom &g = op.g;
     const long plane = g.plane();
     const int part = threadIdx.x / RPB, r = threadIdx.x % RPB;
-    const long t = blockIdx.x * (long)RPB + r;
+    // workgroups are dealt round-robin to the 8 XCDs: give every XCD a contiguous run of rows
+    const int nbk = gridDim.x, x8 = blockIdx.x & 7;
+    const int bid = SYM ? x8 * (nbk >> 3) + min(x8, nbk & 7) + (blockIdx.x >> 3) : blockIdx.x;
+    const long t = bid * (long)RPB + r;
     const bool valid = part < SPLIT && t < g.owned_nodes() * DOF;
     const long q = t + plane * g.own_lo * DOF;  // row
     const double *__restrict__ u = a.x;
@@ -345,8 +352,14 @@ __global__ __launch_bounds__(BLK) void k_dia_row_split(DiaOp<DOF> op, NodeArgs a
                 const bool ok = okj && i + di >= 0 && i + di < g.nx;
                 const int blk = (dk + 1) * 9 + (dj + 1) * 3 + (di + 1);
                 const long nb = ok ? n + di + (long)g.nx * (dj + (long)g.ny * dk) : n;
+                const bool mir = SYM && blk > 13 && ok && k + dk >= g.own_lo && k + dk <= g.own_hi;
+                const int rr = (int)(q - n * DOF);
 #pragma unroll
-                for (int c = 0; c < DOF; c++) y = fma(op.S[(long)(blk * DOF + c) * op.nrows + q], u[nb * DOF + c], y);
+                for (int c = 0; c < DOF; c++) {
+                    const long ad = mir ? (long)((26 - blk) * DOF + rr) * op.nrows + nb * DOF + c
+                                        : (long)(blk * DOF + c) * op.nrows + q;
+                    y = fma(op.S[ad], u[nb * DOF + c], y);
+                }
             }
         }
         s_part[part][r] = y;
