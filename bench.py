@@ -123,6 +123,8 @@ def main():
         df.mul_(10.0 / fx)                                 # main.cc:68-73 (fscale)
         flt.Gradients(x, xt, df, [dg])                     # main.cc:76
         info.update(its=le.last_its, fx=fx, gx=gx, rel_res=le.last_rnorm / le.last_bnorm)
+        info["solve_s"] = info.get("solve_s", 0.0) + le.last_solve_s
+        info["solve_its"] = info.get("solve_its", 0) + le.last_its
 
     def barrier():
         torch.cuda.synchronize()
@@ -132,6 +134,7 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    info.clear()
     le.pop_stats()
     barrier()
     t0 = time.perf_counter()
@@ -140,6 +143,19 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     alg_bytes, flops, launches = le.pop_stats()
+    # MMA::Update on the same design vectors (MMA.cc:522-946 on the device), reported separately
+    mma = tp.MMA(grid, x, 1)
+    xmin, xmax, xw = grid.elem_vec(), grid.elem_vec(), x.clone()
+    t_m = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        tm0 = time.perf_counter()
+        mma.SetOuterMovelimit(0.0, 1.0, 0.2, xw, xmin, xmax)
+        mma.Update(xw, df, [info.get("gx", 0.0)], [dg], xmin, xmax)
+        torch.cuda.synchronize()
+        t_m.append(time.perf_counter() - tm0)
+    mma_ms = 1e3 * min(t_m)
+    del mma
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -207,6 +223,11 @@ def main():
                                                                          "Helmholtz (PDE)" if ftype == 2 else "density", nlv, a.nsmooth, a.ncoarse, a.rtol,
                                                                          "Lanczos(10)" if a.fine_eig else "element bound"),
                    "n_dof": ndof, "cg_its": info.get("its"), "rel_residual": info.get("rel_res"), "fx": info.get("fx"),
+                   # SURVEY 8(d) secondary metrics: Krylov work rate (KSPSolve only, assembly/setup excluded) and the
+                   # MMA update that follows the measured path in the optimisation loop (not part of `value`)
+                   "solver_dof_its_per_s": ndof * info.get("solve_its", 0) / max(info.get("solve_s", 0.0), 1e-30),
+                   "solve_ms_per_step": 1e3 * info.get("solve_s", 0.0) / max(a.steps, 1),
+                   "mma_ms_per_update": mma_ms,
                    "parallelism": "zslab%d" % world, "comm": grid.comm_kind, "kernel_launches_per_step": launches / max(a.steps, 1),
                    "alg_GB_per_step": alg_bytes / max(a.steps, 1) / 1e9,
                    "hot_path_alg_GBps": alg_bytes / dt / 1e9},

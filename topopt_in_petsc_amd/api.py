@@ -202,8 +202,11 @@ class LinearElasticity:
         import numpy as np
         its, rn, bn = C.c_int(), C.c_double(), C.c_double()
         hist = np.zeros(max(hist_cap, 1))
+        import time
+        t0 = time.perf_counter()   # the solve ends with a host read of ||r||: wall time == device time
         rc = self.L.tp_elasticity_solve(self.handle, _ptr(self.RHS), _ptr(self.U), C.byref(its), C.byref(rn),
                                         C.byref(bn), hist.ctypes.data if hist_cap else None, hist_cap)
+        self.last_solve_s = time.perf_counter() - t0
         self.last_its, self.last_rnorm, self.last_bnorm = its.value, rn.value, bn.value
         self.last_hist = hist[: min(its.value + 1, hist_cap)] if hist_cap else None
         _chk(rc, "tp_elasticity_solve")
