@@ -268,6 +268,36 @@ struct MGSolver {
 
     // Chebyshev windows of the stencil / coarse levels (and of the fine level if opt.fine_eig)
     int estimate_spectra(int first_level) {
+        // One rank: the estimates of the levels are independent chains of small kernels -> one stream per level,
+        // forked from and joined to the solver's stream (the device overlaps their launch-latency-bound steps).
+        static const bool serial = getenv("TP_LANCZOS_SERIAL") != nullptr;
+        if (!grid->has_comm && !serial && nlv - first_level >= 2) {
+            hipStream_t main = grid->stream;
+            if (!lan_fork) TP_HIP(hipEventCreateWithFlags(&lan_fork, hipEventDisableTiming));
+            TP_HIP(hipEventRecord(lan_fork, main));
+            int rc = TP_OK;
+            for (int l = first_level; l < nlv && rc == TP_OK; l++) {
+                if (!lan_stream[l]) TP_HIP(hipStreamCreateWithFlags(&lan_stream[l], hipStreamNonBlocking));
+                if (!lan_done[l]) TP_HIP(hipEventCreateWithFlags(&lan_done[l], hipEventDisableTiming));
+                TP_HIP(hipStreamWaitEvent(lan_stream[l], lan_fork, 0));
+                grid->stream = lan_stream[l];  // everything the run launches goes to the level's stream
+                rc = lanczos_enqueue(l, (l == nlv - 1 && l > 0) ? NLANCZOS_COARSE : opt.nlanczos);
+                grid->stream = main;
+                if (rc == TP_OK && hipEventRecord(lan_done[l], lan_stream[l]) != hipSuccess) rc = TP_ERR_HIP;
+            }
+            for (int l = first_level; l < nlv; l++)
+                if (lan_done[l]) (void)hipStreamWaitEvent(main, lan_done[l], 0);
+            for (int l = first_level; l < nlv; l++)
+                if (lan_stream[l]) (void)hipStreamSynchronize(lan_stream[l]);
+            if (rc) return rc;
+            for (int l = first_level; l < nlv; l++) {
+                if (l == nlv - 1 && l > 0)
+                    lanczos_finish(l, &lv[l].lam, &lv[l].lam_min);
+                else
+                    lanczos_finish(l, &lv[l].lam);
+            }
+            return TP_OK;
+        }
         for (int l = first_level; l < nlv; l++) {
             if (l == nlv - 1 && l > 0) {
                 if (replicate) {  // same operator, same hashed start vector, no communication
@@ -330,12 +360,33 @@ struct MGSolver {
             Level<DOF> &L = lv[l];
             for (double *p : {L.b, L.x, L.x2, L.r, L.d, L.dinv, L.S, L.Kel}) (void)hipFree(p);
         }
-        for (double *p : {cg_r, cg_p, cg_w, lan_V, lan_coef}) (void)hipFree(p);
-        lan_V = lan_coef = nullptr;
-        lan_cap = 0;
+        for (double *p : {cg_r, cg_p, cg_w}) (void)hipFree(p);
+        for (LanBuf &b : lan) {
+            (void)hipFree(b.V);
+            (void)hipFree(b.coef);
+            (void)hipFree(b.part);
+            (void)hipHostFree(b.hc);
+            b = LanBuf();
+        }
+        for (int i = 0; i <= TP_MAX_LEVELS; i++) {
+            if (lan_stream[i]) (void)hipStreamDestroy(lan_stream[i]);
+            if (lan_done[i]) (void)hipEventDestroy(lan_done[i]);
+            lan_stream[i] = nullptr;
+            lan_done[i] = nullptr;
+        }
+        if (lan_fork) (void)hipEventDestroy(lan_fork);
+        lan_fork = nullptr;
     }
-    double *lan_V = nullptr, *lan_coef = nullptr;  // Lanczos basis / coefficients, kept across design iterations
-    size_t lan_cap = 0;
+    // Lanczos work space per level (kept across design iterations): basis, coefficients, reduction partials, pinned
+    // host copy of the coefficients; the runs of different levels are independent and may share the device
+    struct LanBuf {
+        double *V = nullptr, *coef = nullptr, *part = nullptr, *hc = nullptr;
+        size_t cap = 0;
+        int m = 0;
+    };
+    LanBuf lan[TP_MAX_LEVELS + 1];
+    hipStream_t lan_stream[TP_MAX_LEVELS + 1] = {};
+    hipEvent_t lan_fork = nullptr, lan_done[TP_MAX_LEVELS + 1] = {};
 
     // ---- operator application with one of the epilogues -------------------
     template <int EPI>
@@ -577,39 +628,42 @@ struct MGSolver {
     // reorthogonalisation (classical Gram-Schmidt twice): the estimates are then reproducible to
     // ~1e-13 between implementations, which the residual-history parity needs.  All coefficients
     // stay on the device; one host read at the end.
-    int lanczos(int l, int steps, double *lam_out, double *lam_min_out = nullptr) {
+    // Enqueues a Lanczos run for level l on grid->stream (everything stays on the device, coefficients are copied to
+    // the level's pinned host buffer at the end); lanczos_finish evaluates them once the stream has drained.
+    int lanczos_enqueue(int l, int steps) {
         Level<DOF> &L = lv[l];
+        LanBuf &B = lan[l];
         if (steps > 128) steps = 128;
         const long off = L.own_off(), n = L.own_n(), nd = L.ndof();
         // small levels: one workgroup per dot product writes its result directly (no second reduction stage)
         const int nb = n <= 65536 ? 1 : grid_for(n, 256);
         const int gn = (int)((L.g.owned_nodes() + BLK - 1) / BLK);
-        auto multi_dot = [&](const double *A, int nv, const double *wv, double *out) {
-            hipLaunchKernelGGL(k_multi_dot, dim3(nb, nv), dim3(BLK), 0, grid->stream, A, nd, nv, wv, off, n,
-                               nb == 1 ? out : grid->partials);
-            if (nb > 1) hipLaunchKernelGGL(k_reduce_multi, dim3(nv), dim3(BLK), 0, grid->stream, grid->partials, nb, nv, out);
-        };
         hipStream_t s = grid->stream;
-        // coef: h1[129] h2[129] alpha[128] beta[128] bb[1]
         const size_t need = (size_t)nd * (size_t)(steps + 1);
-        if (need > lan_cap) {
-            (void)hipFree(lan_V);
-            lan_V = nullptr;
-            lan_cap = 0;
-            TP_HIP(hipMalloc((void **)&lan_V, sizeof(double) * need));
-            lan_cap = need;
+        if (need > B.cap) {
+            (void)hipFree(B.V);
+            B.V = nullptr;
+            B.cap = 0;
+            TP_HIP(hipMalloc((void **)&B.V, sizeof(double) * need));
+            B.cap = need;
         }
-        if (!lan_coef) TP_HIP(hipMalloc((void **)&lan_coef, sizeof(double) * 520));
-        double *V = lan_V, *coef = lan_coef;
+        if (!B.coef) TP_HIP(hipMalloc((void **)&B.coef, sizeof(double) * 520));
+        if (!B.part) TP_HIP(hipMalloc((void **)&B.part, sizeof(double) * 256 * 130));
+        if (!B.hc) TP_HIP(hipHostMalloc((void **)&B.hc, sizeof(double) * 520));
+        double *V = B.V, *coef = B.coef, *part = B.part;
+        auto multi_dot = [&](const double *A, int nv, const double *wv, double *out) {
+            hipLaunchKernelGGL(k_multi_dot, dim3(nb, nv), dim3(BLK), 0, s, A, nd, nv, wv, off, n, nb == 1 ? out : part);
+            if (nb > 1) hipLaunchKernelGGL(k_reduce_multi, dim3(nv), dim3(BLK), 0, s, part, nb, nv, out);
+        };
         TP_HIP(hipMemsetAsync(V, 0, sizeof(double) * (size_t)nd * (size_t)(steps + 1), s));
         TP_HIP(hipMemsetAsync(coef, 0, sizeof(double) * 520, s));
+        // coef: h1[129] h2[129] alpha[128] beta[128] bb[1]
         double *h1 = coef, *h2 = coef + 129, *al = coef + 258, *be = coef + 386, *bb = coef + 514;
         double *w = L.d, *t = L.x, *dis = L.x2;
         hipLaunchKernelGGL((k_lanczos_init<DOF>), dim3(gn), dim3(BLK), 0, s, L.g, V, dis, L.dinv);
         multi_dot(V, 1, V, bb);
         TP_TRY(allreduce_dev(bb, 1, L.no_comm));
         hipLaunchKernelGGL(k_lanczos_next, dim3(grid_for(n)), dim3(BLK), 0, s, V, bb, 0, be, V, off, n);  // normalise v0
-        int m = 0;
         for (int j = 0; j < steps; j++) {
             double *vj = V + (size_t)j * nd;
             hipLaunchKernelGGL(k_pw_mult, dim3(grid_for(n)), dim3(BLK), 0, s, t + off, dis + off, vj + off, n);
@@ -628,12 +682,15 @@ struct MGSolver {
             hipLaunchKernelGGL(k_lanczos_next, dim3(grid_for(n)), dim3(BLK), 0, s, w, bb, j, be, V + (size_t)(j + 1) * nd,
                                off, n);
             grid->launches += nb == 1 ? 9 : 12;
-            m++;
         }
-        double hc[520];
-        TP_HIP(hipMemcpyAsync(hc, coef, sizeof(hc), hipMemcpyDeviceToHost, s));
-        TP_HIP(hipStreamSynchronize(s));
-        const double *ha = hc + 258, *hb = hc + 386;
+        B.m = steps;
+        TP_HIP(hipMemcpyAsync(B.hc, coef, sizeof(double) * 520, hipMemcpyDeviceToHost, s));
+        return TP_OK;
+    }
+    void lanczos_finish(int l, double *lam_out, double *lam_min_out = nullptr) {
+        const LanBuf &B = lan[l];
+        const double *ha = B.hc + 258, *hb = B.hc + 386;
+        int m = B.m;
         for (int j = 0; j < m; j++)  // breakdown (invariant subspace): truncate like the CPU path
             if (!(hb[j] > 1e-14 * fabs(ha[j]))) {
                 m = j + 1;
@@ -641,6 +698,11 @@ struct MGSolver {
             }
         *lam_out = tridiag_lmax(m, ha, hb);
         if (lam_min_out) *lam_min_out = tridiag_lmin(m, ha, hb);
+    }
+    int lanczos(int l, int steps, double *lam_out, double *lam_min_out = nullptr) {
+        TP_TRY(lanczos_enqueue(l, steps));
+        TP_HIP(hipStreamSynchronize(grid->stream));
+        lanczos_finish(l, lam_out, lam_min_out);
         return TP_OK;
     }
 
