@@ -280,8 +280,9 @@ struct MGSolver {
                 if (!lan_stream[l]) TP_HIP(hipStreamCreateWithFlags(&lan_stream[l], hipStreamNonBlocking));
                 if (!lan_done[l]) TP_HIP(hipEventCreateWithFlags(&lan_done[l], hipEventDisableTiming));
                 TP_HIP(hipStreamWaitEvent(lan_stream[l], lan_fork, 0));
+                const int steps = (l == nlv - 1 && l > 0) ? NLANCZOS_COARSE : opt.nlanczos;
                 grid->stream = lan_stream[l];  // everything the run launches goes to the level's stream
-                rc = lanczos_enqueue(l, (l == nlv - 1 && l > 0) ? NLANCZOS_COARSE : opt.nlanczos);
+                rc = lanczos_graph(l, steps);
                 grid->stream = main;
                 if (rc == TP_OK && hipEventRecord(lan_done[l], lan_stream[l]) != hipSuccess) rc = TP_ERR_HIP;
             }
@@ -369,6 +370,9 @@ struct MGSolver {
             b = LanBuf();
         }
         for (int i = 0; i <= TP_MAX_LEVELS; i++) {
+            if (lan_graph[i]) (void)hipGraphExecDestroy(lan_graph[i]);
+            lan_graph[i] = nullptr;
+            lan_graph_state[i] = 0;
             if (lan_stream[i]) (void)hipStreamDestroy(lan_stream[i]);
             if (lan_done[i]) (void)hipEventDestroy(lan_done[i]);
             lan_stream[i] = nullptr;
@@ -385,6 +389,12 @@ struct MGSolver {
         int m = 0;
     };
     LanBuf lan[TP_MAX_LEVELS + 1];
+    // the run of a level is a static chain of ~400-1000 small launches: captured once into a hipGraph and replayed
+    // every design iteration (host cost: one launch); rebuilt when the captured pointers may have changed
+    hipGraphExec_t lan_graph[TP_MAX_LEVELS + 1] = {};
+    const void *lan_graph_key[TP_MAX_LEVELS + 1][5] = {};
+    long topology_epoch = 0;  // bumped by the owner whenever lists/buffers referenced by the operators are rebuilt
+    int lan_graph_state[TP_MAX_LEVELS + 1] = {};  // 0: not tried, 1: valid, -1: capture failed -> direct launches
     hipStream_t lan_stream[TP_MAX_LEVELS + 1] = {};
     hipEvent_t lan_fork = nullptr, lan_done[TP_MAX_LEVELS + 1] = {};
 
@@ -659,7 +669,7 @@ struct MGSolver {
         TP_HIP(hipMemsetAsync(coef, 0, sizeof(double) * 520, s));
         // coef: h1[129] h2[129] alpha[128] beta[128] bb[1]
         double *h1 = coef, *h2 = coef + 129, *al = coef + 258, *be = coef + 386, *bb = coef + 514;
-        double *w = L.d, *t = L.x, *dis = L.x2;
+        double *w = L.d, *t = L.r, *dis = L.b;  // scratch that smooth() never swaps: stable addresses for the graph
         hipLaunchKernelGGL((k_lanczos_init<DOF>), dim3(gn), dim3(BLK), 0, s, L.g, V, dis, L.dinv);
         multi_dot(V, 1, V, bb);
         TP_TRY(allreduce_dev(bb, 1, L.no_comm));
@@ -685,6 +695,55 @@ struct MGSolver {
         }
         B.m = steps;
         TP_HIP(hipMemcpyAsync(B.hc, coef, sizeof(double) * 520, hipMemcpyDeviceToHost, s));
+        return TP_OK;
+    }
+    // replay (or capture, or plain enqueue) of the run of level l on grid->stream
+    int lanczos_graph(int l, int steps) {
+        static const bool no_graph = getenv("TP_NO_GRAPH") != nullptr;
+        Level<DOF> &L = lv[l];
+        hipStream_t s = grid->stream;
+        // the chain reads/writes these vectors by address, and set_bc may rebuild the correction lists
+        const void *key[5] = {L.r, L.b, L.d, L.corr, (const void *)(intptr_t)topology_epoch};
+        if (lan_graph_state[l] == 1 && memcmp(key, lan_graph_key[l], sizeof(key)) != 0) {
+            (void)hipGraphExecDestroy(lan_graph[l]);
+            lan_graph[l] = nullptr;
+            lan_graph_state[l] = 0;
+        }
+        if (no_graph || lan_graph_state[l] < 0) return lanczos_enqueue(l, steps);
+        if (lan_graph_state[l] == 1) {
+            lan[l].m = steps;
+            const long launches = grid->launches;
+            (void)launches;
+            if (hipGraphLaunch(lan_graph[l], s) == hipSuccess) return TP_OK;
+            lan_graph_state[l] = -1;
+            return lanczos_enqueue(l, steps);
+        }
+        // first use: allocate outside the capture (a warm-up run), then capture the identical chain
+        int rc = lanczos_enqueue(l, steps);
+        if (rc) return rc;
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            lan_graph_state[l] = -1;
+            return TP_OK;  // the warm-up run above already did the work
+        }
+        const long l0 = grid->launches;
+        const double b0 = grid->alg_bytes, f0 = grid->flops;
+        rc = lanczos_enqueue(l, steps);
+        grid->launches = l0;  // the captured chain was not executed
+        grid->alg_bytes = b0;
+        grid->flops = f0;
+        hipGraph_t g = nullptr;
+        const hipError_t e1 = hipStreamEndCapture(s, &g);
+        if (rc || e1 != hipSuccess || !g || hipGraphInstantiate(&lan_graph[l], g, nullptr, nullptr, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            if (g) (void)hipGraphDestroy(g);
+            lan_graph[l] = nullptr;
+            lan_graph_state[l] = -1;
+            return rc;
+        }
+        (void)hipGraphDestroy(g);
+        memcpy(lan_graph_key[l], key, sizeof(key));
+        lan_graph_state[l] = 1;
         return TP_OK;
     }
     void lanczos_finish(int l, double *lam_out, double *lam_min_out = nullptr) {

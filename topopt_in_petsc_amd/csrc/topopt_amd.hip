@@ -373,6 +373,7 @@ extern "C" int tp_elasticity_get_ke(const tp_elasticity *e, double *ke) {
     return TP_OK;
 }
 extern "C" int tp_elasticity_set_bc(tp_elasticity *e, const double *N) {
+    if (e) e->mg.topology_epoch++;  // captured launch chains reference the lists rebuilt below
     tp_grid *g = e->grid;
     Geom q = make_geom(g, 0);
     const long nn = q.nodes();
