@@ -108,7 +108,7 @@ def cpu_mode(rank, world):
 def gpu_mode(rank, world):
     import topopt_in_petsc_amd as tp
     torch.cuda.set_device(0)
-    ex, ey, ez, nlv = 16, 8, 16, 3
+    ex, ey, ez, nlv = [int(v) for v in sys.argv[2:6]] if len(sys.argv) >= 6 else (16, 8, 16, 3)
     nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
     grid = tp.Grid(nx, ny, nz, h, rank=rank, nranks=world)
     part = grid.part

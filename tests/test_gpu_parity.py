@@ -377,3 +377,32 @@ def test_mbb_load_case_componentwise_masks(tp, orc):
     assert rel(host(le.U), Uo) <= 1e-8
     k = min(10, its)
     assert np.abs(le.last_hist[:k] / hist_o[:k] - 1).max() <= 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ex,ey,ez,nlv", [(24, 12, 8, 3), (40, 24, 16, 4), (20, 12, 12, 3), (48, 16, 32, 5),
+                                          (36, 20, 28, 3), (64, 16, 16, 2)])
+def test_mesh_shape_sweep(tp, orc, ex, ey, ez, nlv):
+    """Shapes that do not line up with the 15-node tiles, the 32x4x2 filter blocks, the z-chunk heuristics or the
+    XCD-contiguous orders: every level operator, the solve and the cone filter against the oracle."""
+    grid, le, mg, x, KE, N, R = make(tp, orc, ex, ey, ez, nlv, rtol=1e-8)
+    nx, ny, nz = ex + 1, ey + 1, ez + 1
+    u = np.random.default_rng(ex * 1000 + ez).standard_normal(mg.n)
+    for l in range(nlv):
+        ul = u[: mg.size(l)]
+        assert rel(host(le.level_apply(l, dev(ul))), mg.apply(l, ul)) <= 1e-13
+        assert le.level_lambda(l) == pytest.approx(mg.lam(l), rel=1e-9)
+    its = le.KSPSolve(hist_cap=300)
+    Uo, its_o, hist_o = mg.solve(R * N, rtol=1e-8, maxit=300)
+    assert its == its_o
+    assert rel(host(le.U), Uo) <= 1e-8
+    k = min(10, its)
+    assert np.abs(le.last_hist[:k] / hist_o[:k] - 1).max() <= 1e-9
+    h = 1.0 / ey
+    for rfac in (1.5, 2.56):
+        f = tp.Filter(grid, 1, rfac * h)
+        of = orc.Filter(nx, ny, nz, h, rfac * h)
+        xt, xp = grid.elem_vec(), grid.elem_vec()
+        f.FilterProject(dev(x), xt, xp)
+        xto, xpo = of.project(1, x)
+        assert rel(host(xt), xto) <= 1e-13

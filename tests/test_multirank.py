@@ -20,11 +20,11 @@ def _free_port():
     return p
 
 
-def _launch(mode, nproc=2, timeout=600):
+def _launch(mode, nproc=2, timeout=600, extra=()):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "tests", "mp_gloo_worker.py"), mode]
+           os.path.join(ROOT, "tests", "mp_gloo_worker.py"), mode] + [str(v) for v in extra]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-3000:]
     for k in range(nproc):
@@ -56,3 +56,11 @@ def test_two_ranks_cpu_gloo():
 @pytest.mark.gpu
 def test_two_ranks_one_gpu():
     _launch("gpu")
+
+
+@pytest.mark.gpu
+def test_four_ranks_one_gpu_interior_slabs():
+    """4 slabs on one GPU: the two interior ranks have a neighbour on both sides (ghost plane below AND above),
+    on a mesh that does not line up with the tile sizes"""
+    _launch("gpu", nproc=4, extra=(20, 12, 32, 3))
+
