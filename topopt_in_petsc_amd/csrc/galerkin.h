@@ -82,8 +82,10 @@ __global__ __launch_bounds__(192) void k_galerkin_fine_fast(Geom gf, Geom gc, co
 __global__ __launch_bounds__(64) void k_galerkin_fine_masked(Geom gf, Geom gc, const double *__restrict__ E,
                                                              const double *__restrict__ KE,
                                                              const uint8_t *__restrict__ mask,
-                                                             const int *__restrict__ list, double *__restrict__ Kel) {
+                                                             const int *__restrict__ list, double *__restrict__ Kel,
+                                                             int compact) {
     const long t = list[blockIdx.x];
+    const long slot = compact ? (long)blockIdx.x : t;  // compact: the matrix of the f-th listed element is row f
     const int Ie = (int)(t % gc.ex), Je = (int)((t / gc.ex) % gc.ey), Ke = (int)(t / ((long)gc.ex * gc.ey));
     const int I = threadIdx.x >> 3, J = threadIdx.x & 7;
     double acc[9];
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(64) void k_galerkin_fine_masked(Geom gf, Geom gc, c
         }
     }
     for (int r = 0; r < 3; r++)
-        for (int cc = 0; cc < 3; cc++) Kel[t * 576 + (3 * I + r) * 24 + 3 * J + cc] = acc[r * 3 + cc];
+        for (int cc = 0; cc < 3; cc++) Kel[slot * 576 + (3 * I + r) * 24 + 3 * J + cc] = acc[r * 3 + cc];
 }
 
 // ---- level l -> l+1 (l >= 1): one wave per coarse element.
@@ -129,54 +131,85 @@ __global__ __launch_bounds__(64) void k_galerkin_fine_masked(Geom gf, Geom gc, c
 // -> six in-LDS contractions (3 row axes, 3 column axes) of the 576-entry child matrix instead of
 // the dense 64x64 triple product (8x fewer flops, and every matrix is read exactly once, coalesced).
 __device__ __constant__ int c_FLIP[3][8] = {{1, 0, 3, 2, 5, 4, 7, 6}, {3, 2, 1, 0, 7, 6, 5, 4}, {4, 5, 6, 7, 0, 1, 2, 3}};
+// FROM_E (level 1 -> 2 when level 1 is applied matrix-free): the child matrices are never stored; an unflagged
+// child is sum_g E_g M_g formed here from the fine moduli (same fma order as k_galerkin_fine_fast), a flagged one
+// is row fidx[child] of the compact array Kf.
+template <bool FROM_E>
 __global__ __launch_bounds__(64) void k_galerkin_coarse(Geom gf, Geom gc, const double *__restrict__ Kf,
-                                                        double *__restrict__ Kc) {
+                                                        double *__restrict__ Kc, Geom g0, const double *__restrict__ E,
+                                                        const double *__restrict__ M, const int *__restrict__ fidx,
+                                                        long nel) {
     __shared__ double A[576], B[576];
-    const long el = blockIdx.x;  // own coarse element
-    const int Ie = (int)(el % gc.ex), Je = (int)((el / gc.ex) % gc.ey), Ke = (int)(el / ((long)gc.ex * gc.ey));
     const int t = threadIdx.x;
-    double acc[9];
+    // FROM_E: this thread's 9 entries of the 8 constant child matrices stay in registers for all elements of the block
+    double Mr[FROM_E ? 9 : 1][FROM_E ? 8 : 1];
+    if (FROM_E) {
 #pragma unroll
-    for (int q = 0; q < 9; q++) acc[q] = 0.0;
-    for (int c = 0; c < 8; c++) {
-        const long ch = (long)(2 * Ie + (c & 1)) + (long)gf.ex * ((2 * Je + ((c >> 1) & 1)) + (long)gf.ey * (2 * Ke + ((c >> 2) & 1)));
-        const double *__restrict__ src = Kf + ch * 576;
+        for (int q = 0; q < 9; q++)
 #pragma unroll
-        for (int q = 0; q < 9; q++) A[t + 64 * q] = src[t + 64 * q];
-        __syncthreads();
-        double *in = A, *out = B;
-        for (int pass = 0; pass < 6; pass++) {
-            const int d = pass % 3;            // axis
-            const bool rows = pass < 3;        // contract the row (a) or the column (b) node index
-            const int hi = (c >> d) & 1;       // child on the high side of this axis
+            for (int g8 = 0; g8 < 8; g8++) Mr[q][g8] = M[g8 * 576 + t + 64 * q];
+    }
+    for (long el = blockIdx.x; el < nel; el += gridDim.x) {  // own coarse elements
+        const int Ie = (int)(el % gc.ex), Je = (int)((el / gc.ex) % gc.ey), Ke = (int)(el / ((long)gc.ex * gc.ey));
+        double acc[9];
 #pragma unroll
-            for (int q = 0; q < 9; q++) {
-                const int o = t + 64 * q;
-                const int row = o / 24, col = o % 24;
-                const int nd = rows ? row / 3 : col / 3;  // node index being contracted (as coarse corner I_d)
-                const int lbit = d == 0 ? c_LX[nd] : (d == 1 ? c_LY[nd] : c_LZ[nd]);
-                const int fl = c_FLIP[d][nd];
-                const int o2 = rows ? (fl * 3 + row % 3) * 24 + col : row * 24 + fl * 3 + col % 3;
-                // in0 = value at fine node bit 0, in1 = at fine node bit 1 (other indices equal)
-                const double v_same = in[o], v_flip = in[o2];
-                const double in0 = lbit ? v_flip : v_same, in1 = lbit ? v_same : v_flip;
-                double r;
-                if (!hi) r = lbit ? 0.5 * in1 : in0 + 0.5 * in1;  // w = {{1,0},{.5,.5}}
-                else r = lbit ? 0.5 * in0 + in1 : 0.5 * in0;      // w = {{.5,.5},{0,1}}
-                out[o] = r;
+        for (int q = 0; q < 9; q++) acc[q] = 0.0;
+        for (int c = 0; c < 8; c++) {
+            const long ch = (long)(2 * Ie + (c & 1)) + (long)gf.ex * ((2 * Je + ((c >> 1) & 1)) + (long)gf.ey * (2 * Ke + ((c >> 2) & 1)));
+            const int f = FROM_E ? fidx[ch] : 0;
+            if (!FROM_E || f >= 0) {
+                const double *__restrict__ src = Kf + (FROM_E ? (long)f : ch) * 576;
+#pragma unroll
+                for (int q = 0; q < 9; q++) A[t + 64 * q] = src[t + 64 * q];
+            } else {
+                const int i1 = (int)(ch % gf.ex), j1 = (int)((ch / gf.ex) % gf.ey), k1 = (int)(ch / ((long)gf.ex * gf.ey));
+                double Eg[8];
+#pragma unroll
+                for (int g8 = 0; g8 < 8; g8++)
+                    Eg[g8] = E[(long)(2 * i1 + (g8 & 1)) + (long)g0.ex * ((2 * j1 + ((g8 >> 1) & 1)) + (long)g0.ey * (2 * k1 + ((g8 >> 2) & 1)))];
+#pragma unroll
+                for (int q = 0; q < 9; q++) {
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int g8 = 0; g8 < 8; g8++) sacc = fma(Eg[g8], Mr[FROM_E ? q : 0][FROM_E ? g8 : 0], sacc);
+                    A[t + 64 * q] = sacc;
+                }
             }
             __syncthreads();
-            double *tmp = in;
-            in = out;
-            out = tmp;
+            double *in = A, *out = B;
+            for (int pass = 0; pass < 6; pass++) {
+                const int d = pass % 3;            // axis
+                const bool rows = pass < 3;        // contract the row (a) or the column (b) node index
+                const int hi = (c >> d) & 1;       // child on the high side of this axis
+#pragma unroll
+                for (int q = 0; q < 9; q++) {
+                    const int o = t + 64 * q;
+                    const int row = o / 24, col = o % 24;
+                    const int nd = rows ? row / 3 : col / 3;  // node index being contracted (as coarse corner I_d)
+                    const int lbit = d == 0 ? c_LX[nd] : (d == 1 ? c_LY[nd] : c_LZ[nd]);
+                    const int fl = c_FLIP[d][nd];
+                    const int o2 = rows ? (fl * 3 + row % 3) * 24 + col : row * 24 + fl * 3 + col % 3;
+                    // in0 = value at fine node bit 0, in1 = at fine node bit 1 (other indices equal)
+                    const double v_same = in[o], v_flip = in[o2];
+                    const double in0 = lbit ? v_flip : v_same, in1 = lbit ? v_same : v_flip;
+                    double r;
+                    if (!hi) r = lbit ? 0.5 * in1 : in0 + 0.5 * in1;  // w = {{1,0},{.5,.5}}
+                    else r = lbit ? 0.5 * in0 + in1 : 0.5 * in0;      // w = {{.5,.5},{0,1}}
+                    out[o] = r;
+                }
+                __syncthreads();
+                double *tmp = in;
+                in = out;
+                out = tmp;
+            }
+            // after 6 passes the result is back in A (in == A)
+#pragma unroll
+            for (int q = 0; q < 9; q++) acc[q] += in[t + 64 * q];
+            __syncthreads();
         }
-        // after 6 passes the result is back in A (in == A)
 #pragma unroll
-        for (int q = 0; q < 9; q++) acc[q] += in[t + 64 * q];
-        __syncthreads();
+        for (int q = 0; q < 9; q++) Kc[el * 576 + t + 64 * q] = acc[q];
     }
-#pragma unroll
-    for (int q = 0; q < 9; q++) Kc[el * 576 + t + 64 * q] = acc[q];
 }
 
 // ---- collapse element matrices to the 27-point block stencil ----------------
@@ -242,6 +275,43 @@ __global__ __launch_bounds__(BLK) void k_elem_diag(Geom g, const double *__restr
     for (int r = 0; r < 3; r++) dinv[n * 3 + r] = 1.0 / acc[r];
 }
 
+// Jacobi inverse diagonal of the matrix-free level 1 without its element matrices: unflagged elements contribute
+// sum_c E_c diag(M_c) (same fma order as k_galerkin_fine_fast followed by k_elem_diag), flagged ones their compact row
+__global__ __launch_bounds__(BLK) void k_macro_diag(Geom g0, Geom g, const double *__restrict__ E,
+                                                    const double *__restrict__ M, const double *__restrict__ KelF,
+                                                    const int *__restrict__ fidx, double *__restrict__ dinv) {
+    const long plane = g.plane();
+    const long t = blockIdx.x * (long)BLK + threadIdx.x;
+    if (t >= g.owned_nodes()) return;
+    const int k = g.own_lo + (int)(t / plane);
+    const int rem = (int)(t % plane);
+    const int j = rem / g.nx, i = rem % g.nx;
+    const long n = t + plane * g.own_lo;
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int I = 0; I < 8; I++) {
+        const int ei = i - c_LX[I], ej = j - c_LY[I], ek = k - c_LZ[I];
+        if (ei < 0 || ei >= g.ex || ej < 0 || ej >= g.ey || ek < 0 || ek >= g.ezl) continue;
+        const long el = (long)ei + (long)g.ex * (ej + (long)g.ey * ek);
+        const int f = fidx[el];
+        if (f >= 0) {
+#pragma unroll
+            for (int r = 0; r < 3; r++) acc[r] += KelF[(long)f * 576 + (3 * I + r) * 25];
+        } else {
+            double s3[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const double Ec = E[(long)(2 * ei + (c & 1)) + (long)g0.ex * ((2 * ej + ((c >> 1) & 1)) + (long)g0.ey * (2 * ek + ((c >> 2) & 1)))];
+#pragma unroll
+                for (int r = 0; r < 3; r++) s3[r] = fma(Ec, M[c * 576 + (3 * I + r) * 25], s3[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 3; r++) acc[r] += s3[r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++) dinv[n * 3 + r] = 1.0 / acc[r];
+}
+
 // ---- Dirichlet correction of the matrix-free level-1 operator -----------------
 // dK[entry][f] = K_E (exact Galerkin element matrix, with N K N + D) - sum_c E_c M_c
 // for the listed (flagged) coarse elements; thread = (entry, flagged element)
@@ -259,7 +329,7 @@ __global__ __launch_bounds__(BLK) void k_macro_delta(Geom gf, Geom gc, const dou
         const int i = 2 * I + (c & 1), j = 2 * J + ((c >> 1) & 1), k = 2 * K + ((c >> 2) & 1);
         s = fma(E[(long)i + (long)gf.ex * (j + (long)gf.ey * k)], M[c * 576 + e], s);
     }
-    dK[(long)e * nlist + f] = Kel[ce * 576 + e] - s;
+    dK[(long)e * nlist + f] = Kel[(long)f * 576 + e] - s;  // Kel: compact, row f = f-th listed element
 }
 // tmp[r][f] = dK_E[row r] . x_E ; thread = (row r of 24, flagged element f), coalesced over f
 __global__ __launch_bounds__(BLK) void k_macro_corr_rows(Geom g, const double *__restrict__ dK,

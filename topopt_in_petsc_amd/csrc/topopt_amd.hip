@@ -243,6 +243,11 @@ struct tp_elasticity {
     int nflag_all;
     int *d_corr_nodes, *d_corr_adj;
     double *d_dK, *d_corr, *d_corr_tmp;
+    // matrix-free level 1 keeps no element matrices but those of the flagged elements (compact rows: own flagged in
+    // list order, then the ghost-layer ones received from the upper neighbour) and the element -> row map
+    double *d_KelF;
+    int *d_fidx1;
+    int nx_first;            // max over ranks of the flagged elements in a rank's first own level-1 layer
     int nflagged;
     double *d_bN;            // RHS .* N scratch
     double *d_N;             // copy of N (for the load masking of :542)
@@ -296,6 +301,9 @@ extern "C" int tp_elasticity_create(tp_elasticity **out, tp_grid *g, const tp_so
     e->d_colmask = nullptr;
     e->d_flag_all = e->d_corr_nodes = e->d_corr_adj = nullptr;
     e->d_dK = e->d_corr = e->d_corr_tmp = nullptr;
+    e->d_KelF = nullptr;
+    e->d_fidx1 = nullptr;
+    e->nx_first = 0;
     e->nflag_all = 0;
     hex8_stiffness_box(g->o.hx, g->o.hy, g->o.hz, o->nu, e->KE);
     std::vector<double> M(8 * 576);
@@ -350,7 +358,8 @@ extern "C" int tp_elasticity_create(tp_elasticity **out, tp_grid *g, const tp_so
                 TP_HIP(hipMalloc((void **)&L.S, sizeof(double) * 81 * (size_t)L.ndof()));
                 TP_HIP(hipMemset(L.S, 0, sizeof(double) * 81 * (size_t)L.ndof()));
             }
-            TP_HIP(hipMalloc((void **)&L.Kel, sizeof(double) * 576 * (size_t)L.g.elems_stored()));
+            // the matrix-free level 1 materialises no element matrices (1.2 GB at 128^3)
+            if (L.kind != LV_MACRO) TP_HIP(hipMalloc((void **)&L.Kel, sizeof(double) * 576 * (size_t)L.g.elems_stored()));
         }
     }
     *out = e;
@@ -363,7 +372,8 @@ extern "C" int tp_elasticity_destroy(tp_elasticity *e) {
     e->mg.free_levels();
     for (void *p : {(void *)e->d_KE, (void *)e->d_M, (void *)e->d_E, (void *)e->d_mask, (void *)e->d_bN, (void *)e->d_N,
                     (void *)e->d_flagged, (void *)e->d_colmask, (void *)e->d_flag_all, (void *)e->d_corr_nodes,
-                    (void *)e->d_corr_adj, (void *)e->d_dK, (void *)e->d_corr, (void *)e->d_corr_tmp})
+                    (void *)e->d_corr_adj, (void *)e->d_dK, (void *)e->d_corr, (void *)e->d_corr_tmp, (void *)e->d_KelF,
+                    (void *)e->d_fidx1})
         (void)hipFree(p);
     delete e;
     return TP_OK;
@@ -447,10 +457,35 @@ extern "C" int tp_elasticity_set_bc(tp_elasticity *e, const double *N) {
                     }
                 }
         for (void *p : {(void *)e->d_flag_all, (void *)e->d_corr_nodes, (void *)e->d_corr_adj, (void *)e->d_dK,
-                        (void *)e->d_corr_tmp})
+                        (void *)e->d_corr_tmp, (void *)e->d_KelF, (void *)e->d_fidx1})
             (void)hipFree(p);
         e->d_flag_all = e->d_corr_nodes = e->d_corr_adj = nullptr;
-        e->d_dK = e->d_corr_tmp = nullptr;
+        e->d_dK = e->d_corr_tmp = e->d_KelF = nullptr;
+        e->d_fidx1 = nullptr;
+        // own flagged elements come first in `fall` (same order as `fl`), the ghost layer last; the first own layer
+        // is the head of `fl`.  The compact ghost rows travel down with a common row count (max over the ranks).
+        int n0 = 0;
+        for (int id : fl) n0 += id < clay ? 1 : 0;
+        e->nx_first = n0;
+        if (g->has_comm) {
+            std::vector<double> cnt((size_t)g->nranks, 0.0);
+            cnt[(size_t)g->rank] = n0;
+            for (int o = 0; o < g->nranks; o += 16) {
+                const int m16 = g->nranks - o < 16 ? g->nranks - o : 16;
+                TP_HIP(hipMemcpy(g->comm.red, cnt.data() + o, sizeof(double) * m16, hipMemcpyHostToDevice));
+                if (g->comm.allreduce_sum(g->comm.user, m16)) return TP_ERR_COMM;
+                TP_HIP(hipStreamSynchronize(g->stream));
+                TP_HIP(hipMemcpy(cnt.data() + o, g->comm.red, sizeof(double) * m16, hipMemcpyDeviceToHost));
+            }
+            for (double v : cnt) e->nx_first = v > e->nx_first ? (int)v : e->nx_first;
+        }
+        TP_HIP(hipMalloc((void **)&e->d_fidx1, sizeof(int) * fidx.size()));
+        TP_HIP(hipMemcpy(e->d_fidx1, fidx.data(), sizeof(int) * fidx.size(), hipMemcpyHostToDevice));
+        {
+            const size_t rows = fl.size() + 2 * (size_t)e->nx_first + 1;
+            TP_HIP(hipMalloc((void **)&e->d_KelF, sizeof(double) * 576 * rows));
+            TP_HIP(hipMemset(e->d_KelF, 0, sizeof(double) * 576 * rows));
+        }
         e->nflag_all = (int)fall.size();
         TP_HIP(hipMemset(e->d_corr, 0, sizeof(double) * (size_t)L1.ndof()));
         if (!fall.empty()) {
@@ -501,33 +536,58 @@ extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, dou
     // from the fine densities and reaches one coarse = two fine layers up)
     TP_TRY(exchange_segments(g, e->d_E, nullptr, nullptr, e->d_E + nel, 2 * lay, 1, 2 * lay));
     TP_TRY(mg.setup_matfree_level(0, e->KE));
+    const bool macro1 = mg.nlv > 1 && mg.lv[1].kind == LV_MACRO;  // level 1 applied from E: no element matrices there
     for (int l = 1; l < mg.nlv; l++) {
         Level<3> &F = mg.lv[l - 1], &C = mg.lv[l];
         const long nEc = C.g.own_elems();
+        const int gn = (int)((C.g.owned_nodes() + BLK - 1) / BLK);
+        if (l == 1 && macro1) {
+            // only the flagged elements get their (exact, masked) Galerkin matrix: compact rows, own ones first,
+            // then the ghost layer's -- the upper neighbour's first-layer rows, which head ITS array
+            if (e->nflagged) {
+                hipLaunchKernelGGL(k_galerkin_fine_masked, dim3(e->nflagged), dim3(64), 0, s, F.g, C.g, e->d_E, e->d_KE,
+                                   e->d_mask, e->d_flagged, e->d_KelF, 1);
+                count_launch(g);
+            }
+            if (g->has_comm && e->nx_first > 0)
+                TP_TRY(exchange_segments(g, e->d_KelF, nullptr, nullptr, e->d_KelF + 576 * (long)e->nflagged, 576,
+                                         e->nx_first, 576));
+            if (e->nflag_all) {
+                hipLaunchKernelGGL(k_macro_delta, dim3((int)(((long)e->nflag_all * 576 + BLK - 1) / BLK)), dim3(BLK), 0, s,
+                                   F.g, C.g, e->d_E, e->d_M, e->d_KelF, e->d_flag_all, e->nflag_all, e->d_dK);
+                count_launch(g);
+            }
+            hipLaunchKernelGGL(k_macro_diag, dim3(gn), dim3(BLK), 0, s, F.g, C.g, e->d_E, e->d_M, e->d_KelF, e->d_fidx1,
+                               C.dinv);
+            count_launch(g, 8.0 * 8.0 * C.g.own_elems() + 24.0 * C.g.owned_nodes(), 8.0 * 64 * 3 * C.g.owned_nodes());
+            continue;
+        }
         if (l == 1) {
             hipLaunchKernelGGL(k_galerkin_fine_fast, dim3((unsigned)nEc), dim3(192), 0, s, F.g, C.g, e->d_E, e->d_M,
                                C.Kel);
             count_launch(g, 8.0 * nel + 8.0 * 576 * nEc, 2.0 * 8 * 576 * nEc);
             if (e->nflagged) {
                 hipLaunchKernelGGL(k_galerkin_fine_masked, dim3(e->nflagged), dim3(64), 0, s, F.g, C.g, e->d_E, e->d_KE,
-                                   e->d_mask, e->d_flagged, C.Kel);
+                                   e->d_mask, e->d_flagged, C.Kel, 0);
                 count_launch(g);
             }
+        } else if (l == 2 && macro1) {
+            // children = level-1 elements, formed on the fly from the fine moduli (or read from the compact rows)
+            static const long nb_env = getenv("TP_GAL_BLOCKS") ? atol(getenv("TP_GAL_BLOCKS")) : 4096;
+            const unsigned nblk = (unsigned)(nEc < nb_env ? nEc : nb_env);  // several elements per workgroup: the child
+            hipLaunchKernelGGL((k_galerkin_coarse<true>), dim3(nblk), dim3(64), 0, s, F.g, C.g, e->d_KelF, C.Kel,  // matrices' constants
+                               mg.lv[0].g, e->d_E, e->d_M, e->d_fidx1, nEc);                                     // live in registers
+            count_launch(g, 8.0 * 64 * nEc + 8.0 * 576 * nEc, 2.0 * (8 * 576 * 8 + 0.18 * 8 * 64 * 64 * 9) * nEc);
         } else {
-            hipLaunchKernelGGL(k_galerkin_coarse, dim3((unsigned)nEc), dim3(64), 0, s, F.g, C.g, F.Kel, C.Kel);
+            hipLaunchKernelGGL((k_galerkin_coarse<false>), dim3((unsigned)nEc), dim3(64), 0, s, F.g, C.g, F.Kel, C.Kel,
+                               mg.lv[0].g, nullptr, nullptr, nullptr, nEc);
             count_launch(g, 8.0 * 576 * (9.0 * nEc), 2.0 * 0.18 * 8 * 64 * 64 * 9 * nEc);
         }
         // coarse ghost element layer above <- upper neighbour's first own layer
         const long clay = (long)C.g.ex * C.g.ey;
         // (one contiguous block of 576*clay doubles, cut into rows of `clay` so that it fits the staging buffers)
         TP_TRY(exchange_segments(g, C.Kel, nullptr, nullptr, C.Kel + 576 * clay * C.g.ez_own, clay, 576, clay));
-        const int gn = (int)((C.g.owned_nodes() + BLK - 1) / BLK);
-        if (C.kind == LV_MACRO) {
-            if (e->nflag_all) {
-                hipLaunchKernelGGL(k_macro_delta, dim3((int)(((long)e->nflag_all * 576 + BLK - 1) / BLK)), dim3(BLK), 0, s,
-                                   F.g, C.g, e->d_E, e->d_M, C.Kel, e->d_flag_all, e->nflag_all, e->d_dK);
-                count_launch(g);
-            }
+        if (C.kind == LV_MACRO) {  // (not reached: handled above)
             hipLaunchKernelGGL(k_elem_diag, dim3(gn), dim3(BLK), 0, s, C.g, C.Kel, C.dinv);
             count_launch(g, 8.0 * (24.0 + 3.0) * C.g.owned_nodes(), 24.0 * C.g.owned_nodes());
         } else {
