@@ -56,6 +56,71 @@ inline void host_child_matrices(const double *KE, double *M) {
                     }
 }
 
+// M2[(c2*8 + g)][576] = (W_c2 (x) I3)^T M_g (W_c2 (x) I3): the level-2 element matrix is linear in the 64 fine moduli
+// below it, K_E2 = sum_{c2, g} E_{c2 g} M2[c2][g]   (host, once per KE)
+inline void host_grandchild_matrices(const double *M, double *M2) {
+    double W[512];
+    host_W(W);
+    std::vector<double> T(576);
+    for (int c2 = 0; c2 < 8; c2++)
+        for (int g = 0; g < 8; g++) {
+            const double *Mg = M + g * 576;
+            // T = Mg (W_c2 (x) I3): columns contracted
+            for (int ar = 0; ar < 24; ar++)
+                for (int J = 0; J < 8; J++)
+                    for (int cc = 0; cc < 3; cc++) {
+                        double sacc = 0.0;
+                        for (int b = 0; b < 8; b++) sacc += Mg[ar * 24 + 3 * b + cc] * W[(c2 * 8 + b) * 8 + J];
+                        T[ar * 24 + 3 * J + cc] = sacc;
+                    }
+            double *out = M2 + (size_t)(c2 * 8 + g) * 576;
+            for (int I = 0; I < 8; I++)
+                for (int r = 0; r < 3; r++)
+                    for (int col = 0; col < 24; col++) {
+                        double sacc = 0.0;
+                        for (int a = 0; a < 8; a++) sacc += W[(c2 * 8 + a) * 8 + I] * T[(3 * a + r) * 24 + col];
+                        out[(3 * I + r) * 24 + col] = sacc;
+                    }
+        }
+}
+
+// ---- level 0 -> 2 in one step for level-2 elements without flagged children: thread = matrix entry (576 per
+// workgroup), its 64 constants M2[.][entry] live in registers, the 64 moduli are workgroup-uniform (scalar loads):
+// 64 fma per entry, no LDS, no intermediate level-1 matrices.
+__global__ __launch_bounds__(576) void k_galerkin_l2_fast(Geom g0, Geom g2, const double *__restrict__ E,
+                                                          const double *__restrict__ M2, double *__restrict__ Kc,
+                                                          int nel) {
+    const int t = threadIdx.x;
+    double m2[64];
+#pragma unroll
+    for (int q = 0; q < 64; q++) m2[q] = M2[(size_t)q * 576 + t];
+    const long sx = g0.ex, sxy = (long)g0.ex * g0.ey;  // row / layer pitch of the fine moduli
+    // every own element is written here; the few with a flagged level-1 child are overwritten afterwards by the
+    // generic construction (stream order), which spares a per-element flag load in this loop
+    for (int el = blockIdx.x; el < nel; el += gridDim.x) {
+        const int I2 = el % g2.ex, J2 = (el / g2.ex) % g2.ey, K2 = el / (g2.ex * g2.ey);
+        // the 4 x 4 x 4 block of fine moduli: 16 rows of 4 contiguous values, walked with pointer increments (the
+        // addresses are workgroup-uniform: scalar loads, little scalar arithmetic)
+        const double *__restrict__ pz = E + (long)(4 * I2) + sx * (4 * J2) + sxy * (4 * K2);
+        double sacc = 0.0;
+#pragma unroll
+        for (int z = 0; z < 4; z++) {
+            const double *__restrict__ py = pz;
+#pragma unroll
+            for (int y = 0; y < 4; y++) {
+#pragma unroll
+                for (int x = 0; x < 4; x++) {
+                    const int c2 = (x >> 1) + 2 * (y >> 1) + 4 * (z >> 1), g = (x & 1) + 2 * (y & 1) + 4 * (z & 1);
+                    sacc = fma(py[x], m2[c2 * 8 + g], sacc);
+                }
+                py += sx;
+            }
+            pz += sxy;
+        }
+        Kc[(long)el * 576 + t] = sacc;
+    }
+}
+
 // ---- level 0 -> 1, fast path: one 192-thread workgroup per own coarse element, 3 entries per thread
 __global__ __launch_bounds__(192) void k_galerkin_fine_fast(Geom gf, Geom gc, const double *__restrict__ E,
                                                             const double *__restrict__ M, double *__restrict__ Kel) {
@@ -138,7 +203,7 @@ template <bool FROM_E>
 __global__ __launch_bounds__(64) void k_galerkin_coarse(Geom gf, Geom gc, const double *__restrict__ Kf,
                                                         double *__restrict__ Kc, Geom g0, const double *__restrict__ E,
                                                         const double *__restrict__ M, const int *__restrict__ fidx,
-                                                        long nel) {
+                                                        long nel, const int *__restrict__ list) {
     __shared__ double A[576], B[576];
     const int t = threadIdx.x;
     // FROM_E: this thread's 9 entries of the 8 constant child matrices stay in registers for all elements of the block
@@ -149,7 +214,8 @@ __global__ __launch_bounds__(64) void k_galerkin_coarse(Geom gf, Geom gc, const 
 #pragma unroll
             for (int g8 = 0; g8 < 8; g8++) Mr[q][g8] = M[g8 * 576 + t + 64 * q];
     }
-    for (long el = blockIdx.x; el < nel; el += gridDim.x) {  // own coarse elements
+    for (long idx = blockIdx.x; idx < nel; idx += gridDim.x) {  // own coarse elements (or the listed ones)
+        const long el = list ? list[idx] : idx;
         const int Ie = (int)(el % gc.ex), Je = (int)((el / gc.ex) % gc.ey), Ke = (int)(el / ((long)gc.ex * gc.ey));
         double acc[9];
 #pragma unroll

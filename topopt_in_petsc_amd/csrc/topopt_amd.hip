@@ -247,6 +247,10 @@ struct tp_elasticity {
     // list order, then the ghost-layer ones received from the upper neighbour) and the element -> row map
     double *d_KelF;
     int *d_fidx1;
+    double *d_M2;            // 64 grand-child matrices (level 0 -> 2 in one step)
+    uint8_t *d_flag2;        // own level-2 elements with a flagged level-1 child
+    int *d_list2;            // ... as a list
+    int nlist2;
     int nx_first;            // max over ranks of the flagged elements in a rank's first own level-1 layer
     int nflagged;
     double *d_bN;            // RHS .* N scratch
@@ -303,6 +307,10 @@ extern "C" int tp_elasticity_create(tp_elasticity **out, tp_grid *g, const tp_so
     e->d_dK = e->d_corr = e->d_corr_tmp = nullptr;
     e->d_KelF = nullptr;
     e->d_fidx1 = nullptr;
+    e->d_M2 = nullptr;
+    e->d_flag2 = nullptr;
+    e->d_list2 = nullptr;
+    e->nlist2 = 0;
     e->nx_first = 0;
     e->nflag_all = 0;
     hex8_stiffness_box(g->o.hx, g->o.hy, g->o.hz, o->nu, e->KE);
@@ -319,6 +327,12 @@ extern "C" int tp_elasticity_create(tp_elasticity **out, tp_grid *g, const tp_so
     TP_HIP(hipMalloc((void **)&e->d_N, sizeof(double) * 3 * (size_t)q.nodes()));
     TP_HIP(hipMemcpy(e->d_KE, e->KE, sizeof(double) * 576, hipMemcpyHostToDevice));
     TP_HIP(hipMemcpy(e->d_M, M.data(), sizeof(double) * 8 * 576, hipMemcpyHostToDevice));
+    {
+        std::vector<double> M2((size_t)64 * 576);
+        host_grandchild_matrices(M.data(), M2.data());
+        TP_HIP(hipMalloc((void **)&e->d_M2, sizeof(double) * M2.size()));
+        TP_HIP(hipMemcpy(e->d_M2, M2.data(), sizeof(double) * M2.size(), hipMemcpyHostToDevice));
+    }
     TP_HIP(hipMemset(e->d_mask, 0, (size_t)q.nodes()));
     for (int l = 0; l < e->mg.nlv; l++) {
         Level<3> &L = e->mg.lv[l];
@@ -373,7 +387,7 @@ extern "C" int tp_elasticity_destroy(tp_elasticity *e) {
     for (void *p : {(void *)e->d_KE, (void *)e->d_M, (void *)e->d_E, (void *)e->d_mask, (void *)e->d_bN, (void *)e->d_N,
                     (void *)e->d_flagged, (void *)e->d_colmask, (void *)e->d_flag_all, (void *)e->d_corr_nodes,
                     (void *)e->d_corr_adj, (void *)e->d_dK, (void *)e->d_corr, (void *)e->d_corr_tmp, (void *)e->d_KelF,
-                    (void *)e->d_fidx1})
+                    (void *)e->d_fidx1, (void *)e->d_M2, (void *)e->d_flag2, (void *)e->d_list2})
         (void)hipFree(p);
     delete e;
     return TP_OK;
@@ -481,6 +495,34 @@ extern "C" int tp_elasticity_set_bc(tp_elasticity *e, const double *N) {
         }
         TP_HIP(hipMalloc((void **)&e->d_fidx1, sizeof(int) * fidx.size()));
         TP_HIP(hipMemcpy(e->d_fidx1, fidx.data(), sizeof(int) * fidx.size(), hipMemcpyHostToDevice));
+        (void)hipFree(e->d_flag2);
+        (void)hipFree(e->d_list2);
+        e->d_flag2 = nullptr;
+        e->d_list2 = nullptr;
+        e->nlist2 = 0;
+        if (e->mg.nlv > 2) {  // own level-2 elements with a flagged child take the generic construction
+            Geom c2 = make_geom(g, 2);
+            std::vector<uint8_t> f2((size_t)c2.own_elems(), 0);
+            std::vector<int> l2;
+            for (int K = 0; K < c2.ez_own; K++)
+                for (int J = 0; J < c2.ey; J++)
+                    for (int I = 0; I < c2.ex; I++) {
+                        bool any = false;
+                        for (int ch = 0; ch < 8 && !any; ch++)
+                            any = fidx[(size_t)((2 * I + (ch & 1)) + (long)c.ex * ((2 * J + ((ch >> 1) & 1)) + (long)c.ey * (2 * K + (ch >> 2))))] >= 0;
+                        if (any) {
+                            f2[(size_t)(I + (long)c2.ex * (J + (long)c2.ey * K))] = 1;
+                            l2.push_back(I + c2.ex * (J + c2.ey * K));
+                        }
+                    }
+            TP_HIP(hipMalloc((void **)&e->d_flag2, f2.size() + 1));
+            TP_HIP(hipMemcpy(e->d_flag2, f2.data(), f2.size(), hipMemcpyHostToDevice));
+            e->nlist2 = (int)l2.size();
+            if (!l2.empty()) {
+                TP_HIP(hipMalloc((void **)&e->d_list2, sizeof(int) * l2.size()));
+                TP_HIP(hipMemcpy(e->d_list2, l2.data(), sizeof(int) * l2.size(), hipMemcpyHostToDevice));
+            }
+        }
         {
             const size_t rows = fl.size() + 2 * (size_t)e->nx_first + 1;
             TP_HIP(hipMalloc((void **)&e->d_KelF, sizeof(double) * 576 * rows));
@@ -572,15 +614,29 @@ extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, dou
                 count_launch(g);
             }
         } else if (l == 2 && macro1) {
-            // children = level-1 elements, formed on the fly from the fine moduli (or read from the compact rows)
-            static const long nb_env = getenv("TP_GAL_BLOCKS") ? atol(getenv("TP_GAL_BLOCKS")) : 4096;
-            const unsigned nblk = (unsigned)(nEc < nb_env ? nEc : nb_env);  // several elements per workgroup: the child
-            hipLaunchKernelGGL((k_galerkin_coarse<true>), dim3(nblk), dim3(64), 0, s, F.g, C.g, e->d_KelF, C.Kel,  // matrices' constants
-                               mg.lv[0].g, e->d_E, e->d_M, e->d_fidx1, nEc);                                     // live in registers
-            count_launch(g, 8.0 * 64 * nEc + 8.0 * 576 * nEc, 2.0 * (8 * 576 * 8 + 0.18 * 8 * 64 * 64 * 9) * nEc);
+            // all 64 fine moduli below an element at once (constants in registers); elements with a flagged
+            // level-1 child go through the generic contraction with the compact rows
+            static const bool no_fast2 = getenv("TP_NO_L2_FAST") != nullptr;
+            if (!no_fast2) {
+                static const long nb2_env = getenv("TP_L2_BLOCKS") ? atol(getenv("TP_L2_BLOCKS")) : 512;
+                const unsigned nb2 = (unsigned)(nEc < nb2_env ? nEc : nb2_env);
+                hipLaunchKernelGGL(k_galerkin_l2_fast, dim3(nb2), dim3(576), 0, s, mg.lv[0].g, C.g, e->d_E, e->d_M2,
+                                   C.Kel, (int)nEc);
+                count_launch(g, 8.0 * 64 * nEc + 8.0 * 576 * nEc, 2.0 * 64 * 576 * nEc);
+                if (e->nlist2) {
+                    hipLaunchKernelGGL((k_galerkin_coarse<true>), dim3((unsigned)e->nlist2), dim3(64), 0, s, F.g, C.g,
+                                       e->d_KelF, C.Kel, mg.lv[0].g, e->d_E, e->d_M, e->d_fidx1, (long)e->nlist2, e->d_list2);
+                    count_launch(g);
+                }
+            } else {
+                const unsigned nblk = (unsigned)(nEc < 4096 ? nEc : 4096);
+                hipLaunchKernelGGL((k_galerkin_coarse<true>), dim3(nblk), dim3(64), 0, s, F.g, C.g, e->d_KelF, C.Kel,
+                                   mg.lv[0].g, e->d_E, e->d_M, e->d_fidx1, nEc, (const int *)nullptr);
+                count_launch(g, 8.0 * 64 * nEc + 8.0 * 576 * nEc, 2.0 * (8 * 576 * 8 + 0.18 * 8 * 64 * 64 * 9) * nEc);
+            }
         } else {
             hipLaunchKernelGGL((k_galerkin_coarse<false>), dim3((unsigned)nEc), dim3(64), 0, s, F.g, C.g, F.Kel, C.Kel,
-                               mg.lv[0].g, nullptr, nullptr, nullptr, nEc);
+                               mg.lv[0].g, nullptr, nullptr, nullptr, nEc, (const int *)nullptr);
             count_launch(g, 8.0 * 576 * (9.0 * nEc), 2.0 * 0.18 * 8 * 64 * 64 * 9 * nEc);
         }
         // coarse ghost element layer above <- upper neighbour's first own layer
