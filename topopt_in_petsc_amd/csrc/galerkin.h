@@ -149,6 +149,11 @@ __global__ __launch_bounds__(64) void k_galerkin_fine_masked(Geom gf, Geom gc, c
                                                              const uint8_t *__restrict__ mask,
                                                              const int *__restrict__ list, double *__restrict__ Kel,
                                                              int compact) {
+    // interpolation weights and KE in LDS: both are indexed per lane (constant memory would serialise)
+    __shared__ double s_W[512], s_KE[576];
+    for (int q = threadIdx.x; q < 512; q += 64) s_W[q] = c_W[q];
+    for (int q = threadIdx.x; q < 576; q += 64) s_KE[q] = KE[q];
+    __syncthreads();
     const long t = list[blockIdx.x];
     const long slot = compact ? (long)blockIdx.x : t;  // compact: the matrix of the f-th listed element is row f
     const int Ie = (int)(t % gc.ex), Je = (int)((t / gc.ex) % gc.ey), Ke = (int)(t / ((long)gc.ex * gc.ey));
@@ -160,19 +165,19 @@ __global__ __launch_bounds__(64) void k_galerkin_fine_masked(Geom gf, Geom gc, c
         const int i = 2 * Ie + (c & 1), j = 2 * Je + ((c >> 1) & 1), k = 2 * Ke + ((c >> 2) & 1);
         const double Ec = E[(long)i + (long)gf.ex * (j + (long)gf.ey * k)];
         for (int a = 0; a < 8; a++) {
-            const double wa = c_W[(c * 8 + a) * 8 + I];
+            const double wa = s_W[(c * 8 + a) * 8 + I];
             if (wa == 0.0) continue;
             const int ia = i + c_LX[a], ja = j + c_LY[a], ka = k + c_LZ[a];
             const unsigned ma = mask[(long)ia + (long)gf.nx * (ja + (long)gf.ny * ka)];
             for (int b = 0; b < 8; b++) {
-                const double wb = c_W[(c * 8 + b) * 8 + J];
+                const double wb = s_W[(c * 8 + b) * 8 + J];
                 if (wb == 0.0) continue;
                 const unsigned mb = mask[(long)(i + c_LX[b]) + (long)gf.nx * ((j + c_LY[b]) + (long)gf.ny * (k + c_LZ[b]))];
                 const double w = wa * wb * Ec;
                 for (int r = 0; r < 3; r++)
                     for (int cc = 0; cc < 3; cc++)
                         if (!((ma >> r) & 1u) && !((mb >> cc) & 1u))
-                            acc[r * 3 + cc] = fma(w, KE[(3 * a + r) * 24 + 3 * b + cc], acc[r * 3 + cc]);
+                            acc[r * 3 + cc] = fma(w, s_KE[(3 * a + r) * 24 + 3 * b + cc], acc[r * 3 + cc]);
             }
             if (ma) {
                 // Dirichlet identity, shared between the elements around the node:
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(64) void k_galerkin_fine_masked(Geom gf, Geom gc, c
                 const int kg = ka + gf.gz0;
                 const int mult = ((ia == 0 || ia == gf.nx - 1) ? 1 : 2) * ((ja == 0 || ja == gf.ny - 1) ? 1 : 2) *
                                  ((kg == 0 || kg == gf.nz_glob - 1) ? 1 : 2);
-                const double w = wa * c_W[(c * 8 + a) * 8 + J] / (double)mult;
+                const double w = wa * s_W[(c * 8 + a) * 8 + J] / (double)mult;
                 for (int r = 0; r < 3; r++)
                     if ((ma >> r) & 1u) acc[r * 3 + r] += w;
             }
