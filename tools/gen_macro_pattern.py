@@ -6,21 +6,53 @@ element operator written in the Walsh-Hadamard basis of BOTH the 8 coarse corner
     ehat_sigma = sum_c (-1)^{|sigma & c|} E_c,    G_sigma = H (1/8 sum_c (-1)^{|sigma & c|} W_c^T KE W_c) H^T / 64.
 
 The pattern only depends on the reflection symmetries of a box element; it is taken from two
-anisotropic boxes (identical; a cube only adds accidental zeros).  Values are computed at run time (galerkin.h)."""
+anisotropic boxes (identical; a cube only adds accidental zeros).  Values are computed at run time (matfree_tile.h: make_macro_tensor)."""
 import os
 import sys
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-from oracle import oracle as O   # noqa: E402  (generator only; the product does not use the oracle)
+
+
+def hex8_ke_box(nu, hx, hy, hz):
+    """24x24 stiffness of a box hex8 element (E = 1, 2x2x2 Gauss), reference corner order; only its symmetry
+    structure matters here"""
+    lam, mu = nu / ((1 + nu) * (1 - 2 * nu)), 1 / (2 * (1 + nu))
+    Cm = np.zeros((6, 6))
+    Cm[:3, :3] = lam
+    Cm[np.arange(3), np.arange(3)] += 2 * mu
+    Cm[np.arange(3, 6), np.arange(3, 6)] = mu
+    xi = np.array([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]], float)
+    KE = np.zeros((24, 24))
+    gp = 1 / np.sqrt(3)
+    for a in (-gp, gp):
+        for b in (-gp, gp):
+            for c in (-gp, gp):
+                p = np.array([a, b, c])
+                dN = np.zeros((3, 8))
+                for n in range(8):
+                    for d in range(3):
+                        f = 0.125 * xi[n, d]
+                        for o in range(3):
+                            if o != d:
+                                f *= 1 + xi[n, o] * p[o]
+                        dN[d, n] = f
+                dN = dN / (np.array([hx, hy, hz])[:, None] / 2)
+                B = np.zeros((6, 24))
+                for n in range(8):
+                    B[0, 3 * n], B[1, 3 * n + 1], B[2, 3 * n + 2] = dN[0, n], dN[1, n], dN[2, n]
+                    B[3, 3 * n], B[3, 3 * n + 1] = dN[1, n], dN[0, n]
+                    B[4, 3 * n + 1], B[4, 3 * n + 2] = dN[2, n], dN[1, n]
+                    B[5, 3 * n], B[5, 3 * n + 2] = dN[2, n], dN[0, n]
+                KE += B.T @ Cm @ B * (hx * hy * hz / 8)
+    return KE
 
 M2A = [0, 1, 3, 2, 4, 5, 7, 6]
 
 
 def tensors(nu, hx, hy, hz):
-    KE = np.array(O.hex8_ke_box(nu, hx, hy, hz)).reshape(24, 24)
+    KE = hex8_ke_box(nu, hx, hy, hz)
     P = np.zeros((24, 24))
     for m in range(8):
         for c in range(3):
