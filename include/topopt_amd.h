@@ -77,6 +77,8 @@ typedef struct tp_comm {
      * from now on (same message sizes and order, so ranks may differ in their choice); else error. */
     int (*exchange_direct)(void *user, const double *to_lo, double *from_lo, const double *to_hi, double *from_hi,
                            long n);
+    /* optional: in-place sum over ranks of p[0..n), p any [dev] address (NULL -> staged through `red`) */
+    int (*allreduce_inplace)(void *user, double *p, int n);
 } tp_comm;
 
 /* ---- grid / partition --------------------------------------------------- */

@@ -50,7 +50,8 @@ class SlabComm:
         p = lambda t: t.data_ptr()
         self.c_struct = _lib.Comm(None, p(self.send_lo), p(self.send_hi), p(self.recv_lo), p(self.recv_hi),
                                   p(self.red), self.cap, self._ex_cb, self._ar_cb, p(self.gather), self._ag_cb,
-                                  self._dx_cb if self.device.type == "cuda" else _lib.DIRECT_FN(0))
+                                  self._dx_cb if self.device.type == "cuda" else _lib.DIRECT_FN(0),
+                                  _lib.INPLACE_FN(0))   # in-place reductions: only the in-library RCCL path has them
 
     # ---- python-level API (also used directly by the CPU tests) -----------
     def exchange(self, n):

@@ -50,9 +50,13 @@ inline int finish_reduction(tp_grid *g, int nblocks, int slot) {
     hipLaunchKernelGGL(k_reduce_final<NV>, dim3(1), dim3(BLK), 0, g->stream, g->partials, nblocks, g->scal + slot);
     count_launch(g);
     if (g->has_comm) {
-        TP_HIP(hipMemcpyAsync(g->comm.red, g->scal + slot, sizeof(double) * NV, hipMemcpyDeviceToDevice, g->stream));
-        if (g->comm.allreduce_sum(g->comm.user, NV)) return TP_ERR_COMM;
-        TP_HIP(hipMemcpyAsync(g->scal + slot, g->comm.red, sizeof(double) * NV, hipMemcpyDeviceToDevice, g->stream));
+        if (g->comm.allreduce_inplace) {  // the CG scalars are reduced where they live
+            if (g->comm.allreduce_inplace(g->comm.user, g->scal + slot, NV)) return TP_ERR_COMM;
+        } else {
+            TP_HIP(hipMemcpyAsync(g->comm.red, g->scal + slot, sizeof(double) * NV, hipMemcpyDeviceToDevice, g->stream));
+            if (g->comm.allreduce_sum(g->comm.user, NV)) return TP_ERR_COMM;
+            TP_HIP(hipMemcpyAsync(g->scal + slot, g->comm.red, sizeof(double) * NV, hipMemcpyDeviceToDevice, g->stream));
+        }
     }
     return TP_OK;
 }

@@ -75,6 +75,12 @@ static int rccl_allreduce(void *u, int n) {
     c->n_reductions++;
     return 0;
 }
+static int rccl_allreduce_inplace(void *u, double *p, int n) {
+    RcclComm *c = (RcclComm *)u;
+    TP_NCCL(rccl_api().AllReduce(p, p, (size_t)n, ncclDouble, ncclSum, c->comm, c->stream));
+    c->n_reductions++;
+    return 0;
+}
 static int rccl_allgather(void *u, long n) {
     RcclComm *c = (RcclComm *)u;
     TP_NCCL(rccl_api().AllGather(c->hooks.send_lo, c->hooks.gather, (size_t)n, ncclDouble, c->comm, c->stream));
@@ -148,6 +154,7 @@ inline int rccl_comm_create(RcclComm **out, const void *id128, int rank, int nra
     h.allreduce_sum = rccl_allreduce;
     h.allgather = rccl_allgather;
     h.exchange_direct = rccl_exchange_direct;
+    h.allreduce_inplace = rccl_allreduce_inplace;
     *out = c;
     return TP_OK;
 }

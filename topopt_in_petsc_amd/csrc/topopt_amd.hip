@@ -101,7 +101,8 @@ extern "C" int tp_rccl_selftest(int device, void *stream, long n, double *max_er
         (void)hipStreamSynchronize(st);
         for (long i = 0; i < n; i++) err = fmax(err, fmax(fabs(a[i] - (9000.0 + i)), fabs(b[i] - (7000.0 + i))));
         hipLaunchKernelGGL(k_selftest_fill, dim3(1), dim3(64), 0, st, h.red, 16, 3.0);
-        rc = h.allreduce_sum(h.user, 16);
+        rc = h.allreduce_sum(h.user, 8);
+        if (!rc) rc = h.allreduce_inplace(h.user, h.red + 8, 8);
     }
     if (!rc) {
         hipLaunchKernelGGL(k_selftest_fill, dim3(64), dim3(256), 0, st, h.send_lo, n, 11000.0);

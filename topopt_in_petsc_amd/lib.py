@@ -38,13 +38,14 @@ class SolverOpts(C.Structure):
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_long)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
 DIRECT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long)
+INPLACE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int)
 
 
 class Comm(C.Structure):
     _fields_ = [("user", C.c_void_p), ("send_lo", C.c_void_p), ("send_hi", C.c_void_p), ("recv_lo", C.c_void_p),
                 ("recv_hi", C.c_void_p), ("red", C.c_void_p), ("cap", C.c_long), ("exchange", EXCHANGE_FN),
                 ("allreduce_sum", ALLREDUCE_FN), ("gather", C.c_void_p), ("allgather", EXCHANGE_FN),
-                ("exchange_direct", DIRECT_FN)]
+                ("exchange_direct", DIRECT_FN), ("allreduce_inplace", INPLACE_FN)]
 
 
 # every symbol include/topopt_amd.h declares: (restype, argtypes)
