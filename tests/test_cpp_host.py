@@ -90,3 +90,58 @@ def test_reference_code_in_petsc_dialect_matches_the_python_mirror():
         assert r[1] == pytest.approx(gx, rel=1e-12, abs=1e-15)
         assert r[2] == pytest.approx(float(df.sum()), rel=1e-11)
         assert r[3] == pytest.approx(float(le.U.norm()), rel=1e-12)
+
+
+@pytest.mark.gpu
+def test_petsc_shim_vec_operations():
+    """Vec surface of the adapter driven through ctypes: the BLAS-1 calls of the reference's per-iteration code"""
+    import ctypes as C
+    import numpy as np
+    _build()
+    L = C.CDLL(os.path.join(ROOT, "topopt_in_petsc_amd", "libtopopt_petsc_shim.so"))
+    vp, d = C.c_void_p, C.c_double
+    da, x, y, w = vp(), vp(), vp(), vp()
+    L.DMDACreate3d.argtypes = [C.c_int] * 5 + [C.c_int] * 8 + [vp, vp, vp, C.POINTER(vp)]
+    assert L.DMDACreate3d(0, 0, 0, 0, 1, 9, 5, 5, -1, -1, -1, 3, 1, None, None, None, C.byref(da)) == 0
+    L.DMDASetUniformCoordinates.argtypes = [vp] + [d] * 6
+    assert L.DMDASetUniformCoordinates(da, 0, 2, 0, 1, 0, 1) == 0
+    for f in ("DMCreateGlobalVector", "VecDuplicate"):
+        getattr(L, f).argtypes = [vp, C.POINTER(vp)]
+    assert L.DMCreateGlobalVector(da, C.byref(x)) == 0 and L.VecDuplicate(x, C.byref(y)) == 0 and L.VecDuplicate(x, C.byref(w)) == 0
+    n = C.c_int()
+    L.VecGetSize.argtypes = [vp, C.POINTER(C.c_int)]
+    L.VecGetSize(x, C.byref(n))
+    assert n.value == 3 * 9 * 5 * 5
+    L.VecGetArray.argtypes = L.VecRestoreArray.argtypes = [vp, C.POINTER(C.POINTER(d))]
+    rng = np.random.default_rng(5)
+    a, b = rng.standard_normal(n.value), rng.standard_normal(n.value) + 3.0
+    for v, src in ((x, a), (y, b)):
+        p = C.POINTER(d)()
+        assert L.VecGetArray(v, C.byref(p)) == 0
+        np.ctypeslib.as_array(p, shape=(n.value,))[:] = src
+        assert L.VecRestoreArray(v, C.byref(p)) == 0
+    val = d()
+    L.VecDot.argtypes = [vp, vp, C.POINTER(d)]
+    assert L.VecDot(x, y, C.byref(val)) == 0 and val.value == pytest.approx(a @ b, rel=1e-13)
+    L.VecNorm.argtypes = [vp, C.c_int, C.POINTER(d)]
+    assert L.VecNorm(x, 1, C.byref(val)) == 0 and val.value == pytest.approx(np.linalg.norm(a), rel=1e-13)
+    assert L.VecNorm(x, 3, C.byref(val)) == 56          # NORM_INFINITY: not part of the path -> PETSC_ERR_SUP
+    L.VecSum.argtypes = [vp, C.POINTER(d)]
+    assert L.VecSum(y, C.byref(val)) == 0 and val.value == pytest.approx(b.sum(), rel=1e-13)
+    L.VecAXPY.argtypes = [vp, d, vp]
+    L.VecPointwiseDivide.argtypes = L.VecPointwiseMult.argtypes = [vp, vp, vp]
+    L.VecScale.argtypes = [vp, d]
+    assert L.VecAXPY(y, -0.5, x) == 0                       # y = b - a/2
+    assert L.VecPointwiseDivide(w, x, y) == 0               # w = a / (b - a/2)
+    assert L.VecPointwiseMult(w, w, y) == 0                 # w = a
+    assert L.VecScale(w, 2.0) == 0
+    p = C.POINTER(d)()
+    L.VecGetArray(w, C.byref(p))
+    got = np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+    L.VecRestoreArray(w, C.byref(p))
+    assert np.allclose(got, 2.0 * a, rtol=1e-14, atol=1e-14)
+    L.VecDestroy.argtypes = [C.POINTER(vp)]
+    for v in (x, y, w):
+        L.VecDestroy(C.byref(v))
+    L.DMDestroy.argtypes = [C.POINTER(vp)]
+    L.DMDestroy(C.byref(da))
