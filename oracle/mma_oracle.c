@@ -23,11 +23,58 @@ typedef struct {
     double *a, *c, *d, *y, *lam, *mu, *b, *grad, *s, *Hess;
     double z;
     double *L, *U, *alpha, *beta, *p0, *q0, *pij, *qij, *xo1, *xo2; /* pij/qij: m blocks of n */
+    int dev_order; /* 0: the reference's left-to-right sums and pow(); > 0: the DEVICE's operation order (workgroups) */
 } orc_mma_t;
 
 static double dmin(double a, double b) { return a < b ? a : b; }
 static double dmax(double a, double b) { return a > b ? a : b; }
 static double dabs(double a) { return a > 0 ? a : -1.0 * a; }
+
+/* ---- optional: the summation order of the HIP implementation (csrc/common.h: block_sum, csrc/mg.h:
+ * k_reduce_multi), so that device and oracle can be compared BIT FOR BIT.  nb workgroups of 256 threads stride
+ * through the terms; per workgroup a 64-lane shuffle-down tree per wave, then the 4 wave sums left to right;
+ * the workgroup partials are summed by one workgroup in the same way.  The default (dev_order = 0) is the
+ * reference's plain left-to-right loop. */
+static double dev_block_sum(const double *v256) {
+    double w[4];
+    for (int wv = 0; wv < 4; wv++) {
+        double l[64];
+        for (int i = 0; i < 64; i++) l[i] = v256[wv * 64 + i];
+        for (int off = 32; off > 0; off >>= 1)
+            for (int i = 0; i + off < 64; i++) l[i] = l[i] + l[i + off];
+        w[wv] = l[0];
+    }
+    double t = 0.0;
+    for (int wv = 0; wv < 4; wv++) t += w[wv];
+    return t;
+}
+static double dev_order_sum(const double *term, long n, int nb) {
+    double *part = (double *)calloc((size_t)nb, sizeof(double));
+    for (int b = 0; b < nb; b++) {
+        double v[256];
+        for (int t = 0; t < 256; t++) {
+            double acc = 0.0;
+            for (long i = (long)b * 256 + t; i < n; i += (long)nb * 256) acc += term[i];
+            v[t] = acc;
+        }
+        part[b] = dev_block_sum(v);
+    }
+    double v[256];
+    for (int t = 0; t < 256; t++) {
+        double acc = 0.0;
+        for (int b = t; b < nb; b += 256) acc += part[b];
+        v[t] = acc;
+    }
+    free(part);
+    return dev_block_sum(v);
+}
+static double sum_terms(const orc_mma_t *M, const double *term, long n) {
+    if (M->dev_order > 0) return dev_order_sum(term, n, M->dev_order);
+    double sacc = 0.0;
+    for (long i = 0; i < n; i++) sacc += term[i];
+    return sacc;
+}
+static double cube(const orc_mma_t *M, double v) { return M->dev_order > 0 ? v * v * v : pow(v, 3.0); }
 
 /* MMA::MMA(n, m, x): a = 0, c = 1000, d = 0 (MMA.cc:108-190); k counts the calls to Update */
 ORC_API orc_mma_t *orc_mma_create(long n, int m, const double *x) {
@@ -68,6 +115,8 @@ ORC_API orc_mma_t *orc_mma_create(long n, int m, const double *x) {
     memcpy(M->xo2, x, nb);
     return M;
 }
+/* nb = number of 256-thread workgroups of the device kernels (csrc/mma.h: grid_for(n, 1024)); 0 = reference order */
+ORC_API void orc_mma_set_device_order(orc_mma_t *M, int nb) { M->dev_order = nb; }
 ORC_API void orc_mma_destroy(orc_mma_t *M) {
     if (!M) return;
     free(M->a); free(M->c); free(M->d); free(M->y); free(M->lam); free(M->mu); free(M->b); free(M->grad); free(M->s);
@@ -140,12 +189,13 @@ static void gensub(orc_mma_t *M, const double *xv, const double *dfdx, const dou
             M->qij[(size_t)j * n + i] = pow(xv[i] - Li, 2.0) * dm;
         }
     }
+    double *term = (double *)malloc(sizeof(double) * (size_t)n);
     for (int j = 0; j < m; j++) {
-        double bj = 0.0;
         for (long i = 0; i < n; i++)
-            bj += M->pij[(size_t)j * n + i] / (M->U[i] - xv[i]) + M->qij[(size_t)j * n + i] / (xv[i] - M->L[i]);
-        M->b[j] = bj - gx[j];
+            term[i] = M->pij[(size_t)j * n + i] / (M->U[i] - xv[i]) + M->qij[(size_t)j * n + i] / (xv[i] - M->L[i]);
+        M->b[j] = sum_terms(M, term, n) - gx[j];
     }
+    free(term);
 }
 
 static void xyz_of_lambda(orc_mma_t *M, double *xv) {
@@ -173,12 +223,13 @@ static void xyz_of_lambda(orc_mma_t *M, double *xv) {
 
 static void dual_grad(orc_mma_t *M, const double *xv) {
     long n = M->n;
+    double *term = (double *)malloc(sizeof(double) * (size_t)n);
     for (int j = 0; j < M->m; j++) {
-        double g = 0.0;
         for (long i = 0; i < n; i++)
-            g += M->pij[(size_t)j * n + i] / (M->U[i] - xv[i]) + M->qij[(size_t)j * n + i] / (xv[i] - M->L[i]);
-        M->grad[j] = g - M->b[j] - M->a[j] * M->z - M->y[j];
+            term[i] = M->pij[(size_t)j * n + i] / (M->U[i] - xv[i]) + M->qij[(size_t)j * n + i] / (xv[i] - M->L[i]);
+        M->grad[j] = sum_terms(M, term, n) - M->b[j] - M->a[j] * M->z - M->y[j];
     }
+    free(term);
 }
 
 static void dual_hess(orc_mma_t *M, const double *xv) {
@@ -194,16 +245,17 @@ static void dual_hess(orc_mma_t *M, const double *xv) {
             PQ[i * m + j] = M->pij[(size_t)j * n + i] / pow(M->U[i] - xv[i], 2.0) -
                             M->qij[(size_t)j * n + i] / pow(xv[i] - M->L[i], 2.0);
         }
-        df2[i] = -1.0 / (2.0 * pj / pow(M->U[i] - xv[i], 3.0) + 2.0 * qj / pow(xv[i] - M->L[i], 3.0));
+        df2[i] = -1.0 / (2.0 * pj / cube(M, M->U[i] - xv[i]) + 2.0 * qj / cube(M, xv[i] - M->L[i]));
         double xp = (sqrt(pj) * M->L[i] + sqrt(qj) * M->U[i]) / (sqrt(pj) + sqrt(qj));
         if (xp < M->alpha[i]) df2[i] = 0.0;
         if (xp > M->beta[i]) df2[i] = 0.0;
     }
     for (int i = 0; i < m; i++)
         for (int j = 0; j < m; j++) {
-            double h = 0.0;
-            for (long k = 0; k < n; k++) h += (PQ[k * m + i] * df2[k]) * PQ[k * m + j];
-            M->Hess[i * m + j] = h;
+            double *term = (double *)malloc(sizeof(double) * (size_t)n);
+            for (long k = 0; k < n; k++) term[k] = (PQ[k * m + i] * df2[k]) * PQ[k * m + j];
+            M->Hess[i * m + j] = sum_terms(M, term, n);
+            free(term);
         }
     double lamai = 0.0;
     for (int j = 0; j < m; j++) {
@@ -250,9 +302,11 @@ static double dual_residual(orc_mma_t *M, const double *xv, double epsi) {
     int m  = M->m;
     double nrI = 0.0;
     for (int j = 0; j < m; j++) {
-        double r = 0.0;
+        double *term = (double *)malloc(sizeof(double) * (size_t)n);
         for (long i = 0; i < n; i++)
-            r += M->pij[(size_t)j * n + i] / (M->U[i] - xv[i]) + M->qij[(size_t)j * n + i] / (xv[i] - M->L[i]);
+            term[i] = M->pij[(size_t)j * n + i] / (M->U[i] - xv[i]) + M->qij[(size_t)j * n + i] / (xv[i] - M->L[i]);
+        const double r = sum_terms(M, term, n);
+        free(term);
         double r1 = r - M->b[j] - M->a[j] * M->z - M->y[j] + M->mu[j];
         double r2 = M->mu[j] * M->lam[j] - epsi;
         nrI = dmax(nrI, dmax(dabs(r1), dabs(r2)));

@@ -85,6 +85,7 @@ def lib():
         L.orc_mma_create.restype = C.c_void_p
         L.orc_mma_create.argtypes = [C.c_long, C.c_int, C.c_void_p]
         L.orc_mma_destroy.argtypes = [C.c_void_p]
+        L.orc_mma_set_device_order.argtypes = [C.c_void_p, C.c_int]
         L.orc_mma_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_mma_outer_movelimit.argtypes = [C.c_long, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
                                               C.c_void_p]
@@ -342,6 +343,12 @@ class MMA:
         if getattr(self, "h", None):
             self.L.orc_mma_destroy(self.h)
             self.h = None
+
+    def set_device_order(self, on=True):
+        """sum in the HIP kernels' order (workgroups of 256 over grid_for(n, 1024) groups, shuffle trees) and cube by
+        multiplication: for bit-for-bit comparisons with the device; default = the reference's loops and pow()"""
+        nb = min(max((self.n + 255) // 256, 1), 1024) if on else 0
+        self.L.orc_mma_set_device_order(self.h, nb)
 
     def SetOuterMovelimit(self, Xmin, Xmax, movlim, x):
         xmin, xmax = np.zeros(self.n), np.zeros(self.n)

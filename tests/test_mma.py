@@ -43,7 +43,11 @@ def test_oracle_mma_converges_to_kkt_point(orc):
 
 
 @pytest.mark.gpu
-def test_device_mma_matches_oracle(orc):
+@pytest.mark.parametrize("device_order", [False, True])
+def test_device_mma_matches_oracle(orc, device_order):
+    """device_order = False: the oracle sums left to right and cubes with pow() like MMA.cc -> agreement to 1e-12.
+    device_order = True: the oracle performs the SAME operations in the SAME order as the HIP kernels (workgroup /
+    shuffle-tree sums, cube by multiplication) -> the design update is bit-identical, iteration after iteration."""
     import torch
     import topopt_in_petsc_amd as tp
     c, v = _toy(12 * 8 * 8)
@@ -53,6 +57,8 @@ def test_device_mma_matches_oracle(orc):
     x = np.full(n, v)
     xd = dev(x)
     m_o, m_d = orc.MMA(x, 1), tp.MMA(grid, xd, 1)
+    if device_order:
+        m_o.set_device_order()
     xold_o, xold_d = x.copy(), dev(x)
     xmin_d, xmax_d = grid.elem_vec(), grid.elem_vec()
     for it in range(8):
@@ -67,6 +73,9 @@ def test_device_mma_matches_oracle(orc):
         m_d.Update(xd, dev(df), [g], [dev(dg)], xmin_d, xmax_d)
         assert m_d.last_inner == m_o.last_inner
         xg = xd.cpu().numpy()
+        if device_order:
+            assert np.array_equal(xg, x), (it, np.abs(xg - x).max())
+            assert m_d.state()[0][0] == m_o.state()[0][0]
         assert np.abs(xg - x).max() <= 1e-12, (it, np.abs(xg - x).max())
         assert m_d.state()[0][0] == pytest.approx(m_o.state()[0][0], rel=1e-11)
         ch_o = m_o.DesignChange(x, xold_o)
