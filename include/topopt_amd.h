@@ -112,6 +112,11 @@ int tp_rccl_load(const char *librccl_path);
 int tp_rccl_unique_id(void *id128);
 int tp_grid_use_rccl(tp_grid *g, const void *id128);
 int tp_grid_comm_stats(const tp_grid *g, long *exchanges, long *reductions);   /* RCCL path only, else zeros */
+/* back to the tp_comm hooks given at creation (destroys the library's communicator) */
+int tp_grid_drop_rccl(tp_grid *g);
+/* collective: rank-tagged buffers through the grid's CURRENT hooks (staged and in-place exchange, reductions,
+ * all-gather); *ok = 1 if this rank received exactly its neighbours' data */
+int tp_grid_comm_selfcheck(tp_grid *g, int *ok);
 /* one-rank loop-back check of the RCCL call sequence (the rank is its own lower and upper neighbour):
  * returns TP_OK and the largest deviation in *max_err */
 int tp_rccl_selftest(int device, void *stream, long n, double *max_err);

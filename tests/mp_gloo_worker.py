@@ -112,6 +112,10 @@ def gpu_mode(rank, world):
     nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
     grid = tp.Grid(nx, ny, nz, h, rank=rank, nranks=world)
     part = grid.part
+    # the collective self-check that guards the in-library RCCL path, here through the host hooks
+    import ctypes
+    ok = ctypes.c_int(0)
+    assert grid.L.tp_grid_comm_selfcheck(grid.handle, ctypes.byref(ok)) == 0 and ok.value == 1
     le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=nlv, rtol=1e-9, max_it=300))
     le.SetUpLoadAndBC()
     x = grid.synth_density()

@@ -104,6 +104,15 @@ class Grid:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
         if int(flag[0]) == 0:
             raise TopOptError(rc or 4, "tp_grid_use_rccl (some rank could not create its communicator)")
+        # trust, but verify: rank-tagged planes through the new path; any rank unhappy -> everybody back to the hooks
+        ok = C.c_int(0)
+        rc = self.L.tp_grid_comm_selfcheck(self.handle, C.byref(ok))
+        flag = torch.tensor([1 if (rc == 0 and ok.value == 1) else 0], device=self.device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag[0]) == 0:
+            self.L.tp_grid_drop_rccl(self.handle)
+            print("topopt_amd: in-library RCCL exchange failed its self-check; using the torch.distributed hooks", flush=True)
+            return
         self.comm_kind = "rccl (in-library)"
 
     def __del__(self):

@@ -9,6 +9,7 @@ struct tp_grid {
     tp_comm comm;
     bool has_comm;
     struct RcclComm *rccl = nullptr;  // set by tp_grid_use_rccl: the hooks above then point into it
+    tp_comm comm_host;                // the host framework's hooks given at creation (restored by tp_grid_drop_rccl)
     int ex, ey, ez_glob, ez_own;  // fine level element counts
     int rank, nranks;
     double *partials;   // [dev] MAX_RED_BLOCKS * 4

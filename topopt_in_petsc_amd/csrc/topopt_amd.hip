@@ -17,7 +17,7 @@ extern "C" int tp_grid_create(tp_grid **out, const tp_grid_opts *o) {
     g->o = *o;
     g->stream = (hipStream_t)o->stream;
     g->has_comm = o->nranks > 1;
-    if (g->has_comm) g->comm = *o->comm;
+    if (g->has_comm) g->comm = g->comm_host = *o->comm;
     g->ex = o->nx - 1;
     g->ey = o->ny - 1;
     g->ez_glob = o->nz - 1;
@@ -58,6 +58,75 @@ extern "C" int tp_grid_use_rccl(tp_grid *g, const void *id128) {
     if (rc) return rc;
     g->rccl = c;
     g->comm = c->hooks;
+    return TP_OK;
+}
+extern "C" int tp_grid_drop_rccl(tp_grid *g) {
+    if (!g) return TP_ERR_ARG;
+    if (g->rccl) {
+        g->comm = g->comm_host;
+        rccl_comm_destroy(g->rccl);
+        g->rccl = nullptr;
+    }
+    return TP_OK;
+}
+// Rank-tagged planes through the CURRENT hooks (staged and in-place exchange, all-reduce, all-gather) and a check
+// of what arrives: *ok = 1 if this rank saw exactly its neighbours' data.  Collective over the grid's ranks.
+extern "C" int tp_grid_comm_selfcheck(tp_grid *g, int *ok) {
+    if (!g || !ok) return TP_ERR_ARG;
+    *ok = 1;
+    if (!g->has_comm) return TP_OK;
+    const tp_comm &c = g->comm;
+    hipStream_t st = g->stream;
+    const long n = c.cap < 4096 ? c.cap : 4096;
+    const int nr = g->nranks, rk = g->rank;
+    std::vector<double> h(n), a(n), b(n);
+    auto fill = [&](double *dst, double tag) {
+        for (long i = 0; i < n; i++) h[i] = tag + 1e-3 * (double)i;
+        return hipMemcpyAsync(dst, h.data(), sizeof(double) * n, hipMemcpyHostToDevice, st) == hipSuccess &&
+               hipStreamSynchronize(st) == hipSuccess;
+    };
+    auto check = [&](const double *src, double tag) {
+        if (hipMemcpyAsync(a.data(), src, sizeof(double) * n, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
+        if (hipStreamSynchronize(st) != hipSuccess) return false;
+        for (long i = 0; i < n; i++)
+            if (a[i] != tag + 1e-3 * (double)i) return false;
+        return true;
+    };
+    bool good = fill(c.send_lo, 100.0 * rk + 1.0) && fill(c.send_hi, 100.0 * rk + 2.0);
+    if (c.exchange(c.user, n)) return TP_ERR_COMM;
+    if (rk > 0) good = good && check(c.recv_lo, 100.0 * (rk - 1) + 2.0);       // lower neighbour's send_hi
+    if (rk < nr - 1) good = good && check(c.recv_hi, 100.0 * (rk + 1) + 1.0);  // upper neighbour's send_lo
+    if (c.exchange_direct) {  // in place: use the staging areas as "vectors", crossed over
+        good = good && fill(c.recv_lo, 100.0 * rk + 3.0) && fill(c.recv_hi, 100.0 * rk + 4.0);
+        const int rc = c.exchange_direct(c.user, rk > 0 ? c.recv_lo : nullptr, rk > 0 ? c.send_lo : nullptr,
+                                         rk < nr - 1 ? c.recv_hi : nullptr, rk < nr - 1 ? c.send_hi : nullptr, n);
+        if (rc == 1) return TP_ERR_COMM;
+        if (rc == 0) {
+            if (rk > 0) good = good && check(c.send_lo, 100.0 * (rk - 1) + 4.0);
+            if (rk < nr - 1) good = good && check(c.send_hi, 100.0 * (rk + 1) + 3.0);
+        }
+    }
+    {   // sum over ranks of (rank + 1) in slot 0..3
+        for (int i = 0; i < 4; i++) h[i] = (double)(rk + 1) * (i + 1);
+        good = good && hipMemcpyAsync(c.red, h.data(), sizeof(double) * 4, hipMemcpyHostToDevice, st) == hipSuccess;
+        if (c.allreduce_sum(c.user, 4)) return TP_ERR_COMM;
+        good = good && hipMemcpyAsync(b.data(), c.red, sizeof(double) * 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+               hipStreamSynchronize(st) == hipSuccess;
+        for (int i = 0; i < 4; i++) good = good && b[i] == 0.5 * nr * (nr + 1) * (i + 1);
+        if (c.allreduce_inplace) {
+            good = good && hipMemcpyAsync(c.red + 8, h.data(), sizeof(double) * 4, hipMemcpyHostToDevice, st) == hipSuccess;
+            if (c.allreduce_inplace(c.user, c.red + 8, 4)) return TP_ERR_COMM;
+            good = good && hipMemcpyAsync(b.data(), c.red + 8, sizeof(double) * 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                   hipStreamSynchronize(st) == hipSuccess;
+            for (int i = 0; i < 4; i++) good = good && b[i] == 0.5 * nr * (nr + 1) * (i + 1);
+        }
+    }
+    if (c.allgather) {
+        good = good && fill(c.send_lo, 1000.0 * rk);
+        if (c.allgather(c.user, n)) return TP_ERR_COMM;
+        for (int r = 0; r < nr; r++) good = good && check(c.gather + (long)r * n, 1000.0 * r);
+    }
+    *ok = good ? 1 : 0;
     return TP_OK;
 }
 extern "C" int tp_grid_comm_stats(const tp_grid *g, long *ex, long *red) {

@@ -57,6 +57,8 @@ SYMBOLS = {
     "tp_rccl_unique_id": (_i, [_vp]),
     "tp_grid_use_rccl": (_i, [_vp, _vp]),
     "tp_grid_comm_stats": (_i, [_vp, C.POINTER(_l), C.POINTER(_l)]),
+    "tp_grid_drop_rccl": (_i, [_vp]),
+    "tp_grid_comm_selfcheck": (_i, [_vp, C.POINTER(_i)]),
     "tp_rccl_selftest": (_i, [_i, _vp, _l, C.POINTER(_d)]),
     "tp_grid_local_nodes": (_l, [_vp]),
     "tp_grid_local_elems": (_l, [_vp]),
