@@ -11,7 +11,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for fn in glob.glob("gpurun_out/pmc_sq/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(fn)):
         k = r["Kernel_Name"]
-        if "k_matfree_tile" in k or "k_scale" in k:
+        if "k_matfree_tile" in k or "k_fine_tile" in k or "k_scale" in k:
             acc[k[:34]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in acc.items():
     print(k, {c: round(sum(v) / len(v)) for c, v in sorted(cs.items())})

@@ -22,6 +22,30 @@
         if (r_) return r_;     \
     } while (0)
 
+// Every kernel launch goes through TP_LAUNCH: a launch that the runtime rejects (LDS / register over-subscription
+// after a tuning change, bad grid) must not pass silently with stale output and a plausible timing.
+// TP_DEBUG_SYNC=1 additionally synchronises the device after every launch, so that an asynchronous fault is
+// reported at the launch that caused it (implies no graph capture).
+inline bool tp_debug_sync() {
+    static const bool v = getenv("TP_DEBUG_SYNC") != nullptr && atoi(getenv("TP_DEBUG_SYNC")) != 0;
+    return v;
+}
+inline int tp_launch_check(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && tp_debug_sync()) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        fprintf(stderr, "topopt_amd: launch failed (%s): %s\n", what, hipGetErrorString(e));
+        return TP_ERR_HIP + (int)e;
+    }
+    return TP_OK;
+}
+#define TP_LAUNCH(kernel, ...)                            \
+    do {                                                  \
+        hipLaunchKernelGGL(kernel, __VA_ARGS__);          \
+        int lrc_ = tp_launch_check(#kernel);              \
+        if (lrc_) return lrc_;                            \
+    } while (0)
+
 constexpr int WAVE = 64;     // CDNA wavefront
 constexpr int BLK  = 256;    // default workgroup: 4 waves, one per SIMD
 constexpr int MAX_RED_BLOCKS = 8192;

@@ -173,7 +173,7 @@ static int filter_conv(tp_filter *f, double *out, const double *d1, const double
     const dim3 tg((g->ex + 31) / 32, (g->ey + 3) / 4, (g->ez_own + 1) / 2);
     static const bool no_tile = getenv("TP_NO_FILTER_TILE") != nullptr;
 #define TP_CONV_TILED(CC)                                                                                            \
-    hipLaunchKernelGGL(k_conv_filter_tiled<CC>, tg, dim3(256), 0, g->stream, g->ex, g->ey, g->ez_own, g->rank * g->ez_own, \
+    TP_LAUNCH(k_conv_filter_tiled<CC>, tg, dim3(256), 0, g->stream, g->ex, g->ey, g->ez_own, g->rank * g->ez_own, \
                        g->ez_glob, f->xg, f->wtab, out, d1, d2)
     if (!no_tile && c == 1)
         TP_CONV_TILED(1);
@@ -182,7 +182,7 @@ static int filter_conv(tp_filter *f, double *out, const double *d1, const double
     else if (!no_tile && c == 3)
         TP_CONV_TILED(3);
     else
-        hipLaunchKernelGGL(k_conv_filter, dim3((int)((f->nel + BLK - 1) / BLK)), dim3(BLK), 0, g->stream, g->ex, g->ey,
+        TP_LAUNCH(k_conv_filter, dim3((int)((f->nel + BLK - 1) / BLK)), dim3(BLK), 0, g->stream, g->ex, g->ey,
                            g->ez_own, c, g->rank * g->ez_own, g->ez_glob, f->xg, f->wtab, out, d1, d2);
 #undef TP_CONV_TILED
     const double w3 = (2.0 * c + 1) * (2.0 * c + 1) * (2.0 * c + 1);
@@ -191,7 +191,7 @@ static int filter_conv(tp_filter *f, double *out, const double *d1, const double
 }
 static int filter_fill(tp_filter *f, const double *a, const double *b, int mode) {
     tp_grid *g = f->grid;
-    hipLaunchKernelGGL(k_fill_pw, dim3(grid_for(f->nel)), dim3(BLK), 0, g->stream, f->xg + f->conn * f->lay, a, b, mode,
+    TP_LAUNCH(k_fill_pw, dim3(grid_for(f->nel)), dim3(BLK), 0, g->stream, f->xg + f->conn * f->lay, a, b, mode,
                        f->nel);
     count_launch(g, (mode ? 24.0 : 16.0) * f->nel, mode ? 1.0 * f->nel : 0.0);
     return TP_OK;
@@ -205,13 +205,13 @@ static int pde_apply(tp_filter *f, const double *in, double *out) {
     hipStream_t s = g->stream;
     TP_HIP(hipMemcpyAsync(f->xe, in, sizeof(double) * (size_t)f->nel, hipMemcpyDeviceToDevice, s));
     TP_TRY(exchange_segments(g, f->xe, nullptr, nullptr, f->xe + f->nel, f->lay, 1, f->lay));
-    hipLaunchKernelGGL(k_pde_elem_to_node, dim3((int)((q.owned_nodes() + BLK - 1) / BLK)), dim3(BLK), 0, s, q, f->xe,
+    TP_LAUNCH(k_pde_elem_to_node, dim3((int)((q.owned_nodes() + BLK - 1) / BLK)), dim3(BLK), 0, s, q, f->xe,
                        f->elemVol, f->rhs, f->u);
     count_launch(g, 8.0 * f->nel + 16.0 * q.owned_nodes(), 9.0 * q.owned_nodes());
     int rc = mg.solve(f->rhs, f->u, &f->last_its, &f->last_rnorm, nullptr, nullptr, 0);
     if (rc) return rc;
     TP_TRY(halo_nodes(g, q, f->u, 1));
-    hipLaunchKernelGGL(k_pde_node_to_elem, dim3((int)((f->nel + BLK - 1) / BLK)), dim3(BLK), 0, s, q, f->u, out);
+    TP_LAUNCH(k_pde_node_to_elem, dim3((int)((f->nel + BLK - 1) / BLK)), dim3(BLK), 0, s, q, f->u, out);
     count_launch(g, 8.0 * f->nel + 8.0 * q.owned_nodes(), 8.0 * f->nel);
     return TP_OK;
 }
@@ -262,7 +262,7 @@ extern "C" int tp_filter_create(tp_filter **out, tp_grid *g, int filterType, dou
         const size_t ng = (size_t)(g->ez_own + 2 * conn) * f->lay;
         TP_HIP(hipMalloc((void **)&f->xg, sizeof(double) * ng));
         // Hs = H * 1 (:445-448)
-        hipLaunchKernelGGL(k_set, dim3(grid_for((long)ng)), dim3(BLK), 0, g->stream, f->xg, 1.0, (long)ng);
+        TP_LAUNCH(k_set, dim3(grid_for((long)ng)), dim3(BLK), 0, g->stream, f->xg, 1.0, (long)ng);
         TP_TRY(filter_conv(f, f->Hs, nullptr, nullptr));
     } else if (filterType == 2) {
         tp_solver_opts o;
@@ -356,7 +356,7 @@ extern "C" int tp_filter_project(tp_filter *f, const double *x, double *xTilde, 
     } else if (f->type == 2) {  // :73-102
         TP_TRY(pde_apply(f, x, xTilde));
         const int nb = grid_for(n, MAX_RED_BLOCKS);
-        hipLaunchKernelGGL(k_clamp01, dim3(nb), dim3(BLK), 0, s, xTilde, n, g->partials);
+        TP_LAUNCH(k_clamp01, dim3(nb), dim3(BLK), 0, s, xTilde, n, g->partials);
         count_launch(g, 16.0 * n, 0.0);
         TP_TRY(finish_reduction<1>(g, nb, S_TMP));
         double v;
@@ -369,7 +369,7 @@ extern "C" int tp_filter_project(tp_filter *f, const double *x, double *xTilde, 
         if (xTilde != x) TP_HIP(hipMemcpyAsync(xTilde, x, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
     }
     if (proj) {  // :110-114
-        hipLaunchKernelGGL(k_heaviside, dim3(grid_for(n)), dim3(BLK), 0, s, xPhys, xTilde, beta, eta, n);
+        TP_LAUNCH(k_heaviside, dim3(grid_for(n)), dim3(BLK), 0, s, xPhys, xTilde, beta, eta, n);
         count_launch(g, 16.0 * n, 10.0 * n);
     } else {
         TP_HIP(hipMemcpyAsync(xPhys, xTilde, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
@@ -395,9 +395,9 @@ extern "C" int tp_filter_gradients(tp_filter *f, const double *x, const double *
     tp_grid *g = f->grid;
     const long n = f->nel;
     if (proj) {  // chain rule of the projection, :125-164
-        hipLaunchKernelGGL(k_heaviside_chain, dim3(grid_for(n)), dim3(BLK), 0, g->stream, dfdx, xTilde, beta, eta, n);
+        TP_LAUNCH(k_heaviside_chain, dim3(grid_for(n)), dim3(BLK), 0, g->stream, dfdx, xTilde, beta, eta, n);
         for (int i = 0; i < m; i++)
-            hipLaunchKernelGGL(k_heaviside_chain, dim3(grid_for(n)), dim3(BLK), 0, g->stream, dgdx[i], xTilde, beta,
+            TP_LAUNCH(k_heaviside_chain, dim3(grid_for(n)), dim3(BLK), 0, g->stream, dgdx[i], xTilde, beta,
                                eta, n);
         count_launch(g, 24.0 * n * (1 + m), 12.0 * n * (1 + m));
     }
@@ -410,7 +410,7 @@ extern "C" int tp_filter_gradients(tp_filter *f, const double *x, const double *
 extern "C" int tp_filter_mnd(tp_filter *f, const double *x, double *mnd) {
     tp_grid *g = f->grid;
     const int nb = grid_for(f->nel, MAX_RED_BLOCKS);
-    hipLaunchKernelGGL(k_mnd, dim3(nb), dim3(BLK), 0, g->stream, x, f->nel, g->partials);
+    TP_LAUNCH(k_mnd, dim3(nb), dim3(BLK), 0, g->stream, x, f->nel, g->partials);
     count_launch(g, 8.0 * f->nel, 3.0 * f->nel);
     TP_TRY(finish_reduction<1>(g, nb, S_TMP));
     double v;

@@ -48,7 +48,7 @@ inline void count_launch(tp_grid *g, double bytes = 0.0, double flops = 0.0) {
 // out = scal[slot .. slot+NV): block partials -> one value each, then summed over ranks
 template <int NV>
 inline int finish_reduction(tp_grid *g, int nblocks, int slot) {
-    hipLaunchKernelGGL(k_reduce_final<NV>, dim3(1), dim3(BLK), 0, g->stream, g->partials, nblocks, g->scal + slot);
+    TP_LAUNCH(k_reduce_final<NV>, dim3(1), dim3(BLK), 0, g->stream, g->partials, nblocks, g->scal + slot);
     count_launch(g);
     if (g->has_comm) {
         if (g->comm.allreduce_inplace) {  // the CG scalars are reduced where they live
@@ -72,13 +72,13 @@ inline int read_scal(tp_grid *g, int slot, int n, double *out) {
 
 inline int dot_to_slot(tp_grid *g, const double *a, const double *b, long n, int slot) {
     int nb = grid_for(n, MAX_RED_BLOCKS);
-    hipLaunchKernelGGL(k_dot, dim3(nb), dim3(BLK), 0, g->stream, a, b, n, g->partials);
+    TP_LAUNCH(k_dot, dim3(nb), dim3(BLK), 0, g->stream, a, b, n, g->partials);
     count_launch(g, 16.0 * n, 2.0 * n);
     return finish_reduction<1>(g, nb, slot);
 }
 inline int sum_to_slot(tp_grid *g, const double *a, long n, int slot) {
     int nb = grid_for(n, MAX_RED_BLOCKS);
-    hipLaunchKernelGGL(k_sum, dim3(nb), dim3(BLK), 0, g->stream, a, n, g->partials);
+    TP_LAUNCH(k_sum, dim3(nb), dim3(BLK), 0, g->stream, a, n, g->partials);
     count_launch(g, 8.0 * n, 1.0 * n);
     return finish_reduction<1>(g, nb, slot);
 }

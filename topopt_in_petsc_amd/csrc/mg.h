@@ -8,6 +8,7 @@
 #include "grid.h"
 #include "operators.h"
 #include "matfree_tile.h"
+#include "fine_tile.h"
 
 enum { LV_MATFREE = 0, LV_DIA = 1, LV_MACRO = 2 };
 
@@ -253,6 +254,29 @@ inline int xcd_remap() {
     return v;
 }
 
+// z-chunk length of the fine tile kernels.  The chip holds 768 workgroups of them at once (3 per CU: 168 VGPRs,
+// 49 KB LDS).  A grid that fills those slots ONCE with equal chunks has no second, partly empty round and the least
+// redundant z-halo (measured, DESIGN.md 4.1: 128^3 kz 15 -> 729 workgroups beats kz 8 -> 1377 by 10 %; 128x64x64
+// kz 4 -> 765 beats kz 8 by 20 %); that only pays while the chunks stay short enough to fill >= 90 % of the slots,
+// otherwise several rounds of kz ~ 8..32 are better (256x128x128: kz 8 beats kz 33).
+inline int fine_kz(int planes, int tiles, int fine_v) {
+    constexpr int SLOTS = 768;
+    if (fine_v == 2) {
+        const int tz1 = SLOTS / tiles;
+        if (tz1 >= 1) {
+            const int kz1 = (planes + tz1 - 1) / tz1;
+            const int n1 = tiles * ((planes + kz1 - 1) / kz1);
+            if (kz1 >= 3 && kz1 <= 20 && 10 * n1 >= 9 * SLOTS) return kz1;
+        }
+    }
+    int kz = (int)((long)planes * tiles / 5120);  // ~5k workgroups
+    kz = kz < 8 ? 8 : (kz > 32 ? 32 : kz);
+    // small grids: shorter chunks until the workgroup slots of the chip are filled once
+    if ((long)tiles * ((planes + 7) / 8) < SLOTS) kz = (int)((long)planes * tiles / SLOTS);
+    if (kz < 4) kz = 4;
+    return kz > planes ? planes : kz;
+}
+
 template <int DOF>
 struct MGSolver {
     tp_grid *grid = nullptr;
@@ -410,19 +434,17 @@ struct MGSolver {
             const int tx = (L.g.nx + TOUT - 1) / TOUT, ty = (L.g.ny + TOUT - 1) / TOUT;
             const int planes = L.g.own_hi - L.g.own_lo + 1;
             static const int kz_env = getenv("TP_TILE_KZ") ? atoi(getenv("TP_TILE_KZ")) : 0;
-            int kz = kz_env > 0 ? kz_env : (int)((long)planes * tx * ty / 5120);  // ~5k workgroups
-            if (kz_env <= 0) {
-                kz = kz < 8 ? 8 : (kz > 32 ? 32 : kz);
-                // small grids: shorter chunks until the 768 workgroup slots of the chip are filled once
-                if ((long)tx * ty * ((planes + 7) / 8) < 768) kz = (int)((long)planes * tx * ty / 768);
-                if (kz < 4) kz = 4;
-            }
+            static const int fine_v = getenv("TP_FINE_V") ? atoi(getenv("TP_FINE_V")) : 2;
+            int kz = kz_env > 0 ? kz_env : fine_kz(planes, tx * ty, fine_v);
             if (kz > planes) kz = planes;
             const int tz = (planes + kz - 1) / kz;
             last_nblocks = tx * ty * tz;
             TileArgs ta{L.g.nx, L.g.ny, L.g.nzl, L.g.ex, L.g.ey, L.g.ezl, L.g.own_lo, L.g.own_hi, kz,
                         L.E, L.mask, L.colmask, L.sym_slot * SYMKE_STRIDE, 0, 0, nullptr, xcd_remap(), 0};
-            hipLaunchKernelGGL((k_matfree_tile<EPI, 0>), dim3(tx, ty, tz), dim3(TILE * TILE), 0, grid->stream, ta, a);
+            if (fine_v == 2)
+                TP_LAUNCH((k_fine_tile<EPI>), dim3(tx, ty, tz), dim3(TILE * TILE), 0, grid->stream, ta, a);
+            else
+                TP_LAUNCH((k_matfree_tile<EPI, 0>), dim3(tx, ty, tz), dim3(TILE * TILE), 0, grid->stream, ta, a);
             bytes = 16.0 * DOF * nown + 8.0 * L.g.own_elems();
             flops = 2.0 * 576 * (double)L.g.own_elems();
         } else if (DOF == 3 && L.kind == LV_MACRO) {
@@ -435,9 +457,9 @@ struct MGSolver {
             const int tz = (planes + kz - 1) / kz;
             last_nblocks = tx * ty * tz;
             if (L.ncorr_nodes) {
-                hipLaunchKernelGGL(k_macro_corr_rows, dim3((L.nflag * 24 + BLK - 1) / BLK), dim3(BLK), 0, grid->stream, L.g,
+                TP_LAUNCH(k_macro_corr_rows, dim3((L.nflag * 24 + BLK - 1) / BLK), dim3(BLK), 0, grid->stream, L.g,
                                    L.dK, L.flag_list, L.nflag, a.x, L.corr_tmp);
-                hipLaunchKernelGGL(k_macro_corr_gather, dim3((L.ncorr_nodes + BLK - 1) / BLK), dim3(BLK), 0, grid->stream,
+                TP_LAUNCH(k_macro_corr_gather, dim3((L.ncorr_nodes + BLK - 1) / BLK), dim3(BLK), 0, grid->stream,
                                    L.corr_nodes, L.corr_adj, L.ncorr_nodes, L.corr_tmp, L.corr, L.nflag);
                 count_launch(grid);
                 count_launch(grid);
@@ -445,12 +467,12 @@ struct MGSolver {
             TileArgs ta{L.g.nx, L.g.ny, L.g.nzl, L.g.ex, L.g.ey, L.g.ezl, L.g.own_lo, L.g.own_hi, kz,
                         L.E, nullptr, nullptr, L.sym_slot * SYMKE_STRIDE, L.fex, L.fey,
                         L.ncorr_nodes ? L.corr : nullptr, xcd_remap(), L.sym_slot * MACG_STRIDE};
-            hipLaunchKernelGGL((k_matfree_tile<EPI, 1>), dim3(tx, ty, tz), dim3(TILE * TILE), 0, grid->stream, ta, a);
+            TP_LAUNCH((k_matfree_tile<EPI, 1>), dim3(tx, ty, tz), dim3(TILE * TILE), 0, grid->stream, ta, a);
             bytes = 16.0 * DOF * nown + 8.0 * 8.0 * L.g.own_elems();
             flops = 2.0 * 576 * 8.0 * (double)L.g.own_elems();
         } else if (L.kind == LV_MATFREE) {
             MatfreeOp<DOF> o{L.KE, L.E, L.mask, L.g};
-            hipLaunchKernelGGL((k_node<DOF, MatfreeOp<DOF>, EPI>), dim3(nb), dim3(BLK), 0, grid->stream, o, a);
+            TP_LAUNCH((k_node<DOF, MatfreeOp<DOF>, EPI>), dim3(nb), dim3(BLK), 0, grid->stream, o, a);
             bytes = 16.0 * DOF * nown + (L.E ? 8.0 * L.g.own_elems() : 0.0);
             flops = 2.0 * (8 * DOF) * (8 * DOF) * (double)L.g.own_elems();
         } else {
@@ -460,16 +482,16 @@ struct MGSolver {
             const int split = split_env >= 0 ? split_env : (nbr < 128 ? 9 : (nbr < 512 ? 3 : 1));
             if (split == 9) {
                 nbr = (int)((nown * DOF + BLK / 9 - 1) / (BLK / 9));
-                hipLaunchKernelGGL((k_dia_row_split<DOF, EPI, 9>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
+                TP_LAUNCH((k_dia_row_split<DOF, EPI, 9>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
             } else if (split == 3) {
                 nbr = (int)((nown * DOF + BLK / 3 - 1) / (BLK / 3));
                 static const bool sym = getenv("TP_NO_DIA_SYM") == nullptr;
                 if (sym)
-                    hipLaunchKernelGGL((k_dia_row_split<DOF, EPI, 3, true>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
+                    TP_LAUNCH((k_dia_row_split<DOF, EPI, 3, true>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
                 else
-                    hipLaunchKernelGGL((k_dia_row_split<DOF, EPI, 3>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
+                    TP_LAUNCH((k_dia_row_split<DOF, EPI, 3>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
             } else {
-                hipLaunchKernelGGL((k_dia_row<DOF, EPI>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
+                TP_LAUNCH((k_dia_row<DOF, EPI>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
             }
             last_nblocks = nbr;
             bytes = (27.0 * DOF * DOF + 2.0 * DOF) * 8.0 * nown;
@@ -517,7 +539,7 @@ struct MGSolver {
         double rho = 1.0 / sigma;
         int it = 0;
         if (zero_guess) {
-            hipLaunchKernelGGL(k_cheb_first, dim3(grid_for(L.own_n())), dim3(BLK), 0, grid->stream, L.x,
+            TP_LAUNCH(k_cheb_first, dim3(grid_for(L.own_n())), dim3(BLK), 0, grid->stream, L.x,
                                three_term(L) ? nullptr : L.d, b, L.dinv, 1.0 / theta, L.own_off(), L.own_n());
             count_launch(grid, 32.0 * L.own_n(), 2.0 * L.own_n());
             it = 1;
@@ -597,12 +619,12 @@ struct MGSolver {
         }
         Level<DOF> &C = lv[l + 1];
         TP_TRY(halo(l, L.r));
-        hipLaunchKernelGGL((k_restrict<DOF>), dim3((int)((C.g.owned_nodes() + BLK - 1) / BLK)), dim3(BLK), 0,
+        TP_LAUNCH((k_restrict<DOF>), dim3((int)((C.g.owned_nodes() + BLK - 1) / BLK)), dim3(BLK), 0,
                            grid->stream, C.g, L.g, L.r, C.b);
         count_launch(grid, 8.0 * DOF * (L.g.owned_nodes() + C.g.owned_nodes()), 2.0 * 27 * DOF * C.g.owned_nodes());
         TP_TRY(vcycle(l + 1, C.b));
         if (!(replicate && l + 1 == nlv - 1)) TP_TRY(halo(l + 1, C.x));  // the replicated solve returns its ghosts
-        hipLaunchKernelGGL((k_prolong_add<DOF>), dim3((int)((L.g.owned_nodes() + BLK - 1) / BLK)), dim3(BLK), 0,
+        TP_LAUNCH((k_prolong_add<DOF>), dim3((int)((L.g.owned_nodes() + BLK - 1) / BLK)), dim3(BLK), 0,
                            grid->stream, C.g, L.g, C.x, L.x);
         count_launch(grid, 8.0 * DOF * (2 * L.g.owned_nodes() + C.g.owned_nodes()), 2.0 * 8 * DOF * L.g.owned_nodes());
         return smooth(l, b, opt.nsmooth, false);
@@ -612,7 +634,7 @@ struct MGSolver {
     int setup_matfree_level(int l, const double *h_KE) {
         Level<DOF> &L = lv[l];
         MatfreeOp<DOF> o{L.KE, L.E, L.mask, L.g};
-        hipLaunchKernelGGL((k_matfree_diag<DOF>), dim3((int)((L.g.owned_nodes() + BLK - 1) / BLK)), dim3(BLK), 0,
+        TP_LAUNCH((k_matfree_diag<DOF>), dim3((int)((L.g.owned_nodes() + BLK - 1) / BLK)), dim3(BLK), 0,
                            grid->stream, o, L.dinv);
         count_launch(grid, 8.0 * DOF * L.g.owned_nodes() + 8.0 * L.g.own_elems(), 16.0 * DOF * L.g.owned_nodes());
         if (l == 0) {
@@ -661,35 +683,36 @@ struct MGSolver {
         if (!B.part) TP_HIP(hipMalloc((void **)&B.part, sizeof(double) * 256 * 130));
         if (!B.hc) TP_HIP(hipHostMalloc((void **)&B.hc, sizeof(double) * 520));
         double *V = B.V, *coef = B.coef, *part = B.part;
-        auto multi_dot = [&](const double *A, int nv, const double *wv, double *out) {
-            hipLaunchKernelGGL(k_multi_dot, dim3(nb, nv), dim3(BLK), 0, s, A, nd, nv, wv, off, n, nb == 1 ? out : part);
-            if (nb > 1) hipLaunchKernelGGL(k_reduce_multi, dim3(nv), dim3(BLK), 0, s, part, nb, nv, out);
+        auto multi_dot = [&](const double *A, int nv, const double *wv, double *out) -> int {
+            TP_LAUNCH(k_multi_dot, dim3(nb, nv), dim3(BLK), 0, s, A, nd, nv, wv, off, n, nb == 1 ? out : part);
+            if (nb > 1) TP_LAUNCH(k_reduce_multi, dim3(nv), dim3(BLK), 0, s, part, nb, nv, out);
+            return TP_OK;
         };
         TP_HIP(hipMemsetAsync(V, 0, sizeof(double) * (size_t)nd * (size_t)(steps + 1), s));
         TP_HIP(hipMemsetAsync(coef, 0, sizeof(double) * 520, s));
         // coef: h1[129] h2[129] alpha[128] beta[128] bb[1]
         double *h1 = coef, *h2 = coef + 129, *al = coef + 258, *be = coef + 386, *bb = coef + 514;
         double *w = L.d, *t = L.r, *dis = L.b;  // scratch that smooth() never swaps: stable addresses for the graph
-        hipLaunchKernelGGL((k_lanczos_init<DOF>), dim3(gn), dim3(BLK), 0, s, L.g, V, dis, L.dinv);
-        multi_dot(V, 1, V, bb);
+        TP_LAUNCH((k_lanczos_init<DOF>), dim3(gn), dim3(BLK), 0, s, L.g, V, dis, L.dinv);
+        TP_TRY(multi_dot(V, 1, V, bb));
         TP_TRY(allreduce_dev(bb, 1, L.no_comm));
-        hipLaunchKernelGGL(k_lanczos_next, dim3(grid_for(n)), dim3(BLK), 0, s, V, bb, 0, be, V, off, n);  // normalise v0
+        TP_LAUNCH(k_lanczos_next, dim3(grid_for(n)), dim3(BLK), 0, s, V, bb, 0, be, V, off, n);  // normalise v0
         for (int j = 0; j < steps; j++) {
             double *vj = V + (size_t)j * nd;
-            hipLaunchKernelGGL(k_pw_mult, dim3(grid_for(n)), dim3(BLK), 0, s, t + off, dis + off, vj + off, n);
+            TP_LAUNCH(k_pw_mult, dim3(grid_for(n)), dim3(BLK), 0, s, t + off, dis + off, vj + off, n);
             TP_TRY(apply(l, t, w));
-            hipLaunchKernelGGL(k_pw_mult, dim3(grid_for(n)), dim3(BLK), 0, s, w + off, dis + off, w + off, n);
+            TP_LAUNCH(k_pw_mult, dim3(grid_for(n)), dim3(BLK), 0, s, w + off, dis + off, w + off, n);
             for (int pass = 0; pass < 2; pass++) {
                 double *h = pass ? h2 : h1;
-                multi_dot(V, j + 1, w, h);
+                TP_TRY(multi_dot(V, j + 1, w, h));
                 TP_TRY(allreduce_dev(h, j + 1, L.no_comm));
                 // the second pass also records alpha[j] = h1[j] + h2[j]
-                hipLaunchKernelGGL(k_multi_axpy, dim3(grid_for(n)), dim3(BLK), 0, s, V, nd, j + 1, h, w, off, n,
+                TP_LAUNCH(k_multi_axpy, dim3(grid_for(n)), dim3(BLK), 0, s, V, nd, j + 1, h, w, off, n,
                                    pass ? h1 : nullptr, al);
             }
-            multi_dot(w, 1, w, bb);
+            TP_TRY(multi_dot(w, 1, w, bb));
             TP_TRY(allreduce_dev(bb, 1, L.no_comm));
-            hipLaunchKernelGGL(k_lanczos_next, dim3(grid_for(n)), dim3(BLK), 0, s, w, bb, j, be, V + (size_t)(j + 1) * nd,
+            TP_LAUNCH(k_lanczos_next, dim3(grid_for(n)), dim3(BLK), 0, s, w, bb, j, be, V + (size_t)(j + 1) * nd,
                                off, n);
             grid->launches += nb == 1 ? 9 : 12;
         }
@@ -699,7 +722,7 @@ struct MGSolver {
     }
     // replay (or capture, or plain enqueue) of the run of level l on grid->stream
     int lanczos_graph(int l, int steps) {
-        static const bool no_graph = getenv("TP_NO_GRAPH") != nullptr;
+        static const bool no_graph = getenv("TP_NO_GRAPH") != nullptr || tp_debug_sync();
         Level<DOF> &L = lv[l];
         hipStream_t s = grid->stream;
         // the chain reads/writes these vectors by address, and set_bc may rebuild the correction lists
@@ -790,7 +813,7 @@ struct MGSolver {
             TP_TRY(halo(0, x));
             TP_TRY(op<EPI_RESID>(0, a));
         }
-        hipLaunchKernelGGL(k_dot2, dim3(nb), dim3(BLK), 0, s, b, b, r, r, off, n, grid->partials);
+        TP_LAUNCH(k_dot2, dim3(nb), dim3(BLK), 0, s, b, b, r, r, off, n, grid->partials);
         count_launch(grid, 16.0 * n, 4.0 * n);
         TP_TRY(finish_reduction<2>(grid, nb, S_BB));
         double v2[2];
@@ -807,7 +830,7 @@ struct MGSolver {
                 double *z;
                 TP_TRY(precond(r, &z));
                 TP_TRY(dot_to_slot(grid, r + off, z + off, n, rz_cur));
-                hipLaunchKernelGGL(k_cg_update_p, dim3(grid_for(n)), dim3(BLK), 0, s, p, z, grid->scal, rz_cur, rz_old,
+                TP_LAUNCH(k_cg_update_p, dim3(grid_for(n)), dim3(BLK), 0, s, p, z, grid->scal, rz_cur, rz_old,
                                    its == 1 ? 1 : 0, off, n);
                 count_launch(grid, 24.0 * n, 2.0 * n);
                 {
@@ -819,7 +842,7 @@ struct MGSolver {
                     TP_TRY(op<EPI_APPLY_DOT>(0, a));
                     TP_TRY(finish_reduction<1>(grid, last_nblocks, S_PW));
                 }
-                hipLaunchKernelGGL(k_cg_update_xr, dim3(nb), dim3(BLK), 0, s, x, r, p, w, grid->scal, rz_cur, off, n,
+                TP_LAUNCH(k_cg_update_xr, dim3(nb), dim3(BLK), 0, s, x, r, p, w, grid->scal, rz_cur, off, n,
                                    grid->partials);
                 count_launch(grid, 48.0 * n, 6.0 * n);
                 TP_TRY(finish_reduction<1>(grid, nb, S_RR));

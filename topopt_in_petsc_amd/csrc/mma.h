@@ -174,7 +174,7 @@ struct tp_mma {
 
 static int mma_reduce(tp_mma *M, int nb, int nv, double *host) {
     tp_grid *g = M->grid;
-    hipLaunchKernelGGL(k_reduce_multi, dim3(nv), dim3(BLK), 0, g->stream, g->partials, nb, nv, M->red);
+    TP_LAUNCH(k_reduce_multi, dim3(nv), dim3(BLK), 0, g->stream, g->partials, nb, nv, M->red);
     count_launch(g);
     if (g->has_comm)
         for (int o = 0; o < nv; o += 16) {
@@ -232,7 +232,7 @@ extern "C" int tp_mma_destroy(tp_mma *M) {
 }
 extern "C" int tp_mma_set_outer_movelimit(tp_mma *M, double Xmin, double Xmax, double movlim, const double *x,
                                           double *xmin, double *xmax) {
-    hipLaunchKernelGGL(k_mma_movelimit, dim3(grid_for(M->n)), dim3(BLK), 0, M->grid->stream, M->n, Xmin, Xmax, movlim, x,
+    TP_LAUNCH(k_mma_movelimit, dim3(grid_for(M->n)), dim3(BLK), 0, M->grid->stream, M->n, Xmin, Xmax, movlim, x,
                        xmin, xmax);
     count_launch(M->grid, 24.0 * M->n, 2.0 * M->n);
     return TP_OK;
@@ -240,8 +240,8 @@ extern "C" int tp_mma_set_outer_movelimit(tp_mma *M, double Xmin, double Xmax, d
 extern "C" int tp_mma_design_change(tp_mma *M, const double *x, double *xold, double *ch) {
     tp_grid *g = M->grid;
     const int nb = grid_for(M->n, 1024);
-    hipLaunchKernelGGL(k_mma_change, dim3(nb), dim3(BLK), 0, g->stream, M->n, x, xold, g->partials);
-    hipLaunchKernelGGL(k_max_final, dim3(1), dim3(BLK), 0, g->stream, g->partials, nb, M->red);
+    TP_LAUNCH(k_mma_change, dim3(nb), dim3(BLK), 0, g->stream, M->n, x, xold, g->partials);
+    TP_LAUNCH(k_max_final, dim3(1), dim3(BLK), 0, g->stream, g->partials, nb, M->red);
     count_launch(g, 24.0 * M->n, 1.0 * M->n);
     TP_HIP(hipMemcpyAsync(g->h_scal, M->red, sizeof(double), hipMemcpyDeviceToHost, g->stream));
     TP_HIP(hipStreamSynchronize(g->stream));
@@ -294,7 +294,7 @@ extern "C" int tp_mma_update(tp_mma *M, double *x, const double *dfdx, const dou
     TP_HIP(hipMemcpyAsync(M->d_dgdx, dgdx, sizeof(double *) * m, hipMemcpyHostToDevice, s));
     // ---- GenSub
     M->k++;
-    hipLaunchKernelGGL(k_mma_gensub, dim3(nb), dim3(BLK), 0, s, n, m, M->k, M->asyminit, M->asymdec, M->asyminc, x, M->xo1,
+    TP_LAUNCH(k_mma_gensub, dim3(nb), dim3(BLK), 0, s, n, m, M->k, M->asyminit, M->asymdec, M->asyminc, x, M->xo1,
                        M->xo2, xmin, xmax, dfdx, M->d_dgdx, M->L, M->U, M->alpha, M->beta, M->p0, M->q0, M->pij, M->qij,
                        g->partials);
     count_launch(g, 8.0 * n * (12.0 + 3.0 * m), 40.0 * n);
@@ -328,7 +328,7 @@ extern "C" int tp_mma_update(tp_mma *M, double *x, const double *dfdx, const dou
             total++;
             MmaLam lm;
             lam_yz(lm);
-            hipLaunchKernelGGL((k_mma_xyz<1>), dim3(nb), dim3(BLK), 0, s, n, m, lm, x, M->L, M->U, M->alpha, M->beta, M->p0,
+            TP_LAUNCH((k_mma_xyz<1>), dim3(nb), dim3(BLK), 0, s, n, m, lm, x, M->L, M->U, M->alpha, M->beta, M->p0,
                                M->q0, M->pij, M->qij, g->partials);
             count_launch(g, 8.0 * n * (7.0 + 2.0 * m), 40.0 * n);
             TP_TRY(mma_reduce(M, nb, m + m * m, red));
@@ -368,7 +368,7 @@ extern "C" int tp_mma_update(tp_mma *M, double *x, const double *dfdx, const dou
                 M->mu[i] = M->mu[i] + theta * sv[i + m];
             }
             lam_yz(lm);
-            hipLaunchKernelGGL((k_mma_xyz<0>), dim3(nb), dim3(BLK), 0, s, n, m, lm, x, M->L, M->U, M->alpha, M->beta, M->p0,
+            TP_LAUNCH((k_mma_xyz<0>), dim3(nb), dim3(BLK), 0, s, n, m, lm, x, M->L, M->U, M->alpha, M->beta, M->p0,
                                M->q0, M->pij, M->qij, g->partials);
             count_launch(g, 8.0 * n * (7.0 + 2.0 * m), 20.0 * n);
             TP_TRY(mma_reduce(M, nb, m, red));

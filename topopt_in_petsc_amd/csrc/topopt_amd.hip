@@ -151,8 +151,8 @@ extern "C" int tp_rccl_selftest(int device, void *stream, long n, double *max_er
     std::vector<double> a(n), b(n);
     double err = 0.0;
     // staged exchange: send_hi arrives in recv_lo, send_lo in recv_hi
-    hipLaunchKernelGGL(k_selftest_fill, dim3(64), dim3(256), 0, st, h.send_lo, n, 1000.0);
-    hipLaunchKernelGGL(k_selftest_fill, dim3(64), dim3(256), 0, st, h.send_hi, n, 5000.0);
+    TP_LAUNCH(k_selftest_fill, dim3(64), dim3(256), 0, st, h.send_lo, n, 1000.0);
+    TP_LAUNCH(k_selftest_fill, dim3(64), dim3(256), 0, st, h.send_hi, n, 5000.0);
     rc = h.exchange(h.user, n);
     if (!rc) {
         (void)hipMemcpyAsync(a.data(), h.recv_lo, sizeof(double) * n, hipMemcpyDeviceToHost, st);
@@ -160,8 +160,8 @@ extern "C" int tp_rccl_selftest(int device, void *stream, long n, double *max_er
         (void)hipStreamSynchronize(st);
         for (long i = 0; i < n; i++) err = fmax(err, fmax(fabs(a[i] - (5000.0 + i)), fabs(b[i] - (1000.0 + i))));
         // in-place variant on other buffers (gather area as scratch: 1 rank -> cap doubles)
-        hipLaunchKernelGGL(k_selftest_fill, dim3(64), dim3(256), 0, st, h.recv_lo, n, 7000.0);
-        hipLaunchKernelGGL(k_selftest_fill, dim3(64), dim3(256), 0, st, h.recv_hi, n, 9000.0);
+        TP_LAUNCH(k_selftest_fill, dim3(64), dim3(256), 0, st, h.recv_lo, n, 7000.0);
+        TP_LAUNCH(k_selftest_fill, dim3(64), dim3(256), 0, st, h.recv_hi, n, 9000.0);
         rc = h.exchange_direct(h.user, h.recv_lo, h.send_lo, h.recv_hi, h.send_hi, n);  // to_lo, from_lo, to_hi, from_hi
     }
     if (!rc) {
@@ -169,12 +169,12 @@ extern "C" int tp_rccl_selftest(int device, void *stream, long n, double *max_er
         (void)hipMemcpyAsync(b.data(), h.send_hi, sizeof(double) * n, hipMemcpyDeviceToHost, st);  // from_hi <- to_lo
         (void)hipStreamSynchronize(st);
         for (long i = 0; i < n; i++) err = fmax(err, fmax(fabs(a[i] - (9000.0 + i)), fabs(b[i] - (7000.0 + i))));
-        hipLaunchKernelGGL(k_selftest_fill, dim3(1), dim3(64), 0, st, h.red, 16, 3.0);
+        TP_LAUNCH(k_selftest_fill, dim3(1), dim3(64), 0, st, h.red, 16, 3.0);
         rc = h.allreduce_sum(h.user, 8);
         if (!rc) rc = h.allreduce_inplace(h.user, h.red + 8, 8);
     }
     if (!rc) {
-        hipLaunchKernelGGL(k_selftest_fill, dim3(64), dim3(256), 0, st, h.send_lo, n, 11000.0);
+        TP_LAUNCH(k_selftest_fill, dim3(64), dim3(256), 0, st, h.send_lo, n, 11000.0);
         rc = h.allgather(h.user, n);
     }
     if (!rc) {
@@ -230,21 +230,21 @@ extern "C" int tp_sync(const tp_grid *g) {
     return TP_OK;
 }
 extern "C" int tp_vec_scale(tp_grid *g, double *x, double a, long n) {
-    hipLaunchKernelGGL(k_scale, dim3(grid_for(n)), dim3(BLK), 0, g->stream, x, a, n);
+    TP_LAUNCH(k_scale, dim3(grid_for(n)), dim3(BLK), 0, g->stream, x, a, n);
     count_launch(g, 16.0 * n, 1.0 * n);
     return TP_OK;
 }
 // BLAS-1 surface of the PETSc-named adapter (include/petsc_shim.h): Vec operations of LinearElasticity.cc / Filter.cc
 extern "C" int tp_vec_axpby(tp_grid *g, double *y, double a, const double *x, double b, long n) {
-    hipLaunchKernelGGL(k_axpby, dim3(grid_for(n)), dim3(BLK), 0, g->stream, y, a, x, b, n);
+    TP_LAUNCH(k_axpby, dim3(grid_for(n)), dim3(BLK), 0, g->stream, y, a, x, b, n);
     count_launch(g, 24.0 * n, 3.0 * n);
     return TP_OK;
 }
 extern "C" int tp_vec_pointwise(tp_grid *g, double *w, const double *x, const double *y, int divide, long n) {
     if (divide)
-        hipLaunchKernelGGL(k_pw_div, dim3(grid_for(n)), dim3(BLK), 0, g->stream, w, x, y, n);
+        TP_LAUNCH(k_pw_div, dim3(grid_for(n)), dim3(BLK), 0, g->stream, w, x, y, n);
     else
-        hipLaunchKernelGGL(k_pw_mult, dim3(grid_for(n)), dim3(BLK), 0, g->stream, w, x, y, n);
+        TP_LAUNCH(k_pw_mult, dim3(grid_for(n)), dim3(BLK), 0, g->stream, w, x, y, n);
     count_launch(g, 24.0 * n, 1.0 * n);
     return TP_OK;
 }
@@ -255,7 +255,7 @@ extern "C" int tp_vec_dot(tp_grid *g, const double *x, const double *y, long n, 
     return read_scal(g, S_TMP, 1, out);
 }
 extern "C" int tp_vec_set(tp_grid *g, double *x, double a, long n) {
-    hipLaunchKernelGGL(k_set, dim3(grid_for(n)), dim3(BLK), 0, g->stream, x, a, n);
+    TP_LAUNCH(k_set, dim3(grid_for(n)), dim3(BLK), 0, g->stream, x, a, n);
     count_launch(g, 8.0 * n, 0.0);
     return TP_OK;
 }
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(BLK) void k_synth_density(int ex, int ey, int ez, i
 }
 extern "C" int tp_synth_density(tp_grid *g, double *x, uint64_t seed) {
     const long n = (long)g->ex * g->ey * g->ez_own;
-    hipLaunchKernelGGL(k_synth_density, dim3(grid_for(n)), dim3(BLK), 0, g->stream, g->ex, g->ey, g->ez_own,
+    TP_LAUNCH(k_synth_density, dim3(grid_for(n)), dim3(BLK), 0, g->stream, g->ex, g->ey, g->ez_own,
                        g->rank * g->ez_own, g->o.hy, seed, x);
     count_launch(g);
     return TP_OK;
@@ -471,7 +471,7 @@ extern "C" int tp_elasticity_set_bc(tp_elasticity *e, const double *N) {
     tp_grid *g = e->grid;
     Geom q = make_geom(g, 0);
     const long nn = q.nodes();
-    hipLaunchKernelGGL(k_mask_from_N, dim3(grid_for(nn)), dim3(BLK), 0, g->stream, N, e->d_mask, nn);
+    TP_LAUNCH(k_mask_from_N, dim3(grid_for(nn)), dim3(BLK), 0, g->stream, N, e->d_mask, nn);
     TP_HIP(hipMemcpyAsync(e->d_N, N, sizeof(double) * 3 * (size_t)nn, hipMemcpyDeviceToDevice, g->stream));
     e->h_mask.resize((size_t)nn);
     TP_HIP(hipMemcpyAsync(e->h_mask.data(), e->d_mask, (size_t)nn, hipMemcpyDeviceToHost, g->stream));
@@ -631,7 +631,7 @@ extern "C" int tp_elasticity_set_bc(tp_elasticity *e, const double *N) {
 extern "C" int tp_elasticity_cantilever(tp_elasticity *e, double *N, double *RHS) {
     tp_grid *g = e->grid;
     Geom q = make_geom(g, 0);
-    hipLaunchKernelGGL(k_cantilever, dim3(grid_for(q.nodes())), dim3(BLK), 0, g->stream, q, N, RHS);
+    TP_LAUNCH(k_cantilever, dim3(grid_for(q.nodes())), dim3(BLK), 0, g->stream, q, N, RHS);
     return tp_elasticity_set_bc(e, N);
 }
 
@@ -642,7 +642,7 @@ extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, dou
     hipStream_t s = g->stream;
     Geom q0 = mg.lv[0].g;
     const long nel = q0.own_elems(), lay = (long)q0.ex * q0.ey;
-    hipLaunchKernelGGL(k_simp, dim3(grid_for(nel)), dim3(BLK), 0, s, xPhys, Emin, Emax, penal, e->d_E, nel);
+    TP_LAUNCH(k_simp, dim3(grid_for(nel)), dim3(BLK), 0, s, xPhys, Emin, Emax, penal, e->d_E, nel);
     count_launch(g, 16.0 * nel, 3.0 * nel);
     // two ghost layers above <- upper neighbour's first own layers (level 1 is applied
     // from the fine densities and reaches one coarse = two fine layers up)
@@ -657,7 +657,7 @@ extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, dou
             // only the flagged elements get their (exact, masked) Galerkin matrix: compact rows, own ones first,
             // then the ghost layer's -- the upper neighbour's first-layer rows, which head ITS array
             if (e->nflagged) {
-                hipLaunchKernelGGL(k_galerkin_fine_masked, dim3(e->nflagged), dim3(64), 0, s, F.g, C.g, e->d_E, e->d_KE,
+                TP_LAUNCH(k_galerkin_fine_masked, dim3(e->nflagged), dim3(64), 0, s, F.g, C.g, e->d_E, e->d_KE,
                                    e->d_mask, e->d_flagged, e->d_KelF, 1);
                 count_launch(g);
             }
@@ -665,21 +665,21 @@ extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, dou
                 TP_TRY(exchange_segments(g, e->d_KelF, nullptr, nullptr, e->d_KelF + 576 * (long)e->nflagged, 576,
                                          e->nx_first, 576));
             if (e->nflag_all) {
-                hipLaunchKernelGGL(k_macro_delta, dim3((int)(((long)e->nflag_all * 576 + BLK - 1) / BLK)), dim3(BLK), 0, s,
+                TP_LAUNCH(k_macro_delta, dim3((int)(((long)e->nflag_all * 576 + BLK - 1) / BLK)), dim3(BLK), 0, s,
                                    F.g, C.g, e->d_E, e->d_M, e->d_KelF, e->d_flag_all, e->nflag_all, e->d_dK);
                 count_launch(g);
             }
-            hipLaunchKernelGGL(k_macro_diag, dim3(gn), dim3(BLK), 0, s, F.g, C.g, e->d_E, e->d_M, e->d_KelF, e->d_fidx1,
+            TP_LAUNCH(k_macro_diag, dim3(gn), dim3(BLK), 0, s, F.g, C.g, e->d_E, e->d_M, e->d_KelF, e->d_fidx1,
                                C.dinv);
             count_launch(g, 8.0 * 8.0 * C.g.own_elems() + 24.0 * C.g.owned_nodes(), 8.0 * 64 * 3 * C.g.owned_nodes());
             continue;
         }
         if (l == 1) {
-            hipLaunchKernelGGL(k_galerkin_fine_fast, dim3((unsigned)nEc), dim3(192), 0, s, F.g, C.g, e->d_E, e->d_M,
+            TP_LAUNCH(k_galerkin_fine_fast, dim3((unsigned)nEc), dim3(192), 0, s, F.g, C.g, e->d_E, e->d_M,
                                C.Kel);
             count_launch(g, 8.0 * nel + 8.0 * 576 * nEc, 2.0 * 8 * 576 * nEc);
             if (e->nflagged) {
-                hipLaunchKernelGGL(k_galerkin_fine_masked, dim3(e->nflagged), dim3(64), 0, s, F.g, C.g, e->d_E, e->d_KE,
+                TP_LAUNCH(k_galerkin_fine_masked, dim3(e->nflagged), dim3(64), 0, s, F.g, C.g, e->d_E, e->d_KE,
                                    e->d_mask, e->d_flagged, C.Kel, 0);
                 count_launch(g);
             }
@@ -690,22 +690,22 @@ extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, dou
             if (!no_fast2) {
                 static const long nb2_env = getenv("TP_L2_BLOCKS") ? atol(getenv("TP_L2_BLOCKS")) : 512;
                 const unsigned nb2 = (unsigned)(nEc < nb2_env ? nEc : nb2_env);
-                hipLaunchKernelGGL(k_galerkin_l2_fast, dim3(nb2), dim3(576), 0, s, mg.lv[0].g, C.g, e->d_E, e->d_M2,
+                TP_LAUNCH(k_galerkin_l2_fast, dim3(nb2), dim3(576), 0, s, mg.lv[0].g, C.g, e->d_E, e->d_M2,
                                    C.Kel, (int)nEc);
                 count_launch(g, 8.0 * 64 * nEc + 8.0 * 576 * nEc, 2.0 * 64 * 576 * nEc);
                 if (e->nlist2) {
-                    hipLaunchKernelGGL((k_galerkin_coarse<true>), dim3((unsigned)e->nlist2), dim3(64), 0, s, F.g, C.g,
+                    TP_LAUNCH((k_galerkin_coarse<true>), dim3((unsigned)e->nlist2), dim3(64), 0, s, F.g, C.g,
                                        e->d_KelF, C.Kel, mg.lv[0].g, e->d_E, e->d_M, e->d_fidx1, (long)e->nlist2, e->d_list2);
                     count_launch(g);
                 }
             } else {
                 const unsigned nblk = (unsigned)(nEc < 4096 ? nEc : 4096);
-                hipLaunchKernelGGL((k_galerkin_coarse<true>), dim3(nblk), dim3(64), 0, s, F.g, C.g, e->d_KelF, C.Kel,
+                TP_LAUNCH((k_galerkin_coarse<true>), dim3(nblk), dim3(64), 0, s, F.g, C.g, e->d_KelF, C.Kel,
                                    mg.lv[0].g, e->d_E, e->d_M, e->d_fidx1, nEc, (const int *)nullptr);
                 count_launch(g, 8.0 * 64 * nEc + 8.0 * 576 * nEc, 2.0 * (8 * 576 * 8 + 0.18 * 8 * 64 * 64 * 9) * nEc);
             }
         } else {
-            hipLaunchKernelGGL((k_galerkin_coarse<false>), dim3((unsigned)nEc), dim3(64), 0, s, F.g, C.g, F.Kel, C.Kel,
+            TP_LAUNCH((k_galerkin_coarse<false>), dim3((unsigned)nEc), dim3(64), 0, s, F.g, C.g, F.Kel, C.Kel,
                                mg.lv[0].g, nullptr, nullptr, nullptr, nEc, (const int *)nullptr);
             count_launch(g, 8.0 * 576 * (9.0 * nEc), 2.0 * 0.18 * 8 * 64 * 64 * 9 * nEc);
         }
@@ -714,10 +714,10 @@ extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, dou
         // (one contiguous block of 576*clay doubles, cut into rows of `clay` so that it fits the staging buffers)
         TP_TRY(exchange_segments(g, C.Kel, nullptr, nullptr, C.Kel + 576 * clay * C.g.ez_own, clay, 576, clay));
         if (C.kind == LV_MACRO) {  // (not reached: handled above)
-            hipLaunchKernelGGL(k_elem_diag, dim3(gn), dim3(BLK), 0, s, C.g, C.Kel, C.dinv);
+            TP_LAUNCH(k_elem_diag, dim3(gn), dim3(BLK), 0, s, C.g, C.Kel, C.dinv);
             count_launch(g, 8.0 * (24.0 + 3.0) * C.g.owned_nodes(), 24.0 * C.g.owned_nodes());
         } else {
-            hipLaunchKernelGGL(k_elem_to_dia, dim3(gn, 27), dim3(BLK), 0, s, C.g, C.Kel, C.S, C.dinv);
+            TP_LAUNCH(k_elem_to_dia, dim3(gn, 27), dim3(BLK), 0, s, C.g, C.Kel, C.S, C.dinv);
             count_launch(g, 8.0 * (576.0 * C.g.elems_stored() + 243.0 * C.g.owned_nodes()), 9.0 * 64 * C.g.owned_nodes());
         }
     }
@@ -744,7 +744,7 @@ extern "C" int tp_elasticity_solve(tp_elasticity *e, const double *RHS, double *
     tp_grid *g = e->grid;
     const long n = e->mg.lv[0].ndof();
     // RHS <- RHS .* N (LinearElasticity.cc:542), on a scratch copy
-    hipLaunchKernelGGL(k_mul, dim3(grid_for(n)), dim3(BLK), 0, g->stream, e->d_bN, RHS, e->d_N, n);
+    TP_LAUNCH(k_mul, dim3(grid_for(n)), dim3(BLK), 0, g->stream, e->d_bN, RHS, e->d_N, n);
     count_launch(g, 24.0 * n, 1.0 * n);
     return e->mg.solve(e->d_bN, U, its, rnorm, bnorm, hist, hist_cap);
 }
@@ -796,7 +796,7 @@ extern "C" int tp_elasticity_objective(tp_elasticity *e, const double *U, const 
     const long nel_glob = (long)g->ex * g->ey * g->ez_glob;
     TP_TRY(halo_nodes(g, q, const_cast<double *>(U), 3));  // DMGlobalToLocal, :388-390
     const int nb = (int)((nel + BLK - 1) / BLK);
-    hipLaunchKernelGGL(k_objective, dim3(nb), dim3(BLK), 0, g->stream, q, e->d_KE, U, xPhys, Emin, Emax, penal, dfdx,
+    TP_LAUNCH(k_objective, dim3(nb), dim3(BLK), 0, g->stream, q, e->d_KE, U, xPhys, Emin, Emax, penal, dfdx,
                        g->partials);
     count_launch(g, 24.0 * q.owned_nodes() + 16.0 * nel, 2.0 * 600 * nel);
     TP_TRY(finish_reduction<2>(g, nb, S_TMP));
@@ -850,7 +850,7 @@ extern "C" int tp_elasticity_restrict(tp_elasticity *e, int l, const double *rf,
     MGSolver<3> &mg = e->mg;
     if (l < 0 || l + 1 >= mg.nlv) return TP_ERR_ARG;
     TP_TRY(mg.halo(l, const_cast<double *>(rf)));
-    hipLaunchKernelGGL((k_restrict<3>), dim3((int)((mg.lv[l + 1].g.owned_nodes() + BLK - 1) / BLK)), dim3(BLK), 0,
+    TP_LAUNCH((k_restrict<3>), dim3((int)((mg.lv[l + 1].g.owned_nodes() + BLK - 1) / BLK)), dim3(BLK), 0,
                        e->grid->stream, mg.lv[l + 1].g, mg.lv[l].g, rf, rc);
     return TP_OK;
 }
@@ -858,7 +858,7 @@ extern "C" int tp_elasticity_prolong_add(tp_elasticity *e, int l, const double *
     MGSolver<3> &mg = e->mg;
     if (l < 0 || l + 1 >= mg.nlv) return TP_ERR_ARG;
     TP_TRY(mg.halo(l + 1, const_cast<double *>(xc)));
-    hipLaunchKernelGGL((k_prolong_add<3>), dim3((int)((mg.lv[l].g.owned_nodes() + BLK - 1) / BLK)), dim3(BLK), 0,
+    TP_LAUNCH((k_prolong_add<3>), dim3((int)((mg.lv[l].g.owned_nodes() + BLK - 1) / BLK)), dim3(BLK), 0,
                        e->grid->stream, mg.lv[l + 1].g, mg.lv[l].g, xc, xf);
     return TP_OK;
 }

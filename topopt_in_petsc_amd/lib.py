@@ -6,7 +6,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libtopopt_amd.so")
+SO_PATH = os.environ.get("TP_LIB") or os.path.join(_HERE, "libtopopt_amd.so")  # TP_LIB: experiment builds
 _LIB = None
 
 
