@@ -112,6 +112,48 @@ __device__ inline double block_sum(double v) {
     return t;
 }
 
+// Tail of a reducing kernel: every workgroup has its NV partial sums in thread 0 (block_sum); they are written to
+// partials[v * nb + b] and the LAST workgroup to arrive adds them up in the same fixed order as k_reduce_final --
+// bitwise the same result, one launch less per dot product.  Hand-off per MI355X_MICROARCH.md ("8-byte agent atomics
+// both sides"): the partial goes out as a relaxed agent-scope atomic store (write-through, sc1), is drained with an
+// explicit vmcnt(0), then the relaxed agent atomic ticket; the last arriver reads the partials with relaxed
+// agent-scope atomic loads (served past its L1).  NO release fence: `buffer_wbl2` would write back the XCD's whole
+// dirty L2 once per workgroup -- measured +40 % on the design iteration when every block of the CG update did it.
+// Arrivals are counted on 8 shard counters (workgroup b -> shard b & 7, i.e. its XCD under round-robin dispatch) and
+// the last arriver of a shard on a top counter: same-address atomics serialise at ~12 ns each, which a single counter
+// turns into 100 us for an 8192-workgroup grid.  `ticket[0..8]` are left at 0.
+template <int NV>
+__device__ inline void reduce_tail(const double (&mine)[NV], double *__restrict__ partials, int nb, int b,
+                                   unsigned *ticket, double *__restrict__ out) {
+    __shared__ int s_last;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int v = 0; v < NV; v++)
+            __hip_atomic_store(&partials[(long)v * nb + b], mine[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int sh = b & 7;
+        const unsigned in_shard = (unsigned)((nb + 7 - sh) >> 3);  // workgroups b' < nb with b' & 7 == sh
+        int last = 0;
+        if (__hip_atomic_fetch_add(ticket + sh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1) {
+            __hip_atomic_store(ticket + sh, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned shards = (unsigned)(nb < 8 ? nb : 8);
+            last = __hip_atomic_fetch_add(ticket + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards - 1;
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < nb; i += BLK)
+            s += __hip_atomic_load(&partials[(long)v * nb + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s = block_sum(s);
+        if (threadIdx.x == 0) out[v] = s;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(ticket + 8, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // partials laid out [value][block]; out[v] = sum_b partials[v*nblocks + b]
 template <int NV>
 __global__ __launch_bounds__(BLK) void k_reduce_final(const double *__restrict__ partials, int nblocks,
@@ -158,17 +200,18 @@ __global__ __launch_bounds__(BLK) void k_pw_div(double *__restrict__ w, const do
     for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) w[i] = x[i] / y[i];
 }
 __global__ __launch_bounds__(BLK) void k_dot(const double *__restrict__ a, const double *__restrict__ b, long n,
-                                             double *__restrict__ partials) {
+                                             double *__restrict__ partials, unsigned *ticket, double *__restrict__ out) {
     double s = 0.0;
     for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) s += a[i] * b[i];
-    s = block_sum(s);
-    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+    const double v[1] = {block_sum(s)};
+    reduce_tail<1>(v, partials, gridDim.x, blockIdx.x, ticket, out);
 }
-__global__ __launch_bounds__(BLK) void k_sum(const double *__restrict__ a, long n, double *__restrict__ partials) {
+__global__ __launch_bounds__(BLK) void k_sum(const double *__restrict__ a, long n, double *__restrict__ partials,
+                                             unsigned *ticket, double *__restrict__ out) {
     double s = 0.0;
     for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) s += a[i];
-    s = block_sum(s);
-    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+    const double v[1] = {block_sum(s)};
+    reduce_tail<1>(v, partials, gridDim.x, blockIdx.x, ticket, out);
 }
 
 // splitmix64 -> [0,1): the synthetic-field generator of SURVEY.md 8(d)

@@ -358,7 +358,7 @@ extern "C" int tp_filter_project(tp_filter *f, const double *x, double *xTilde, 
         const int nb = grid_for(n, MAX_RED_BLOCKS);
         TP_LAUNCH(k_clamp01, dim3(nb), dim3(BLK), 0, s, xTilde, n, g->partials);
         count_launch(g, 16.0 * n, 0.0);
-        TP_TRY(finish_reduction<1>(g, nb, S_TMP));
+        TP_TRY(reduce_partials<1>(g, nb, S_TMP));
         double v;
         TP_TRY(read_scal(g, S_TMP, 1, &v));
         f->violations = (long)v;
@@ -412,7 +412,7 @@ extern "C" int tp_filter_mnd(tp_filter *f, const double *x, double *mnd) {
     const int nb = grid_for(f->nel, MAX_RED_BLOCKS);
     TP_LAUNCH(k_mnd, dim3(nb), dim3(BLK), 0, g->stream, x, f->nel, g->partials);
     count_launch(g, 8.0 * f->nel, 3.0 * f->nel);
-    TP_TRY(finish_reduction<1>(g, nb, S_TMP));
+    TP_TRY(reduce_partials<1>(g, nb, S_TMP));
     double v;
     TP_TRY(read_scal(g, S_TMP, 1, &v));
     *mnd = v / (double)((long)g->ex * g->ey * g->ez_glob);

@@ -37,8 +37,9 @@ template <int EPI, bool MASKED>
 __device__ __forceinline__ void fine_tile_run(const TileArgs &t, const NodeArgs &a, double (*s_u)[SLOT],
                                               double (*s_y)[TILE * TILE * 3], double (*s_e)[TILE * TILE], int bxi,
                                               int byi, int bzi) {
-    constexpr bool DIAG_FLY = (EPI == EPI_CHEB);
-    constexpr bool HAS_B = (EPI == EPI_RESID || EPI == EPI_CHEB);
+    constexpr bool IS_CHEB = (EPI == EPI_CHEB || EPI == EPI_CHEB_DOT);
+    constexpr bool DIAG_FLY = IS_CHEB;
+    constexpr bool HAS_B = (EPI == EPI_RESID || IS_CHEB);
     const int tid = threadIdx.x;
     const int tx = tid & (TILE - 1), ty = tid / TILE;
     const int bx = bxi * TOUT, by = byi * TOUT;
@@ -125,7 +126,7 @@ __device__ __forceinline__ void fine_tile_run(const TileArgs &t, const NodeArgs 
     const long ncq = 3 * ncol;
     const unsigned voff_out = node_ok ? 8u * (unsigned)ncq : 0x7FFFFF00u;  // byte offset inside an output plane
     double bo[3] = {0, 0, 0}, dd[3] = {0, 0, 0};
-    const bool read_prev = EPI == EPI_CHEB && a.c1 != 0.0 && !a.prev_zero;  // uniform, loop invariant
+    const bool read_prev = IS_CHEB && a.c1 != 0.0 && !a.prev_zero;  // uniform, loop invariant
     auto load_epi = [&](int pl) {
         const double *__restrict__ bp = a.b + 3 * plane * min(max(pl, 0), t.nzl - 1) + ncq;
 #pragma unroll
@@ -273,9 +274,10 @@ __device__ __forceinline__ void fine_tile_run(const TileArgs &t, const NodeArgs 
                 o[c] = y;
             } else if (EPI == EPI_RESID) {
                 o[c] = bo[c] - y;
-            } else if (EPI == EPI_CHEB) {
+            } else if (IS_CHEB) {
                 const double dprev = PREV ? xo - dd[c] : (a.c1 != 0.0 ? xo : 0.0);  // zero guess: u- = 0
                 o[c] = xo + (a.c1 * dprev + a.c2 * (di[c] * (bo[c] - y)));
+                if (EPI == EPI_CHEB_DOT) pdot = (s >= 1 && node_ok) ? fma(bo[c], o[c], pdot) : pdot;
             } else {
                 o[c] = y;
                 pdot = (s >= 1 && node_ok) ? fma(xo, y, pdot) : pdot;
@@ -308,9 +310,10 @@ __device__ __forceinline__ void fine_tile_run(const TileArgs &t, const NodeArgs 
     } else {
         for (int s = 0; s < nsteps; s++) step(s, std::false_type{});
     }
-    if (EPI == EPI_APPLY_DOT) {
-        pdot = block_sum(pdot);
-        if (tid == 0) a.partials[blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)] = pdot;
+    if (EPI == EPI_APPLY_DOT || EPI == EPI_CHEB_DOT) {
+        const double v[1] = {block_sum(pdot)};
+        reduce_tail<1>(v, a.partials, gridDim.x * gridDim.y * gridDim.z, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z),
+                       a.ticket, a.red_out);
     }
 }
 

@@ -14,6 +14,7 @@ struct tp_grid {
     int rank, nranks;
     double *partials;   // [dev] MAX_RED_BLOCKS * 4
     double *scal;       // [dev] 64 device scalars
+    unsigned *ticket;   // [dev] arrival counter of the in-kernel reduction tails (common.h: reduce_tail), rests at 0
     double *h_scal;     // pinned host mirror
     // accounting (algorithmic model)
     double alg_bytes, flops;
@@ -45,11 +46,9 @@ inline void count_launch(tp_grid *g, double bytes = 0.0, double flops = 0.0) {
     g->flops += flops;
 }
 
-// out = scal[slot .. slot+NV): block partials -> one value each, then summed over ranks
+// scal[slot .. slot+NV) holds this rank's sums (written by the producing kernel's reduce_tail): sum over ranks
 template <int NV>
-inline int finish_reduction(tp_grid *g, int nblocks, int slot) {
-    TP_LAUNCH(k_reduce_final<NV>, dim3(1), dim3(BLK), 0, g->stream, g->partials, nblocks, g->scal + slot);
-    count_launch(g);
+inline int finish_reduction(tp_grid *g, int slot) {
     if (g->has_comm) {
         if (g->comm.allreduce_inplace) {  // the CG scalars are reduced where they live
             if (g->comm.allreduce_inplace(g->comm.user, g->scal + slot, NV)) return TP_ERR_COMM;
@@ -62,6 +61,14 @@ inline int finish_reduction(tp_grid *g, int nblocks, int slot) {
     return TP_OK;
 }
 
+// the two-launch form for the once-per-call reductions (block partials in g->partials -> scal[slot..], then ranks)
+template <int NV>
+inline int reduce_partials(tp_grid *g, int nblocks, int slot) {
+    TP_LAUNCH(k_reduce_final<NV>, dim3(1), dim3(BLK), 0, g->stream, g->partials, nblocks, g->scal + slot);
+    count_launch(g);
+    return finish_reduction<NV>(g, slot);
+}
+
 // blocking read of device scalars (the only host synchronisation of the Krylov loop)
 inline int read_scal(tp_grid *g, int slot, int n, double *out) {
     TP_HIP(hipMemcpyAsync(g->h_scal, g->scal + slot, sizeof(double) * n, hipMemcpyDeviceToHost, g->stream));
@@ -71,16 +78,16 @@ inline int read_scal(tp_grid *g, int slot, int n, double *out) {
 }
 
 inline int dot_to_slot(tp_grid *g, const double *a, const double *b, long n, int slot) {
-    int nb = grid_for(n, MAX_RED_BLOCKS);
-    TP_LAUNCH(k_dot, dim3(nb), dim3(BLK), 0, g->stream, a, b, n, g->partials);
+    int nb = grid_for(n, 2048);
+    TP_LAUNCH(k_dot, dim3(nb), dim3(BLK), 0, g->stream, a, b, n, g->partials, g->ticket, g->scal + slot);
     count_launch(g, 16.0 * n, 2.0 * n);
-    return finish_reduction<1>(g, nb, slot);
+    return finish_reduction<1>(g, slot);
 }
 inline int sum_to_slot(tp_grid *g, const double *a, long n, int slot) {
-    int nb = grid_for(n, MAX_RED_BLOCKS);
-    TP_LAUNCH(k_sum, dim3(nb), dim3(BLK), 0, g->stream, a, n, g->partials);
+    int nb = grid_for(n, 2048);
+    TP_LAUNCH(k_sum, dim3(nb), dim3(BLK), 0, g->stream, a, n, g->partials, g->ticket, g->scal + slot);
     count_launch(g, 8.0 * n, 1.0 * n);
-    return finish_reduction<1>(g, nb, slot);
+    return finish_reduction<1>(g, slot);
 }
 
 // Generic neighbour exchange of `rows` segments of `seg` doubles each (pitch in

@@ -527,7 +527,8 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
         if (more) store_plane(b0, pre);
     }
     if (EPI == EPI_APPLY_DOT) {
-        pdot = block_sum(pdot);
-        if (tid == 0) a.partials[blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)] = pdot;
+        const double v[1] = {block_sum(pdot)};
+        reduce_tail<1>(v, a.partials, gridDim.x * gridDim.y * gridDim.z, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z),
+                       a.ticket, a.red_out);
     }
 }

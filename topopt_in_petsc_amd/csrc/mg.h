@@ -52,7 +52,8 @@ enum { S_BB = 0, S_RR = 1, S_PW = 2, S_RZ0 = 3, S_RZ1 = 4, S_TMP = 8 };
 __global__ __launch_bounds__(BLK) void k_cg_update_xr(double *__restrict__ x, double *__restrict__ r,
                                                       const double *__restrict__ p, const double *__restrict__ w,
                                                       const double *__restrict__ scal, int slot_rz, long off, long n,
-                                                      double *__restrict__ partials) {
+                                                      double *__restrict__ partials, unsigned *ticket,
+                                                      double *__restrict__ out) {
     const double alpha = scal[slot_rz] / scal[S_PW];
     double s = 0.0;
     for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
@@ -62,8 +63,8 @@ __global__ __launch_bounds__(BLK) void k_cg_update_xr(double *__restrict__ x, do
         r[q] = rn;
         s = fma(rn, rn, s);
     }
-    s = block_sum(s);
-    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+    const double v[1] = {block_sum(s)};
+    reduce_tail<1>(v, partials, gridDim.x, blockIdx.x, ticket, out);
 }
 // p = z + (rz_new/rz_old) p   (first: p = z)
 __global__ __launch_bounds__(BLK) void k_cg_update_p(double *__restrict__ p, const double *__restrict__ z,
@@ -441,12 +442,16 @@ struct MGSolver {
             last_nblocks = tx * ty * tz;
             TileArgs ta{L.g.nx, L.g.ny, L.g.nzl, L.g.ex, L.g.ey, L.g.ezl, L.g.own_lo, L.g.own_hi, kz,
                         L.E, L.mask, L.colmask, L.sym_slot * SYMKE_STRIDE, 0, 0, nullptr, xcd_remap(), 0};
-            if (fine_v == 2)
+            if (fine_v == 2) {
                 TP_LAUNCH((k_fine_tile<EPI>), dim3(tx, ty, tz), dim3(TILE * TILE), 0, grid->stream, ta, a);
-            else
-                TP_LAUNCH((k_matfree_tile<EPI, 0>), dim3(tx, ty, tz), dim3(TILE * TILE), 0, grid->stream, ta, a);
+            } else {
+                if constexpr (EPI == EPI_CHEB_DOT) return TP_ERR_STATE;
+                else TP_LAUNCH((k_matfree_tile<EPI, 0>), dim3(tx, ty, tz), dim3(TILE * TILE), 0, grid->stream, ta, a);
+            }
             bytes = 16.0 * DOF * nown + 8.0 * L.g.own_elems();
             flops = 2.0 * 576 * (double)L.g.own_elems();
+        } else if constexpr (EPI == EPI_CHEB_DOT) {
+            return TP_ERR_STATE;  // only the fine tile kernel carries the fused b . x_out
         } else if (DOF == 3 && L.kind == LV_MACRO) {
             const int tx = (L.g.nx + TOUT - 1) / TOUT, ty = (L.g.ny + TOUT - 1) / TOUT;
             const int planes = L.g.own_hi - L.g.own_lo + 1;
@@ -499,7 +504,7 @@ struct MGSolver {
         }
         if (EPI == EPI_RESID) bytes += 8.0 * DOF * nown;
         // d (r/w), b, dinv -- the fine tile kernel instead reads b and the previous iterate (3-term form, diagonal on the fly)
-        if (EPI == EPI_CHEB) bytes += (three_term(L) ? 2.0 : 4.0) * 8.0 * DOF * nown;
+        if (EPI == EPI_CHEB || EPI == EPI_CHEB_DOT) bytes += (three_term(L) ? 2.0 : 4.0) * 8.0 * DOF * nown;
         count_launch(grid, bytes, flops);
         return TP_OK;
     }
@@ -518,7 +523,8 @@ struct MGSolver {
     }
 
     // Chebyshev(k)-Jacobi; the iterate ping-pongs between L.x and L.x2, on exit L.x holds it
-    int smooth(int l, const double *b, int k, bool zero_guess) {
+    // dot_slot >= 0: the LAST step also leaves b . x in scal[dot_slot] (this rank's part; fine tile kernel only)
+    int smooth(int l, const double *b, int k, bool zero_guess, int dot_slot = -1) {
         if (replicate && l == nlv - 1) {
             // coarsest level replicated on every rank: one all-gather of the right-hand side instead of a
             // halo exchange per Chebyshev step; the result comes back with its ghost planes filled
@@ -562,10 +568,23 @@ struct MGSolver {
                 rho = rn;
             }
             TP_TRY(halo(l, L.x));
-            TP_TRY(op<EPI_CHEB>(l, a));
+            if (dot_slot >= 0 && it == k - 1) {
+                a.partials = grid->partials;
+                a.ticket = grid->ticket;
+                a.red_out = grid->scal + dot_slot;
+                TP_TRY(op<EPI_CHEB_DOT>(l, a));
+            } else {
+                TP_TRY(op<EPI_CHEB>(l, a));
+            }
             std::swap(L.x, L.x2);
         }
         return TP_OK;
+    }
+    // can the last post-smoothing step of a V-cycle return r . z ?  (fine tile kernel, at least one fused step)
+    bool can_fuse_rz() const {
+        static const int fine_v = getenv("TP_FINE_V") ? atoi(getenv("TP_FINE_V")) : 2;
+        static const bool off = getenv("TP_NO_FUSE_RZ") != nullptr;
+        return !off && fine_v == 2 && nlv > 1 && three_term(lv[0]) && opt.nsmooth >= 1;
     }
 
     // every rank's owned rows of `nseg` consecutive level vectors (stride src_stride / dst_stride) -> the
@@ -605,7 +624,7 @@ struct MGSolver {
     }
 
     // PCMG multiplicative V-cycle with zero initial guesses; result in lv[l].x
-    int vcycle(int l, const double *b) {
+    int vcycle(int l, const double *b, int dot_slot = -1) {
         Level<DOF> &L = lv[l];
         if (l == nlv - 1) return smooth(l, b, opt.ncoarse, true);
         TP_TRY(smooth(l, b, opt.nsmooth, true));
@@ -627,7 +646,7 @@ struct MGSolver {
         TP_LAUNCH((k_prolong_add<DOF>), dim3((int)((L.g.owned_nodes() + BLK - 1) / BLK)), dim3(BLK), 0,
                            grid->stream, C.g, L.g, C.x, L.x);
         count_launch(grid, 8.0 * DOF * (2 * L.g.owned_nodes() + C.g.owned_nodes()), 2.0 * 8 * DOF * L.g.owned_nodes());
-        return smooth(l, b, opt.nsmooth, false);
+        return smooth(l, b, opt.nsmooth, false, l == 0 ? dot_slot : -1);
     }
 
     // Jacobi diagonal + Chebyshev bound of a matrix-free level
@@ -789,8 +808,8 @@ struct MGSolver {
     }
 
     // z = M r : one V-cycle.  Returns the pointer holding z (lv[0].x).
-    int precond(const double *r, double **z) {
-        TP_TRY(vcycle(0, r));
+    int precond(const double *r, double **z, int dot_slot = -1) {
+        TP_TRY(vcycle(0, r, dot_slot));
         *z = lv[0].x;
         return TP_OK;
     }
@@ -803,7 +822,7 @@ struct MGSolver {
         Level<DOF> &L = lv[0];
         hipStream_t s = grid->stream;
         const long off = L.own_off(), n = L.own_n();
-        const int nb = grid_for(n, MAX_RED_BLOCKS);
+        const int nb = grid_for(n, 2048);  // one resident round of workgroups; the reduction tail wants few arrivals
         double *r = cg_r, *p = cg_p, *w = cg_w;
         {
             NodeArgs a{};
@@ -815,7 +834,7 @@ struct MGSolver {
         }
         TP_LAUNCH(k_dot2, dim3(nb), dim3(BLK), 0, s, b, b, r, r, off, n, grid->partials);
         count_launch(grid, 16.0 * n, 4.0 * n);
-        TP_TRY(finish_reduction<2>(grid, nb, S_BB));
+        TP_TRY(reduce_partials<2>(grid, nb, S_BB));
         double v2[2];
         TP_TRY(read_scal(grid, S_BB, 2, v2));
         const double bnorm = sqrt(v2[0]);
@@ -828,8 +847,13 @@ struct MGSolver {
         if (rnorm > ttol) {
             for (its = 1; its <= opt.max_it; its++) {
                 double *z;
-                TP_TRY(precond(r, &z));
-                TP_TRY(dot_to_slot(grid, r + off, z + off, n, rz_cur));
+                if (can_fuse_rz()) {  // r . z comes out of the V-cycle's last smoothing step
+                    TP_TRY(precond(r, &z, rz_cur));
+                    TP_TRY(finish_reduction<1>(grid, rz_cur));
+                } else {
+                    TP_TRY(precond(r, &z));
+                    TP_TRY(dot_to_slot(grid, r + off, z + off, n, rz_cur));
+                }
                 TP_LAUNCH(k_cg_update_p, dim3(grid_for(n)), dim3(BLK), 0, s, p, z, grid->scal, rz_cur, rz_old,
                                    its == 1 ? 1 : 0, off, n);
                 count_launch(grid, 24.0 * n, 2.0 * n);
@@ -838,14 +862,16 @@ struct MGSolver {
                     a.x = p;
                     a.out = w;
                     a.partials = grid->partials;
+                    a.ticket = grid->ticket;
+                    a.red_out = grid->scal + S_PW;
                     TP_TRY(halo(0, p));
                     TP_TRY(op<EPI_APPLY_DOT>(0, a));
-                    TP_TRY(finish_reduction<1>(grid, last_nblocks, S_PW));
+                    TP_TRY(finish_reduction<1>(grid, S_PW));
                 }
                 TP_LAUNCH(k_cg_update_xr, dim3(nb), dim3(BLK), 0, s, x, r, p, w, grid->scal, rz_cur, off, n,
-                                   grid->partials);
+                                   grid->partials, grid->ticket, grid->scal + S_RR);
                 count_launch(grid, 48.0 * n, 6.0 * n);
-                TP_TRY(finish_reduction<1>(grid, nb, S_RR));
+                TP_TRY(finish_reduction<1>(grid, S_RR));
                 double rr;
                 TP_TRY(read_scal(grid, S_RR, 1, &rr));
                 rnorm = sqrt(rr);

@@ -101,7 +101,9 @@ struct DiaOp {
 
 // ---------------------------------------------------------------------------
 // epilogues of the node kernel
-enum { EPI_APPLY = 0, EPI_RESID = 1, EPI_CHEB = 2, EPI_APPLY_DOT = 3 };
+// EPI_CHEB_DOT (fine tile kernel only): Chebyshev step that also returns b . x_out -- the r.z of CG when it is the
+// last smoothing step of the V-cycle
+enum { EPI_APPLY = 0, EPI_RESID = 1, EPI_CHEB = 2, EPI_APPLY_DOT = 3, EPI_CHEB_DOT = 4 };
 
 struct NodeArgs {
     const double *x;     // operator input
@@ -111,7 +113,9 @@ struct NodeArgs {
     const double *dinv;  // CHEB Jacobi
     double c1, c2;       // CHEB recurrence coefficients
     int prev_zero;       // CHEB, 3-term form: the previous iterate is the zero guess (not read)
-    double *partials;    // APPLY_DOT: per-block partial of x . (A x)
+    double *partials;    // APPLY_DOT / CHEB_DOT: per-block partials of x . (A x) / b . x_out
+    unsigned *ticket;    // ... arrival counter and result of the in-kernel reduction tail (common.h)
+    double *red_out;
 };
 
 template <int DOF, class Op, int EPI>
@@ -146,8 +150,8 @@ __global__ __launch_bounds__(BLK) void k_node(Op op, NodeArgs a) {
         }
     }
     if (EPI == EPI_APPLY_DOT) {
-        pdot = block_sum(pdot);
-        if (threadIdx.x == 0) a.partials[blockIdx.x] = pdot;
+        const double v[1] = {block_sum(pdot)};
+        reduce_tail<1>(v, a.partials, gridDim.x, blockIdx.x, a.ticket, a.red_out);
     }
 }
 
@@ -309,8 +313,8 @@ __global__ __launch_bounds__(BLK) void k_dia_row(DiaOp<DOF> op, NodeArgs a) {
         }
     }
     if (EPI == EPI_APPLY_DOT) {
-        pdot = block_sum(pdot);
-        if (threadIdx.x == 0) a.partials[blockIdx.x] = pdot;
+        const double v[1] = {block_sum(pdot)};
+        reduce_tail<1>(v, a.partials, gridDim.x, blockIdx.x, a.ticket, a.red_out);
     }
 }
 
@@ -384,7 +388,7 @@ __global__ __launch_bounds__(BLK) void k_dia_row_split(DiaOp<DOF> op, NodeArgs a
         }
     }
     if (EPI == EPI_APPLY_DOT) {
-        pdot = block_sum(pdot);
-        if (threadIdx.x == 0) a.partials[blockIdx.x] = pdot;
+        const double v[1] = {block_sum(pdot)};
+        reduce_tail<1>(v, a.partials, gridDim.x, blockIdx.x, a.ticket, a.red_out);
     }
 }

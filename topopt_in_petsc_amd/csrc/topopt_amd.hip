@@ -31,11 +31,13 @@ extern "C" int tp_grid_create(tp_grid **out, const tp_grid_opts *o) {
     if (nblk < MAX_RED_BLOCKS) nblk = MAX_RED_BLOCKS;
     if (hipMalloc((void **)&g->partials, sizeof(double) * 4 * (size_t)nblk) != hipSuccess ||
         hipMalloc((void **)&g->scal, sizeof(double) * 64) != hipSuccess ||
+        hipMalloc((void **)&g->ticket, sizeof(unsigned) * 16) != hipSuccess ||
         hipHostMalloc((void **)&g->h_scal, sizeof(double) * 64) != hipSuccess) {
         delete g;
         return TP_ERR_HIP + (int)hipErrorOutOfMemory;
     }
     (void)hipMemsetAsync(g->scal, 0, sizeof(double) * 64, g->stream);
+    (void)hipMemsetAsync(g->ticket, 0, sizeof(unsigned) * 16, g->stream);
     double W[512];
     host_W(W);
     TP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_W), W, sizeof(W)));
@@ -195,6 +197,7 @@ extern "C" int tp_grid_destroy(tp_grid *g) {
     rccl_comm_destroy(g->rccl);
     (void)hipFree(g->partials);
     (void)hipFree(g->scal);
+    (void)hipFree(g->ticket);
     (void)hipHostFree(g->h_scal);
     delete g;
     return TP_OK;
@@ -799,7 +802,7 @@ extern "C" int tp_elasticity_objective(tp_elasticity *e, const double *U, const 
     TP_LAUNCH(k_objective, dim3(nb), dim3(BLK), 0, g->stream, q, e->d_KE, U, xPhys, Emin, Emax, penal, dfdx,
                        g->partials);
     count_launch(g, 24.0 * q.owned_nodes() + 16.0 * nel, 2.0 * 600 * nel);
-    TP_TRY(finish_reduction<2>(g, nb, S_TMP));
+    TP_TRY(reduce_partials<2>(g, nb, S_TMP));
     double v[2];
     TP_TRY(read_scal(g, S_TMP, 2, v));
     if (fx) *fx = v[0];
