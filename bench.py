@@ -6,8 +6,10 @@
 
 on a synthetic cantilever; metric = DOF-updates/s = n_DOF / t_step.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU, z-slabs, weak scaling)
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
+    (N > 1: one rank per GPU over RCCL, z-slabs.  Launched by torch.distributed.run -- or plainly: the script then
+    re-executes itself under torch.distributed.run on 127.0.0.1.  weak (default): the workload's mesh PER GPU, i.e.
+    128^3 elements per slab; strong: the workload's mesh split over the N slabs.)
 
 Prints ONE JSON line on rank 0.
 """
@@ -50,10 +52,24 @@ def parse():
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="gloo + --same-device validates the multi-rank path on a 1-GPU box")
     p.add_argument("--same-device", action="store_true")
+    p.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                   help="weak: the workload mesh per GPU (default); strong: the workload mesh split over the GPUs")
+    p.add_argument("--no-cube256", action="store_true", help="skip the 256^3 fine-kernel roofline entry")
     return p.parse_args()
 
 
-def cpu_baseline(sample, rtol, fine_eig):
+def respawn_under_torchrun(n):
+    """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run ... bench.py --gpus N`."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
+def cpu_baseline(sample, rtol, fine_eig, gpu_ndof):
     """The oracle (a port of the reference's assembled-CSR path, OpenMP) timed on
     the host cores for one step of the same algorithm on a bounded sample mesh."""
     from oracle import oracle as orc
@@ -76,12 +92,46 @@ def cpu_baseline(sample, rtol, fine_eig):
     t = time.perf_counter() - t0
     ndof = 3 * nx * ny * nz
     return {"value": ndof / t, "unit": "DOF-updates/s", "cores": cores, "kind": "port",
-            "sample": "1 step on %s elements (%d DOF), %d levels, CG its %d, %.2f s; assembled CSR + Galerkin SpGEMM "
-                      "(the reference's data path), OpenMP on %d threads" % (sample, ndof, nlv, its, t, cores)}
+            "sample_n_dof": ndof, "gpu_line_n_dof": gpu_ndof,
+            "sample": "1 step on %s elements (%d DOF -- NOT the GPU line's %d-DOF mesh: bounded to ~15 s of host time), "
+                      "%d levels, CG its %d, %.2f s; assembled CSR + Galerkin SpGEMM (the reference's data path), "
+                      "OpenMP on %d threads" % (sample, ndof, gpu_ndof, nlv, its, t, cores)}
+
+
+def fine_kernel_times(tp, torch, ex, ey, ez, reps):
+    """HIP-event averages of the two fine-level kernels on an ex x ey x ez mesh (1 level, synthetic density):
+    (spmv_ms, cheb_ms, n_nodes, n_elems)."""
+    h = 1.0 / ey
+    grid = tp.Grid(ex + 1, ey + 1, ez + 1, h)
+    le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=1))
+    le.SetUpLoadAndBC()
+    le.AssembleStiffnessMatrix(grid.synth_density(12345), 1e-9, 1.0, 3.0)
+    u = grid.node_vec(3).normal_()
+    y = torch.zeros_like(u)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def timed(fn, n):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    k = 8
+    spmv = timed(lambda: le.MatMult(u, y), reps)
+    cheb = (timed(lambda: le.smooth(0, u, y, k, False), max(reps // 4, 2)) -
+            timed(lambda: le.smooth(0, u, y, 0, False), max(reps // 4, 2))) / k
+    return spmv, cheb, (ex + 1) * (ey + 1) * (ez + 1), ex * ey * ez
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(a.gpus)
     import torch
     import torch.distributed as dist
     import topopt_in_petsc_amd as tp
@@ -90,8 +140,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, a.gpus))
     dev = 0 if a.same_device else local_rank
     torch.cuda.set_device(dev)
     if world > 1:
@@ -104,7 +153,9 @@ def main():
     ex, ey, ezg, nlv = WORKLOADS[a.workload][:4]
     ftype, bc = (WORKLOADS[a.workload] + (1, "cantilever"))[4:6]
     nlv = a.nlvls or nlv
-    ez = ezg * world  # weak scaling: fixed slab per GPU
+    if a.scaling == "strong" and (ezg % world or (ezg // world) % (1 << (nlv - 1))):
+        raise SystemExit("strong scaling: %d element layers do not split into %d slabs of whole coarse layers" % (ezg, world))
+    ez = ezg * world if a.scaling == "weak" else ezg  # weak: fixed slab per GPU; strong: fixed mesh
     nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
     ndof = 3 * nx * ny * nz
     grid = tp.Grid(nx, ny, nz, h, rank=rank, nranks=world)
@@ -201,21 +252,38 @@ def main():
         rec = json.load(open(tj)).get("%dx%dx%d" % (ex, ey, part.ez_own))
         if rec:
             traffic = rec
-    roofline = {"bound": "hbm", "kernel": "k_matfree_tile<EPI_CHEB,0> (fine-level matrix-free hex8 operator fused with "
+    roofline = {"bound": "hbm", "kernel": "k_fine_tile<EPI_CHEB> (fine-level matrix-free hex8 operator fused with "
                                           "the Chebyshev-Jacobi update)",
                 "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                 "traffic": (traffic or {}).get("cheb_hbm_bytes_per_launch", None) and traffic["cheb_hbm_bytes_per_launch"] / 1e9,
-                "traffic_unit": "GB per launch (PMC)", "alg_bytes_per_launch": cheb_bytes, "avg_launch_ms": cheb_ms,
-                "spmv": {"kernel": "k_matfree_tile<EPI_APPLY,0> (plain y = K u)", "alg_bytes_per_launch": spmv_bytes,
+                "traffic_unit": "GB per launch (PMC)",
+                "traffic_source": "profiles/spmv_traffic.json (static: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                  "of tools/pmc_traffic.py on this mesh, not measured in this run)" if traffic else None,
+                "alg_bytes_per_launch": cheb_bytes, "avg_launch_ms": cheb_ms,
+                "spmv": {"kernel": "k_fine_tile<EPI_APPLY> (plain y = K u)", "alg_bytes_per_launch": spmv_bytes,
                          "avg_launch_ms": spmv_ms, "achieved": spmv_bytes / (spmv_ms * 1e-3) / 1e9,
                          "frac": spmv_bytes / (spmv_ms * 1e-3) / 1e9 / 8000.0,
                          "traffic": (traffic or {}).get("hbm_bytes_per_launch", None) and traffic["hbm_bytes_per_launch"] / 1e9,
                          "fp64_tflops_dense_equiv": 1152.0 * n_el_own / (spmv_ms * 1e-3) / 1e12}}
+    # the north-star mesh of the SpMV target (256^3 elements, 50.9 M DOF; vectors 407 MB each: beyond the 256 MB
+    # Infinity Cache), measured in this run on rank 0 of a 1-GPU job
+    if world == 1 and not a.no_cube256 and a.workload == "cantilever128":
+        u = y = None
+        s256, c256, nn, ne = fine_kernel_times(tp, torch, 256, 256, 256, 10)
+        rec = json.load(open(tj)).get("256x256x256") if os.path.exists(tj) else None
+        roofline["spmv256"] = {
+            "mesh": "256x256x256 elements (50923779 DOF)",
+            "spmv": {"alg_bytes_per_launch": 48.0 * nn + 8.0 * ne, "avg_launch_ms": s256,
+                     "achieved": (48.0 * nn + 8.0 * ne) / (s256 * 1e-3) / 1e9, "frac": (48.0 * nn + 8.0 * ne) / (s256 * 1e-3) / 1e9 / 8000.0,
+                     "traffic": rec and rec.get("hbm_bytes_per_launch") and rec["hbm_bytes_per_launch"] / 1e9},
+            "cheb": {"alg_bytes_per_launch": 96.0 * nn + 8.0 * ne, "avg_launch_ms": c256,
+                     "achieved": (96.0 * nn + 8.0 * ne) / (c256 * 1e-3) / 1e9, "frac": (96.0 * nn + 8.0 * ne) / (c256 * 1e-3) / 1e9 / 8000.0,
+                     "traffic": rec and rec.get("cheb_hbm_bytes_per_launch") and rec["cheb_hbm_bytes_per_launch"] / 1e9}}
 
     out = {
         "metric": "DOF-updates/s per design iter (assembly+PCG+filter)",
         "value": ndof / t_step, "unit": "DOF-updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": t_step * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": t_step * 1e3, "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s: %s %dx%dx%d elements (%d DOF), z-slabs over %d GPU(s), rmin=2.56h %s "
                                "filter, CG + %d-level GMG (Chebyshev(%d)-Jacobi, coarse Chebyshev(%d), Galerkin), rtol %g, fine-level eig %s, cold start, "
@@ -228,13 +296,14 @@ def main():
                    "solver_dof_its_per_s": ndof * info.get("solve_its", 0) / max(info.get("solve_s", 0.0), 1e-30),
                    "solve_ms_per_step": 1e3 * info.get("solve_s", 0.0) / max(a.steps, 1),
                    "mma_ms_per_update": mma_ms,
-                   "parallelism": "zslab%d" % world, "comm": grid.comm_kind, "kernel_launches_per_step": launches / max(a.steps, 1),
+                   "parallelism": "zslab%d" % world, "comm": grid.comm_kind, "halo_overlap": grid.halo_overlap,
+                   "scaling_note": "weak: %dx%dx%d elements per GPU" % (ex, ey, ezg) if a.scaling == "weak" else "strong: fixed %dx%dx%d mesh" % (ex, ey, ezg), "kernel_launches_per_step": launches / max(a.steps, 1),
                    "alg_GB_per_step": alg_bytes / max(a.steps, 1) / 1e9,
                    "hot_path_alg_GBps": alg_bytes / dt / 1e9},
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.cpu_sample, a.rtol, a.fine_eig)
+        out["cpu_baseline"] = cpu_baseline(a.cpu_sample, a.rtol, a.fine_eig, ndof)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -55,9 +55,12 @@ extern "C" {
 #define TP_MAX_LEVELS 10
 
 /* ---- communication hooks (z-slab halo + reductions) -------------------- */
-/* The library never links RCCL itself: the host framework (torch.distributed
- * with the nccl(=RCCL) backend, or gloo in CPU/1-GPU tests) supplies two
- * stream-ordered operations on four staging buffers it owns.               */
+/* tp_comm is the set of slab-exchange operations the library calls: a staged neighbour exchange, an all-reduce
+ * of up to 16 doubles and an all-gather on staging buffers the host framework owns, plus two optional in-place
+ * forms (zero-copy halo of contiguous planes, in-place all-reduce).  All of them are ordered on the stream the grid
+ * was created with.  Two implementations exist: the host framework's hooks (torch.distributed with the nccl(=RCCL)
+ * backend, gloo in the CPU / one-GPU tests, MPI in a C++ host) and the library's own RCCL path, which replaces the
+ * hooks after tp_grid_use_rccl (RCCL is dlopen'ed from the path the host passes, never linked).               */
 typedef struct tp_comm {
     void *user;
     double *send_lo, *send_hi, *recv_lo, *recv_hi; /* [dev] staging, cap doubles each */
@@ -174,6 +177,11 @@ int tp_elasticity_objective(tp_elasticity *e, const double *U, const double *xPh
 /* introspection for parity tests */
 /* KSPSetTolerances (LinearElasticity.cc:646); a negative value keeps the current one (PETSC_DEFAULT) */
 int tp_elasticity_set_tolerances(tp_elasticity *le, double rtol, double atol, double dtol, int max_it);
+/* The parity solver as a literal PETSc 3.11 option string with the numeric per-level Chebyshev windows of the last
+ * tp_elasticity_assemble (KSPSetFromOptions, LinearElasticity.cc:659; -mg_levels_N_ksp_chebyshev_eigenvalues a,b):
+ * someone with a PETSc build can paste it on the reference's command line and compare the residual history.
+ * Returns the length of the full string (buf receives at most cap-1 characters), or -1 before the first assembly. */
+int tp_elasticity_petsc_options(const tp_elasticity *e, char *buf, size_t cap);
 int tp_elasticity_level_count(const tp_elasticity *e);
 long tp_elasticity_level_nodes(const tp_elasticity *e, int level);
 double tp_elasticity_level_lambda(const tp_elasticity *e, int level);
@@ -197,6 +205,8 @@ int tp_filter_mult_h(tp_filter *f, const double *x, double *y);
 int tp_filter_destroy(tp_filter *f);
 int tp_filter_stencil_width(const tp_filter *f);        /* ElemConn, Filter.cc:326 */
 int tp_filter_get_hs(tp_filter *f, double *Hs);          /* [dev, own elements] */
+/* PDE filter (type 2): the 8x8 Helmholtz element matrix KF of PDEFilt::PDEFilterMatrix (PDEFilter.cc:472-576), host */
+int tp_filter_get_kf(const tp_filter *f, double *kf_host_64);
 /* Filter::FilterProject (:60-117): x -> xTilde -> xPhys [dev, own elements] */
 int tp_filter_project(tp_filter *f, const double *x, double *xTilde, double *xPhys, int projectionFilter, double beta,
                       double eta);

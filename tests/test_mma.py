@@ -153,3 +153,38 @@ def test_restart_files_continue_the_run(tmp_path):
     # like the reference, xold is not part of the restart set (TopOpt.cc:380-381): the first ch is against volfrac
     assert b.history[1]["ch"] == pytest.approx(ref.history[7]["ch"], rel=1e-7, abs=1e-12)
     assert float((b.x - ref.x).abs().max()) < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m", [2, 6])
+def test_device_mma_several_constraints(orc, m):
+    """m > 1 constraints (MMA.cc:742-880: the dual is an m x m Newton system): the device update against the
+    oracle's reference-order sums, 1e-11.  m = 6 also exercises the (m + m^2) x 1024 block-partial buffer."""
+    import torch
+    import topopt_in_petsc_amd as tp
+    c, v = _toy(12 * 8 * 8, seed=3)
+    n = c.size
+    rng = np.random.default_rng(11)
+    W = rng.random((m, n)) + 0.5                      # constraint j: sum(W_j x) / sum(W_j) <= v_j
+    W /= W.sum(axis=1, keepdims=True)
+    vj = v * (1.0 + 0.05 * np.arange(m))
+    grid = tp.Grid(13, 9, 9, 0.125)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    x = np.full(n, v)
+    xd = dev(x)
+    m_o, m_d = orc.MMA(x, m), tp.MMA(grid, xd, m)
+    xmin_d, xmax_d = grid.elem_vec(), grid.elem_vec()
+    for it in range(6):
+        df = -c / x ** 2 * (10.0 / 2000.0)
+        g = [float(W[j] @ x - vj[j]) for j in range(m)]
+        dg = [W[j].copy() for j in range(m)]
+        xmin, xmax = m_o.SetOuterMovelimit(1e-3, 1.0, 0.2, x)
+        m_d.SetOuterMovelimit(1e-3, 1.0, 0.2, xd, xmin_d, xmax_d)
+        x = m_o.Update(x, df, g, dg, xmin, xmax)
+        m_d.Update(xd, dev(df), g, [dev(d) for d in dg], xmin_d, xmax_d)
+        assert m_d.last_inner == m_o.last_inner
+        xg = xd.cpu().numpy()
+        assert np.abs(xg - x).max() <= 1e-11, (it, np.abs(xg - x).max())
+        lam_d, lam_o = np.asarray(m_d.state()[0])[:m], np.asarray(m_o.state()[0])[:m]
+        assert np.abs(lam_d - lam_o).max() <= 1e-9 * max(np.abs(lam_o).max(), 1.0)
+        xd.copy_(dev(x))

@@ -64,3 +64,12 @@ def test_four_ranks_one_gpu_interior_slabs():
     on a mesh that does not line up with the tile sizes"""
     _launch("gpu", nproc=4, extra=(20, 12, 32, 3))
 
+
+
+@pytest.mark.gpu
+def test_eight_ranks_one_gpu_c3_c5_slab_geometry():
+    """The 8-GPU slab geometry of BASELINE configs C3 (256x128x128) and C5 (512x256x256) before hardware sees it:
+    8 ranks, 4 multigrid levels, 16 fine = 2 coarsest-level element layers per rank, replicated coarsest level,
+    interior ranks with neighbours on both sides -- on a mesh reduced in x-y (16x8x128), every rank on cuda:0,
+    against the serial oracle (residual history, U, objective, sensitivities, filters, every level operator)."""
+    _launch("gpu", nproc=8, timeout=900, extra=(16, 8, 128, 4))

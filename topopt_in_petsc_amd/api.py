@@ -73,12 +73,14 @@ class Grid:
         comm_p = None
         if nranks > 1:
             self.comm = SlabComm(self.part, self.device, group)
+            self.comm.stream = self.stream   # the hooks issue their collectives on the library's stream
             comm_p = C.cast(C.pointer(self.comm.c_struct), C.c_void_p)
         self._opts = _lib.GridOpts(nx, ny, nz, self.h[0], self.h[1], self.h[2], rank, nranks, self.device.index,
                                    self.stream.cuda_stream, comm_p)
         self.handle = C.c_void_p()
         _chk(self.L.tp_grid_create(C.byref(self.handle), C.byref(self._opts)), "tp_grid_create")
         self.comm_kind = "none" if nranks == 1 else "torch.distributed hooks"
+        self.halo_overlap = False
         if nranks > 1 and self.comm.backend == "nccl" and os.environ.get("TP_COMM", "rccl") != "torch":
             self._use_rccl(group)
 
@@ -239,6 +241,14 @@ class LinearElasticity:
         return self.Objective(xPhys, Emin, Emax, penal, volfrac, dfdx, dgdx)
 
     # ---- introspection used by the parity tests ----------------------------
+    def petsc_options(self):
+        """The solver of the last assembly as a literal PETSc 3.11 option string (numeric Chebyshev windows per level)."""
+        buf = C.create_string_buffer(8192)
+        n = self.L.tp_elasticity_petsc_options(self.handle, buf, len(buf))
+        if n < 0:
+            raise TopOptError(2, "tp_elasticity_petsc_options (no assembly yet)")
+        return buf.value.decode()
+
     def level_count(self):
         return self.L.tp_elasticity_level_count(self.handle)
 
@@ -309,6 +319,13 @@ class Filter:
         hs = self.grid.elem_vec()
         _chk(self.L.tp_filter_get_hs(self.handle, _ptr(hs)), "tp_filter_get_hs")
         return hs
+
+    def KF(self):
+        """PDE filter: the 8x8 Helmholtz element matrix (PDEFilter.cc:472-576), numpy"""
+        import numpy as np
+        kf = np.zeros(64)
+        _chk(self.L.tp_filter_get_kf(self.handle, kf.ctypes.data_as(C.c_void_p)), "tp_filter_get_kf")
+        return kf
 
     def FilterProject(self, x, xTilde, xPhys, projectionFilter=False, beta=0.1, eta=0.0):
         """Filter.cc:60-117"""

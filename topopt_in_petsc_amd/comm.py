@@ -25,6 +25,11 @@ class SlabComm:
         self.rank, self.nranks = part.rank, part.nranks
         assert dist.is_initialized(), "torch.distributed must be initialised for nranks > 1"
         self.backend = dist.get_backend(group)
+        # The library orders its kernels on the stream it was created with (api.Grid sets this attribute); the
+        # C callbacks below issue their collectives under that SAME stream, whatever stream is current when the
+        # library calls back (a Grid built inside a torch.cuda.stream(...) block and used outside it, or the reverse,
+        # would otherwise race on the staging buffers).
+        self.stream = None
         # staging: large enough for one 3-dof node plane and a few filter layers
         self.cap = int(cap or max(3 * part.plane, 4 * part.ex * part.ey, 1 << 20))
         mk = lambda n: torch.zeros(n, dtype=torch.float64, device=self.device)
@@ -153,7 +158,8 @@ class SlabComm:
                 print("SlabComm: zero-copy halo unavailable (%r); staging buffers are used instead" % (e,), flush=True)
                 return 2   # the library falls back to exchange() for good (same message sizes and order)
         try:
-            self.exchange_direct(*args)
+            with self._on_stream():
+                self.exchange_direct(*args)
             return 0
         except Exception as e:
             print("SlabComm.exchange_direct failed: %r" % (e,), flush=True)
@@ -188,9 +194,16 @@ class SlabComm:
         return r if self.group is None else dist.get_global_rank(self.group, r)
 
     # ---- C callbacks --------------------------------------------------------
+    def _on_stream(self):
+        import contextlib
+        if self.stream is not None and self.device.type == "cuda":
+            return torch.cuda.stream(self.stream)
+        return contextlib.nullcontext()
+
     def _exchange_cb(self, _user, n):
         try:
-            self.exchange(int(n))
+            with self._on_stream():
+                self.exchange(int(n))
             return 0
         except Exception as e:  # never let an exception cross the C boundary
             print("SlabComm.exchange failed: %r" % (e,), flush=True)
@@ -198,7 +211,8 @@ class SlabComm:
 
     def _allgather_cb(self, _user, n):
         try:
-            self.allgather(int(n))
+            with self._on_stream():
+                self.allgather(int(n))
             return 0
         except Exception as e:
             print("SlabComm.allgather failed: %r" % (e,), flush=True)
@@ -206,7 +220,8 @@ class SlabComm:
 
     def _allreduce_cb(self, _user, n):
         try:
-            self.allreduce_sum(int(n))
+            with self._on_stream():
+                self.allreduce_sum(int(n))
             return 0
         except Exception as e:
             print("SlabComm.allreduce_sum failed: %r" % (e,), flush=True)

@@ -339,6 +339,11 @@ extern "C" int tp_filter_destroy(tp_filter *f) {
     return TP_OK;
 }
 extern "C" int tp_filter_stencil_width(const tp_filter *f) { return f->conn; }
+extern "C" int tp_filter_get_kf(const tp_filter *f, double *kf_host_64) {
+    if (!f || !kf_host_64 || f->type != 2 || f->KF.size() < 64) return TP_ERR_ARG;
+    std::memcpy(kf_host_64, f->KF.data(), sizeof(double) * 64);
+    return TP_OK;
+}
 extern "C" int tp_filter_get_hs(tp_filter *f, double *Hs) {
     if (!f->Hs) return TP_ERR_STATE;
     TP_HIP(hipMemcpyAsync(Hs, f->Hs, sizeof(double) * (size_t)f->nel, hipMemcpyDeviceToDevice, f->grid->stream));

@@ -169,12 +169,14 @@ struct tp_mma {
     double *L, *U, *alpha, *beta, *p0, *q0, *pij, *qij, *xo1, *xo2;
     const double **d_dgdx;  // [dev] m pointers
     double *red;            // [dev] m + m*m reduced values
+    double *part;           // [dev] (m + m*m) x 1024 block partials of the MMA kernels (own buffer: g->partials is
+                            //       sized for 4 values per block)
     int last_inner;
 };
 
 static int mma_reduce(tp_mma *M, int nb, int nv, double *host) {
     tp_grid *g = M->grid;
-    TP_LAUNCH(k_reduce_multi, dim3(nv), dim3(BLK), 0, g->stream, g->partials, nb, nv, M->red);
+    TP_LAUNCH(k_reduce_multi, dim3(nv), dim3(BLK), 0, g->stream, M->part, nb, nv, M->red);
     count_launch(g);
     if (g->has_comm)
         for (int o = 0; o < nv; o += 16) {
@@ -215,6 +217,7 @@ extern "C" int tp_mma_create(tp_mma **out, tp_grid *g, long n_local, long n_glob
     TP_HIP(hipMalloc((void **)&M->qij, nb * m));
     TP_HIP(hipMalloc((void **)&M->d_dgdx, sizeof(double *) * m));
     TP_HIP(hipMalloc((void **)&M->red, sizeof(double) * 128));
+    TP_HIP(hipMalloc((void **)&M->part, sizeof(double) * 1024 * (size_t)(m + m * m)));
     TP_HIP(hipMemcpyAsync(M->xo1, x, nb, hipMemcpyDeviceToDevice, g->stream));
     TP_HIP(hipMemcpyAsync(M->xo2, x, nb, hipMemcpyDeviceToDevice, g->stream));
     M->last_inner = 0;
@@ -225,7 +228,7 @@ extern "C" int tp_mma_destroy(tp_mma *M) {
     if (!M) return TP_OK;
     (void)hipStreamSynchronize(M->grid->stream);
     for (void *p : {(void *)M->L, (void *)M->U, (void *)M->alpha, (void *)M->beta, (void *)M->p0, (void *)M->q0,
-                    (void *)M->xo1, (void *)M->xo2, (void *)M->pij, (void *)M->qij, (void *)M->d_dgdx, (void *)M->red})
+                    (void *)M->xo1, (void *)M->xo2, (void *)M->pij, (void *)M->qij, (void *)M->d_dgdx, (void *)M->red, (void *)M->part})
         (void)hipFree(p);
     delete M;
     return TP_OK;
@@ -240,22 +243,26 @@ extern "C" int tp_mma_set_outer_movelimit(tp_mma *M, double Xmin, double Xmax, d
 extern "C" int tp_mma_design_change(tp_mma *M, const double *x, double *xold, double *ch) {
     tp_grid *g = M->grid;
     const int nb = grid_for(M->n, 1024);
-    TP_LAUNCH(k_mma_change, dim3(nb), dim3(BLK), 0, g->stream, M->n, x, xold, g->partials);
-    TP_LAUNCH(k_max_final, dim3(1), dim3(BLK), 0, g->stream, g->partials, nb, M->red);
+    TP_LAUNCH(k_mma_change, dim3(nb), dim3(BLK), 0, g->stream, M->n, x, xold, M->part);
+    TP_LAUNCH(k_max_final, dim3(1), dim3(BLK), 0, g->stream, M->part, nb, M->red);
     count_launch(g, 24.0 * M->n, 1.0 * M->n);
     TP_HIP(hipMemcpyAsync(g->h_scal, M->red, sizeof(double), hipMemcpyDeviceToHost, g->stream));
     TP_HIP(hipStreamSynchronize(g->stream));
     double v = g->h_scal[0];
     if (g->has_comm) {
-        // max over ranks through the sum hook: gather each rank's value into its own slot
-        if (g->nranks > 16) return TP_ERR_ARG;
-        double slots[16] = {0};
-        slots[g->rank] = v;
-        TP_HIP(hipMemcpyAsync(g->comm.red, slots, sizeof(double) * g->nranks, hipMemcpyHostToDevice, g->stream));
-        if (g->comm.allreduce_sum(g->comm.user, g->nranks)) return TP_ERR_COMM;
-        TP_HIP(hipMemcpyAsync(g->h_scal, g->comm.red, sizeof(double) * g->nranks, hipMemcpyDeviceToHost, g->stream));
-        TP_HIP(hipStreamSynchronize(g->stream));
-        for (int r = 0; r < g->nranks; r++) v = fmax(v, g->h_scal[r]);
+        // max over ranks through the sum hook: every rank's value in its own slot, 16 slots (the hook's buffer) at a time
+        const double mine = v;
+        for (int o = 0; o < g->nranks; o += 16) {
+            const int cnt = g->nranks - o < 16 ? g->nranks - o : 16;
+            double slots[16] = {0};
+            if (g->rank >= o && g->rank < o + cnt) slots[g->rank - o] = mine;
+            TP_HIP(hipMemcpyAsync(g->comm.red, slots, sizeof(double) * cnt, hipMemcpyHostToDevice, g->stream));
+            TP_HIP(hipStreamSynchronize(g->stream));  // `slots` is a stack buffer
+            if (g->comm.allreduce_sum(g->comm.user, cnt)) return TP_ERR_COMM;
+            TP_HIP(hipMemcpyAsync(g->h_scal, g->comm.red, sizeof(double) * cnt, hipMemcpyDeviceToHost, g->stream));
+            TP_HIP(hipStreamSynchronize(g->stream));
+            for (int r = 0; r < cnt; r++) v = fmax(v, g->h_scal[r]);
+        }
     }
     *ch = v;
     return TP_OK;
@@ -296,7 +303,7 @@ extern "C" int tp_mma_update(tp_mma *M, double *x, const double *dfdx, const dou
     M->k++;
     TP_LAUNCH(k_mma_gensub, dim3(nb), dim3(BLK), 0, s, n, m, M->k, M->asyminit, M->asymdec, M->asyminc, x, M->xo1,
                        M->xo2, xmin, xmax, dfdx, M->d_dgdx, M->L, M->U, M->alpha, M->beta, M->p0, M->q0, M->pij, M->qij,
-                       g->partials);
+                       M->part);
     count_launch(g, 8.0 * n * (12.0 + 3.0 * m), 40.0 * n);
     TP_TRY(mma_reduce(M, nb, m, red));
     for (int j = 0; j < m; j++) M->b[j] = red[j] - gx[j];
@@ -329,7 +336,7 @@ extern "C" int tp_mma_update(tp_mma *M, double *x, const double *dfdx, const dou
             MmaLam lm;
             lam_yz(lm);
             TP_LAUNCH((k_mma_xyz<1>), dim3(nb), dim3(BLK), 0, s, n, m, lm, x, M->L, M->U, M->alpha, M->beta, M->p0,
-                               M->q0, M->pij, M->qij, g->partials);
+                               M->q0, M->pij, M->qij, M->part);
             count_launch(g, 8.0 * n * (7.0 + 2.0 * m), 40.0 * n);
             TP_TRY(mma_reduce(M, nb, m + m * m, red));
             for (int j = 0; j < m; j++) {
@@ -369,7 +376,7 @@ extern "C" int tp_mma_update(tp_mma *M, double *x, const double *dfdx, const dou
             }
             lam_yz(lm);
             TP_LAUNCH((k_mma_xyz<0>), dim3(nb), dim3(BLK), 0, s, n, m, lm, x, M->L, M->U, M->alpha, M->beta, M->p0,
-                               M->q0, M->pij, M->qij, g->partials);
+                               M->q0, M->pij, M->qij, M->part);
             count_launch(g, 8.0 * n * (7.0 + 2.0 * m), 20.0 * n);
             TP_TRY(mma_reduce(M, nb, m, red));
             err = 0.0;  // DualResidual

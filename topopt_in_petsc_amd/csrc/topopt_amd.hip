@@ -1,5 +1,7 @@
 // topopt_amd.hip -- C-ABI entry points (include/topopt_amd.h) of the MI355X-native
 // hot path.  gfx950 only; no CPU fallback anywhere in this library.
+#include <string>
+
 #include "elements.h"
 #include "mg.h"
 #include "rccl_comm.h"
@@ -94,30 +96,37 @@ extern "C" int tp_grid_comm_selfcheck(tp_grid *g, int *ok) {
             if (a[i] != tag + 1e-3 * (double)i) return false;
         return true;
     };
+    // A hook that fails on THIS rank must not end the sequence: the other ranks are inside the same collectives and
+    // would block.  Failures are recorded, every step runs on every rank, the verdict is returned at the end (the
+    // host then takes the minimum over ranks).
+    bool hook_failed = false;
     bool good = fill(c.send_lo, 100.0 * rk + 1.0) && fill(c.send_hi, 100.0 * rk + 2.0);
-    if (c.exchange(c.user, n)) return TP_ERR_COMM;
+    if (c.exchange(c.user, n)) hook_failed = true;
     if (rk > 0) good = good && check(c.recv_lo, 100.0 * (rk - 1) + 2.0);       // lower neighbour's send_hi
     if (rk < nr - 1) good = good && check(c.recv_hi, 100.0 * (rk + 1) + 1.0);  // upper neighbour's send_lo
     if (c.exchange_direct) {  // in place: use the staging areas as "vectors", crossed over
         good = good && fill(c.recv_lo, 100.0 * rk + 3.0) && fill(c.recv_hi, 100.0 * rk + 4.0);
         const int rc = c.exchange_direct(c.user, rk > 0 ? c.recv_lo : nullptr, rk > 0 ? c.send_lo : nullptr,
                                          rk < nr - 1 ? c.recv_hi : nullptr, rk < nr - 1 ? c.send_hi : nullptr, n);
-        if (rc == 1) return TP_ERR_COMM;
         if (rc == 0) {
             if (rk > 0) good = good && check(c.send_lo, 100.0 * (rk - 1) + 4.0);
             if (rk < nr - 1) good = good && check(c.send_hi, 100.0 * (rk + 1) + 3.0);
+        } else if (rc == 2) {
+            g->comm.exchange_direct = nullptr;  // the host cannot address our memory in place: staged exchange from now on
+        } else {
+            hook_failed = true;
         }
     }
     {   // sum over ranks of (rank + 1) in slot 0..3
         for (int i = 0; i < 4; i++) h[i] = (double)(rk + 1) * (i + 1);
         good = good && hipMemcpyAsync(c.red, h.data(), sizeof(double) * 4, hipMemcpyHostToDevice, st) == hipSuccess;
-        if (c.allreduce_sum(c.user, 4)) return TP_ERR_COMM;
+        if (c.allreduce_sum(c.user, 4)) hook_failed = true;
         good = good && hipMemcpyAsync(b.data(), c.red, sizeof(double) * 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
                hipStreamSynchronize(st) == hipSuccess;
         for (int i = 0; i < 4; i++) good = good && b[i] == 0.5 * nr * (nr + 1) * (i + 1);
         if (c.allreduce_inplace) {
             good = good && hipMemcpyAsync(c.red + 8, h.data(), sizeof(double) * 4, hipMemcpyHostToDevice, st) == hipSuccess;
-            if (c.allreduce_inplace(c.user, c.red + 8, 4)) return TP_ERR_COMM;
+            if (c.allreduce_inplace(c.user, c.red + 8, 4)) hook_failed = true;
             good = good && hipMemcpyAsync(b.data(), c.red + 8, sizeof(double) * 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
                    hipStreamSynchronize(st) == hipSuccess;
             for (int i = 0; i < 4; i++) good = good && b[i] == 0.5 * nr * (nr + 1) * (i + 1);
@@ -125,11 +134,11 @@ extern "C" int tp_grid_comm_selfcheck(tp_grid *g, int *ok) {
     }
     if (c.allgather) {
         good = good && fill(c.send_lo, 1000.0 * rk);
-        if (c.allgather(c.user, n)) return TP_ERR_COMM;
+        if (c.allgather(c.user, n)) hook_failed = true;
         for (int r = 0; r < nr; r++) good = good && check(c.gather + (long)r * n, 1000.0 * r);
     }
-    *ok = good ? 1 : 0;
-    return TP_OK;
+    *ok = (good && !hook_failed) ? 1 : 0;
+    return hook_failed ? TP_ERR_COMM : TP_OK;
 }
 extern "C" int tp_grid_comm_stats(const tp_grid *g, long *ex, long *red) {
     if (!g) return TP_ERR_ARG;
@@ -818,6 +827,42 @@ extern "C" int tp_elasticity_set_tolerances(tp_elasticity *e, double rtol, doubl
     if (dtol >= 0) e->mg.opt.dtol = dtol;
     if (max_it >= 0) e->mg.opt.max_it = max_it;
     return TP_OK;
+}
+// The solver configuration as a literal PETSc 3.11 option string (PETSc numbers the levels from the coarsest = 0 to
+// the finest = nlvls - 1; level 0 takes the -mg_coarse_ prefix), with the numeric Chebyshev windows of the LAST
+// assembly: pasted next to KSPSetFromOptions (LinearElasticity.cc:659; the level KSPs read their options in
+// PCSetUp_MG, after the reference's hard-coded KSPSetType calls) it reproduces this solver inside the reference.
+extern "C" int tp_elasticity_petsc_options(const tp_elasticity *e, char *buf, size_t cap) {
+    if (!e || !e->assembled) return -1;
+    const MGSolver<3> &mg = e->mg;
+    std::string o;
+    char t[512];
+    snprintf(t, sizeof t,
+             "-ksp_type cg -ksp_norm_type unpreconditioned -ksp_rtol %.17g -ksp_atol %.17g -ksp_divtol %.17g -ksp_max_it %d "
+             "-ksp_initial_guess_nonzero true -pc_type mg -pc_mg_levels %d -pc_mg_type multiplicative -pc_mg_cycle_type v "
+             "-pc_mg_galerkin both",
+             mg.opt.rtol, mg.opt.atol, mg.opt.dtol, mg.opt.max_it, mg.nlv);
+    o += t;
+    for (int l = 0; l < mg.nlv; l++) {
+        const Level<3> &L = mg.lv[l];
+        const int k = mg.nlv - 1 - l;  // PETSc level number
+        const bool coarse = (l == mg.nlv - 1 && l > 0);
+        char pre[32];
+        if (k == 0 && mg.nlv > 1) snprintf(pre, sizeof pre, "mg_coarse");
+        else snprintf(pre, sizeof pre, "mg_levels_%d", k);
+        const double lo = coarse ? L.lam_min : mg.opt.cheb_lo * L.lam, hi = mg.opt.cheb_hi * L.lam;
+        snprintf(t, sizeof t,
+                 " -%s_ksp_type chebyshev -%s_pc_type jacobi -%s_ksp_max_it %d -%s_ksp_norm_type none "
+                 "-%s_ksp_chebyshev_eigenvalues %.17g,%.17g",
+                 pre, pre, pre, coarse ? mg.opt.ncoarse : mg.opt.nsmooth, pre, pre, lo, hi);
+        o += t;
+    }
+    if (buf && cap > 0) {
+        const size_t n = o.size() < cap - 1 ? o.size() : cap - 1;
+        memcpy(buf, o.data(), n);
+        buf[n] = 0;
+    }
+    return (int)o.size();
 }
 extern "C" int tp_elasticity_level_count(const tp_elasticity *e) { return e->mg.nlv; }
 extern "C" long tp_elasticity_level_nodes(const tp_elasticity *e, int l) { return e->mg.lv[l].g.nodes(); }

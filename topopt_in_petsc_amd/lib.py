@@ -81,6 +81,7 @@ SYMBOLS = {
     "tp_elasticity_apply": (_i, [_vp, _vp, _vp]),
     "tp_elasticity_solve": (_i, [_vp, _vp, _vp, C.POINTER(_i), C.POINTER(_d), C.POINTER(_d), _vp, _i]),
     "tp_elasticity_objective": (_i, [_vp, _vp, _vp, _d, _d, _d, _d, C.POINTER(_d), C.POINTER(_d), _vp, _vp]),
+    "tp_elasticity_petsc_options": (_i, [_vp, C.c_char_p, C.c_size_t]),
     "tp_elasticity_level_count": (_i, [_vp]),
     "tp_elasticity_level_nodes": (_l, [_vp, _i]),
     "tp_elasticity_level_lambda": (_d, [_vp, _i]),
@@ -95,6 +96,7 @@ SYMBOLS = {
     "tp_filter_destroy": (_i, [_vp]),
     "tp_filter_stencil_width": (_i, [_vp]),
     "tp_filter_get_hs": (_i, [_vp, _vp]),
+    "tp_filter_get_kf": (_i, [_vp, _vp]),
     "tp_filter_project": (_i, [_vp, _vp, _vp, _vp, _i, _d, _d]),
     "tp_filter_gradients": (_i, [_vp, _vp, _vp, _vp, _i, C.POINTER(_vp), _i, _d, _d]),
     "tp_filter_mnd": (_i, [_vp, _vp, C.POINTER(_d)]),
