@@ -82,6 +82,11 @@ typedef struct tp_comm {
                            long n);
     /* optional: in-place sum over ranks of p[0..n), p any [dev] address (NULL -> staged through `red`) */
     int (*allreduce_inplace)(void *user, double *p, int n);
+    /* optional: issue the FOLLOWING operations on `stream` (a hipStream_t) instead of the grid's stream, until the
+     * next call (NULL restores the grid's stream).  With it and exchange_direct the library overlaps the halo of a
+     * smoothing step with the step's interior planes on a second stream (DMGlobalToLocalBegin ... End,
+     * LinearElasticity.cc:249-250); NULL -> every halo is exchanged on the grid's stream before its consumer. */
+    void (*set_stream)(void *user, void *stream);
 } tp_comm;
 
 /* ---- grid / partition --------------------------------------------------- */
@@ -115,6 +120,9 @@ int tp_rccl_load(const char *librccl_path);
 int tp_rccl_unique_id(void *id128);
 int tp_grid_use_rccl(tp_grid *g, const void *id128);
 int tp_grid_comm_stats(const tp_grid *g, long *exchanges, long *reductions);   /* RCCL path only, else zeros */
+/* halos that travelled on the second stream, overlapped with the interior planes of their producer (0 if the hooks
+ * lack set_stream / exchange_direct, or with TP_OVERLAP=0) */
+long tp_grid_overlapped_halos(const tp_grid *g);
 /* back to the tp_comm hooks given at creation (destroys the library's communicator) */
 int tp_grid_drop_rccl(tp_grid *g);
 /* collective: rank-tagged buffers through the grid's CURRENT hooks (staged and in-place exchange, reductions,

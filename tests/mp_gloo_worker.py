@@ -125,6 +125,8 @@ def gpu_mode(rank, world):
     fx, gx = le.ComputeObjectiveConstraintsSensitivities(df, dg, xp, 1e-9, 1.0, 3.0, 0.12, hist_cap=400)
     flt.Gradients(x, xt, df, [dg])
     mnd = flt.GetMND(xp)
+    xp_e = xp.clone()
+    own_t = torch.arange(le.U.numel(), device="cuda")[grid.part.owned_slice(3)]
     # ---- serial oracle on the global mesh
     xo = orc.synth_density(ex, ey, ez, h)
     of = orc.Filter(nx, ny, nz, h, 2.56 * h)
@@ -164,8 +166,20 @@ def gpu_mode(rank, world):
     xpf, its_p, _ = opf.apply(xo)
     assert pf.last_pde_solve()[0] == its_p
     assert rel(xt.cpu().numpy(), np.clip(xpf, 0, 1)[es]) <= 1e-9
-    print("rank %d gpu OK its=%d exchanges=%d allreduces=%d" % (rank, its, grid.comm.n_exchanges, grid.comm.n_allreduces),
-          flush=True)
+    # ---- halo overlap (second stream, boundary planes first) is ON by default and changes NOTHING bitwise: the same
+    # solve with TP_OVERLAP=0 semantics (a grid created with the switch off) gives the identical U and history
+    assert grid.halo_overlap > 0, "no halo travelled on the second stream"
+    os.environ["TP_OVERLAP"] = "0"
+    grid0 = tp.Grid(nx, ny, nz, h, rank=rank, nranks=world)
+    os.environ.pop("TP_OVERLAP")
+    le0 = tp.LinearElasticity(grid0, tp.SolverOptions(nlvls=nlv, rtol=1e-9, max_it=300))
+    le0.SetUpLoadAndBC()
+    le0.ComputeObjectiveConstraintsSensitivities(grid0.elem_vec(), grid0.elem_vec(), xp_e, 1e-9, 1.0, 3.0, 0.12, hist_cap=400)
+    assert grid0.halo_overlap == 0
+    assert np.array_equal(le0.last_hist, hh), "overlapped and blocking halos differ"
+    assert torch.equal(le0.U[own_t], le.U[own_t])
+    print("rank %d gpu OK its=%d exchanges=%d allreduces=%d overlapped=%d" %
+          (rank, its, grid.comm.n_exchanges, grid.comm.n_allreduces, grid.halo_overlap), flush=True)
 
 
 if __name__ == "__main__":

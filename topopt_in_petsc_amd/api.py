@@ -80,9 +80,13 @@ class Grid:
         self.handle = C.c_void_p()
         _chk(self.L.tp_grid_create(C.byref(self.handle), C.byref(self._opts)), "tp_grid_create")
         self.comm_kind = "none" if nranks == 1 else "torch.distributed hooks"
-        self.halo_overlap = False
         if nranks > 1 and self.comm.backend == "nccl" and os.environ.get("TP_COMM", "rccl") != "torch":
             self._use_rccl(group)
+
+    @property
+    def halo_overlap(self):
+        """number of halos that travelled on the second stream, overlapped with interior planes (0 = none)"""
+        return int(self.L.tp_grid_overlapped_halos(self.handle))
 
     def _use_rccl(self, group):
         """Hand the slab exchange to RCCL inside the library (tp_grid_use_rccl): same RCCL instance as

@@ -49,6 +49,8 @@ class SlabComm:
         self._ar_cb = _lib.ALLREDUCE_FN(self._allreduce_cb)
         self._ag_cb = _lib.EXCHANGE_FN(self._allgather_cb)
         self._dx_cb = _lib.DIRECT_FN(self._direct_cb)
+        self._ss_cb = _lib.SETSTREAM_FN(self._set_stream_cb)
+        self.home_stream = None
         self._raw_cache = {}
         self._direct_cache = {}
         self.n_direct = 0
@@ -56,7 +58,8 @@ class SlabComm:
         self.c_struct = _lib.Comm(None, p(self.send_lo), p(self.send_hi), p(self.recv_lo), p(self.recv_hi),
                                   p(self.red), self.cap, self._ex_cb, self._ar_cb, p(self.gather), self._ag_cb,
                                   self._dx_cb if self.device.type == "cuda" else _lib.DIRECT_FN(0),
-                                  _lib.INPLACE_FN(0))   # in-place reductions: only the in-library RCCL path has them
+                                  _lib.INPLACE_FN(0),   # in-place reductions: only the in-library RCCL path has them
+                                  self._ss_cb if self.device.type == "cuda" else _lib.SETSTREAM_FN(0))
 
     # ---- python-level API (also used directly by the CPU tests) -----------
     def exchange(self, n):
@@ -199,6 +202,15 @@ class SlabComm:
         if self.stream is not None and self.device.type == "cuda":
             return torch.cuda.stream(self.stream)
         return contextlib.nullcontext()
+
+    def _set_stream_cb(self, _user, stream):
+        """set_stream hook: the library's second (halo) stream, or NULL = back to the grid's stream"""
+        try:
+            if self.home_stream is None:
+                self.home_stream = self.stream
+            self.stream = torch.cuda.ExternalStream(stream, device=self.device) if stream else self.home_stream
+        except Exception as e:
+            print("SlabComm.set_stream failed: %r" % (e,), flush=True)
 
     def _exchange_cb(self, _user, n):
         try:

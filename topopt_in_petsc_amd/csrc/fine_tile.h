@@ -37,14 +37,19 @@ template <int EPI, bool MASKED>
 __device__ __forceinline__ void fine_tile_run(const TileArgs &t, const NodeArgs &a, double (*s_u)[SLOT],
                                               double (*s_y)[TILE * TILE * 3], double (*s_e)[TILE * TILE], int bxi,
                                               int byi, int bzi) {
+    // No implicit mul+add contraction in this function: the compiler peels / specialises iterations of the z-loop and
+    // contracted them differently, which made a node's result depend (in the last bit) on whether its plane is the
+    // first of a z-chunk.  With explicit fma() only, the result of a node is independent of the chunking -- which the
+    // boundary-first launches of the halo overlap rely on (bitwise equal to the single launch).
+#pragma clang fp contract(off)
     constexpr bool IS_CHEB = (EPI == EPI_CHEB || EPI == EPI_CHEB_DOT);
     constexpr bool DIAG_FLY = IS_CHEB;
     constexpr bool HAS_B = (EPI == EPI_RESID || IS_CHEB);
     const int tid = threadIdx.x;
     const int tx = tid & (TILE - 1), ty = tid / TILE;
     const int bx = bxi * TOUT, by = byi * TOUT;
-    const int kz0 = t.own_lo + bzi * t.kz;
-    const int kz1 = min(kz0 + t.kz - 1, t.own_hi);
+    int kz0, kz1;
+    tile_chunk(t, bzi, kz0, kz1);
     const int nsteps = kz1 - kz0 + 2;  // element layers kz0-1 .. kz1
     const int ei = bx - 1 + tx, ej = by - 1 + ty;
     const bool elem_ok = ei >= 0 && ei < t.ex && ej >= 0 && ej < t.ey;

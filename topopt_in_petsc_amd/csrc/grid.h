@@ -9,6 +9,12 @@ struct tp_grid {
     tp_comm comm;
     bool has_comm;
     struct RcclComm *rccl = nullptr;  // set by tp_grid_use_rccl: the hooks above then point into it
+    // halo overlap (DMGlobalToLocalBegin/End split, LinearElasticity.cc:249-250): ghost planes travel on a second
+    // stream while the interior planes of the producing kernel are computed on `stream`
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_ready = nullptr;    // "boundary planes written" on `stream`
+    bool overlap = false;
+    long n_overlapped = 0;            // halos started with halo_nodes_begin
     tp_comm comm_host;                // the host framework's hooks given at creation (restored by tp_grid_drop_rccl)
     int ex, ey, ez_glob, ez_own;  // fine level element counts
     int rank, nranks;
@@ -116,6 +122,33 @@ inline int exchange_segments(tp_grid *g, const double *to_lo, double *from_lo, c
             TP_HIP(hipMemcpy2DAsync(from_hi + r0 * pitch, pitch * 8, c.recv_hi, seg * 8, seg * 8, nr,
                                     hipMemcpyDeviceToDevice, g->stream));
     }
+    return TP_OK;
+}
+
+inline bool halo_can_overlap(const tp_grid *g) {
+    return g->has_comm && g->overlap && g->comm_stream && g->comm.set_stream && g->comm.exchange_direct;
+}
+// DMGlobalToLocalBegin: the boundary planes of v are complete on g->stream at the time of the call; the ghost planes
+// are exchanged (zero-copy, in place) on the second stream and `done` is recorded there -- the consumer of the ghost
+// planes makes g->stream wait for it (MGSolver::halo).  Returns 2 if the host cannot exchange in place (nothing was
+// sent: the caller falls back to the blocking form for good).
+inline int halo_nodes_begin(tp_grid *g, const Geom &q, double *v, int dof, hipEvent_t done) {
+    const long pl = q.plane() * dof;
+    const bool lo = g->rank > 0, hi = g->rank < g->nranks - 1;
+    TP_HIP(hipEventRecord(g->ev_ready, g->stream));
+    TP_HIP(hipStreamWaitEvent(g->comm_stream, g->ev_ready, 0));
+    g->comm.set_stream(g->comm.user, g->comm_stream);
+    const int rc = g->comm.exchange_direct(g->comm.user, lo ? v + pl * q.own_lo : nullptr, lo ? v : nullptr,
+                                           hi ? v + pl * q.own_hi : nullptr, hi ? v + pl * (q.nzl - 1) : nullptr, pl);
+    g->comm.set_stream(g->comm.user, nullptr);
+    if (rc == 2) {
+        g->overlap = false;
+        g->comm.exchange_direct = nullptr;
+        return 2;
+    }
+    if (rc) return TP_ERR_COMM;
+    TP_HIP(hipEventRecord(done, g->comm_stream));
+    g->n_overlapped++;
     return TP_OK;
 }
 

@@ -212,6 +212,7 @@ inline void sym_slot_release(int i) {
 
 // fhat = B uhat for one element in the Walsh-Hadamard basis; [component][p], p = px + 2 py + 4 pz.
 __device__ inline void sym_ke_blocks(const double *B, const double u[3][8], double f[3][8]) {
+#pragma clang fp contract(off)
 #pragma unroll
     for (int q = 0; q < 8; q++) {
         const double v[3] = {u[0][q ^ 1], u[1][q ^ 2], u[2][q ^ 4]};
@@ -249,7 +250,20 @@ struct TileArgs {
     const double *corr;        // [level-1 dofs] Dirichlet correction added to y (k_macro_corr), or null
     int xcd_remap;             // 1: contiguous tile ranges per XCD
     int macg_off;              // offset of the level-1 constants inside c_macG
+    int r1_lo, r1_hi;          // second range of output planes (empty if r1_lo > r1_hi): the launch that produces the
+                               // two boundary planes of a slab first (halo overlap); chunks of the first range come first
 };
+// output planes [kz0, kz1] of z-chunk bzi
+__device__ inline void tile_chunk(const TileArgs &t, int bzi, int &kz0, int &kz1) {
+    const int na = (t.own_hi - t.own_lo + t.kz) / t.kz;  // chunks of the first range (0 if empty)
+    if (bzi < na) {
+        kz0 = t.own_lo + bzi * t.kz;
+        kz1 = min(kz0 + t.kz - 1, t.own_hi);
+    } else {
+        kz0 = t.r1_lo + (bzi - na) * t.kz;
+        kz1 = min(kz0 + t.kz - 1, t.r1_hi);
+    }
+}
 
 // MACRO = 0: fine level, one element per thread and step.
 // MACRO = 1: level 1.  The Galerkin operator P^T A_0 P is never stored: a coarse element's matrix is linear in its 8
@@ -287,8 +301,8 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
         bzi = m / (gridDim.x * gridDim.y);
     }
     const int bx = bxi * TOUT, by = byi * TOUT;
-    const int kz0 = t.own_lo + bzi * t.kz;
-    const int kz1 = min(kz0 + t.kz - 1, t.own_hi);
+    int kz0, kz1;
+    tile_chunk(t, bzi, kz0, kz1);
     const int nsteps = kz1 - kz0 + 2;  // element layers kz0-1 .. kz1
     const int ei = bx - 1 + tx, ej = by - 1 + ty;
     const bool elem_ok = ei >= 0 && ei < t.ex && ej >= 0 && ej < t.ey;

@@ -405,6 +405,11 @@ struct MGSolver {
         }
         if (lan_fork) (void)hipEventDestroy(lan_fork);
         lan_fork = nullptr;
+        for (int i = 0; i <= TP_MAX_LEVELS; i++) {
+            if (pend_ev[i]) (void)hipEventDestroy(pend_ev[i]);
+            pend_ev[i] = nullptr;
+            pend[i].ptr = nullptr;
+        }
     }
     // Lanczos work space per level (kept across design iterations): basis, coefficients, reduction partials, pinned
     // host copy of the coefficients; the runs of different levels are independent and may share the device
@@ -424,13 +429,42 @@ struct MGSolver {
     hipEvent_t lan_fork = nullptr, lan_done[TP_MAX_LEVELS + 1] = {};
 
     // ---- operator application with one of the epilogues -------------------
+    // out_halo: the ghost planes of a.out will be read next (another operator application, a grid transfer).  On the
+    // tile levels the slab's boundary planes are then produced FIRST, their exchange starts on the second stream and
+    // overlaps with the interior planes (halo() of the consumer waits for it); everywhere else out_halo is ignored
+    // and the consumer's halo() exchanges as before.  Per-node arithmetic does not depend on the split: bitwise the
+    // same result.
     template <int EPI>
-    int op(int l, NodeArgs a) {
+    int op(int l, NodeArgs a, bool out_halo = false) {
         Level<DOF> &L = lv[l];
         const long nown = L.g.owned_nodes();
         const int nb = (int)((nown + BLK - 1) / BLK);
         double bytes, flops;
         last_nblocks = nb;
+        if (pend[l].ptr && (pend[l].ptr == a.out || pend[l].ptr != a.x)) TP_TRY(drain_halo(l));  // stale / about to be overwritten
+        const int n_bnd = (L.g.has_lo ? 1 : 0) + (L.g.has_hi ? 1 : 0);
+        const bool tile_level = DOF == 3 && ((L.kind == LV_MATFREE && L.use_tile) || L.kind == LV_MACRO);
+        const bool split = out_halo && tile_level && EPI != EPI_APPLY_DOT && EPI != EPI_CHEB_DOT && !L.no_comm && n_bnd > 0 &&
+                           halo_can_overlap(grid) && (L.g.own_hi - L.g.own_lo + 1) > n_bnd;
+        // the two passes of a split launch: boundary planes (one or two single-plane ranges), then the interior
+        auto tile_ranges = [&](int pass, int &lo, int &hi, int &r1lo, int &r1hi) {
+            lo = L.g.own_lo, hi = L.g.own_hi, r1lo = 0, r1hi = -1;
+            if (!split) return;
+            if (pass == 0) {
+                if (L.g.has_lo && L.g.has_hi) lo = hi = L.g.own_lo, r1lo = r1hi = L.g.own_hi;
+                else if (L.g.has_lo) hi = lo;
+                else lo = hi;
+            } else {
+                lo += L.g.has_lo ? 1 : 0;
+                hi -= L.g.has_hi ? 1 : 0;
+            }
+        };
+        auto after_boundary = [&]() -> int {  // DMGlobalToLocalBegin on the output
+            if (!pend_ev[l]) TP_HIP(hipEventCreateWithFlags(&pend_ev[l], hipEventDisableTiming));
+            const int rc = halo_nodes_begin(grid, L.g, a.out, DOF, pend_ev[l]);
+            if (rc == TP_OK) pend[l].ptr = a.out;
+            return rc == 2 ? TP_OK : rc;  // 2: no in-place exchange after all -> the consumer's halo() does it
+        };
         if (DOF == 3 && L.kind == LV_MATFREE && L.use_tile) {
             const int tx = (L.g.nx + TOUT - 1) / TOUT, ty = (L.g.ny + TOUT - 1) / TOUT;
             const int planes = L.g.own_hi - L.g.own_lo + 1;
@@ -438,15 +472,20 @@ struct MGSolver {
             static const int fine_v = getenv("TP_FINE_V") ? atoi(getenv("TP_FINE_V")) : 2;
             int kz = kz_env > 0 ? kz_env : fine_kz(planes, tx * ty, fine_v);
             if (kz > planes) kz = planes;
-            const int tz = (planes + kz - 1) / kz;
-            last_nblocks = tx * ty * tz;
-            TileArgs ta{L.g.nx, L.g.ny, L.g.nzl, L.g.ex, L.g.ey, L.g.ezl, L.g.own_lo, L.g.own_hi, kz,
-                        L.E, L.mask, L.colmask, L.sym_slot * SYMKE_STRIDE, 0, 0, nullptr, xcd_remap(), 0};
-            if (fine_v == 2) {
-                TP_LAUNCH((k_fine_tile<EPI>), dim3(tx, ty, tz), dim3(TILE * TILE), 0, grid->stream, ta, a);
-            } else {
-                if constexpr (EPI == EPI_CHEB_DOT) return TP_ERR_STATE;
-                else TP_LAUNCH((k_matfree_tile<EPI, 0>), dim3(tx, ty, tz), dim3(TILE * TILE), 0, grid->stream, ta, a);
+            for (int pass = 0; pass < (split ? 2 : 1); pass++) {
+                int lo, hi, r1lo, r1hi;
+                tile_ranges(pass, lo, hi, r1lo, r1hi);
+                const int tz = (hi - lo + kz) / kz + (r1hi - r1lo + kz) / kz;
+                last_nblocks = tx * ty * tz;
+                TileArgs ta{L.g.nx, L.g.ny, L.g.nzl, L.g.ex, L.g.ey, L.g.ezl, lo, hi, kz,
+                            L.E, L.mask, L.colmask, L.sym_slot * SYMKE_STRIDE, 0, 0, nullptr, xcd_remap(), 0, r1lo, r1hi};
+                if (fine_v == 2) {
+                    TP_LAUNCH((k_fine_tile<EPI>), dim3(tx, ty, tz), dim3(TILE * TILE), 0, grid->stream, ta, a);
+                } else {
+                    if constexpr (EPI == EPI_CHEB_DOT) return TP_ERR_STATE;
+                    else TP_LAUNCH((k_matfree_tile<EPI, 0>), dim3(tx, ty, tz), dim3(TILE * TILE), 0, grid->stream, ta, a);
+                }
+                if (split && pass == 0) TP_TRY(after_boundary());
             }
             bytes = 16.0 * DOF * nown + 8.0 * L.g.own_elems();
             flops = 2.0 * 576 * (double)L.g.own_elems();
@@ -459,8 +498,6 @@ struct MGSolver {
             int kz = kz_env > 0 ? kz_env : (int)((long)planes * tx * ty / 768);
             if (kz_env <= 0) kz = kz < 4 ? 4 : (kz > 64 ? 64 : kz);
             if (kz > planes) kz = planes;
-            const int tz = (planes + kz - 1) / kz;
-            last_nblocks = tx * ty * tz;
             if (L.ncorr_nodes) {
                 TP_LAUNCH(k_macro_corr_rows, dim3((L.nflag * 24 + BLK - 1) / BLK), dim3(BLK), 0, grid->stream, L.g,
                                    L.dK, L.flag_list, L.nflag, a.x, L.corr_tmp);
@@ -469,10 +506,17 @@ struct MGSolver {
                 count_launch(grid);
                 count_launch(grid);
             }
-            TileArgs ta{L.g.nx, L.g.ny, L.g.nzl, L.g.ex, L.g.ey, L.g.ezl, L.g.own_lo, L.g.own_hi, kz,
-                        L.E, nullptr, nullptr, L.sym_slot * SYMKE_STRIDE, L.fex, L.fey,
-                        L.ncorr_nodes ? L.corr : nullptr, xcd_remap(), L.sym_slot * MACG_STRIDE};
-            TP_LAUNCH((k_matfree_tile<EPI, 1>), dim3(tx, ty, tz), dim3(TILE * TILE), 0, grid->stream, ta, a);
+            for (int pass = 0; pass < (split ? 2 : 1); pass++) {
+                int lo, hi, r1lo, r1hi;
+                tile_ranges(pass, lo, hi, r1lo, r1hi);
+                const int tz = (hi - lo + kz) / kz + (r1hi - r1lo + kz) / kz;
+                last_nblocks = tx * ty * tz;
+                TileArgs ta{L.g.nx, L.g.ny, L.g.nzl, L.g.ex, L.g.ey, L.g.ezl, lo, hi, kz,
+                            L.E, nullptr, nullptr, L.sym_slot * SYMKE_STRIDE, L.fex, L.fey,
+                            L.ncorr_nodes ? L.corr : nullptr, xcd_remap(), L.sym_slot * MACG_STRIDE, r1lo, r1hi};
+                TP_LAUNCH((k_matfree_tile<EPI, 1>), dim3(tx, ty, tz), dim3(TILE * TILE), 0, grid->stream, ta, a);
+                if (split && pass == 0) TP_TRY(after_boundary());
+            }
             bytes = 16.0 * DOF * nown + 8.0 * 8.0 * L.g.own_elems();
             flops = 2.0 * 576 * 8.0 * (double)L.g.own_elems();
         } else if (L.kind == LV_MATFREE) {
@@ -506,12 +550,34 @@ struct MGSolver {
         // d (r/w), b, dinv -- the fine tile kernel instead reads b and the previous iterate (3-term form, diagonal on the fly)
         if (EPI == EPI_CHEB || EPI == EPI_CHEB_DOT) bytes += (three_term(L) ? 2.0 : 4.0) * 8.0 * DOF * nown;
         count_launch(grid, bytes, flops);
+        if (split) grid->launches++;
+        return TP_OK;
+    }
+    // ---- halos in flight on the second stream (one per level: the output of the last split launch)
+    struct PendingHalo {
+        const double *ptr = nullptr;
+    };
+    PendingHalo pend[TP_MAX_LEVELS + 1];
+    hipEvent_t pend_ev[TP_MAX_LEVELS + 1] = {};
+    int drain_halo(int l) {  // DMGlobalToLocalEnd
+        if (pend[l].ptr) {
+            TP_HIP(hipStreamWaitEvent(grid->stream, pend_ev[l], 0));
+            pend[l].ptr = nullptr;
+        }
+        return TP_OK;
+    }
+    int drain_halos() {
+        for (int l = 0; l <= nlv; l++) TP_TRY(drain_halo(l));
         return TP_OK;
     }
     // Fine tile kernel: Chebyshev in its 3-term form  u+ = u + c1 (u - u-) + c2 D^-1 (b - A u); u- sits in the output
     // buffer (read and overwritten by the same thread), so no direction vector is streamed.
     static bool three_term(const Level<DOF> &L) { return DOF == 3 && L.kind == LV_MATFREE && L.use_tile; }
-    int halo(int l, double *v) { return lv[l].no_comm ? TP_OK : halo_nodes(grid, lv[l].g, v, DOF); }
+    int halo(int l, double *v) {
+        if (lv[l].no_comm) return TP_OK;
+        if (pend[l].ptr == v) return drain_halo(l);  // already under way: ordered behind it, nothing to exchange
+        return halo_nodes(grid, lv[l].g, v, DOF);
+    }
 
     // y = A_l u (ghost planes of u refreshed first)
     int apply(int l, double *u, double *y) {
@@ -574,7 +640,7 @@ struct MGSolver {
                 a.red_out = grid->scal + dot_slot;
                 TP_TRY(op<EPI_CHEB_DOT>(l, a));
             } else {
-                TP_TRY(op<EPI_CHEB>(l, a));
+                TP_TRY(op<EPI_CHEB>(l, a, true));
             }
             std::swap(L.x, L.x2);
         }
@@ -634,7 +700,7 @@ struct MGSolver {
             a.out = L.r;
             a.b = b;
             TP_TRY(halo(l, L.x));
-            TP_TRY(op<EPI_RESID>(l, a));
+            TP_TRY(op<EPI_RESID>(l, a, true));
         }
         Level<DOF> &C = lv[l + 1];
         TP_TRY(halo(l, L.r));
@@ -810,6 +876,7 @@ struct MGSolver {
     // z = M r : one V-cycle.  Returns the pointer holding z (lv[0].x).
     int precond(const double *r, double **z, int dot_slot = -1) {
         TP_TRY(vcycle(0, r, dot_slot));
+        TP_TRY(drain_halos());
         *z = lv[0].x;
         return TP_OK;
     }
@@ -885,6 +952,7 @@ struct MGSolver {
                 std::swap(rz_cur, rz_old);
             }
         }
+        TP_TRY(drain_halos());
         if (its_out) *its_out = its;
         if (rnorm_out) *rnorm_out = rnorm;
         return rc;

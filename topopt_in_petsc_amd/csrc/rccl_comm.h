@@ -31,7 +31,8 @@ inline RcclApi &rccl_api() {
 
 struct RcclComm {
     ncclComm_t comm = nullptr;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // stream the operations are issued on (set_stream hook)
+    hipStream_t home_stream = nullptr;  // the grid's stream
     int rank = 0, nranks = 1;
     bool periodic = false;  // self test only: the single rank is its own lower and upper neighbour
     double *buf = nullptr;  // owns send_lo | send_hi | recv_lo | recv_hi | red | gather
@@ -81,6 +82,10 @@ static int rccl_allreduce_inplace(void *u, double *p, int n) {
     c->n_reductions++;
     return 0;
 }
+static void rccl_set_stream(void *u, void *stream) {
+    RcclComm *c = (RcclComm *)u;
+    c->stream = stream ? (hipStream_t)stream : c->home_stream;
+}
 static int rccl_allgather(void *u, long n) {
     RcclComm *c = (RcclComm *)u;
     TP_NCCL(rccl_api().AllGather(c->hooks.send_lo, c->hooks.gather, (size_t)n, ncclDouble, c->comm, c->stream));
@@ -127,7 +132,7 @@ inline int rccl_comm_create(RcclComm **out, const void *id128, int rank, int nra
     RcclComm *c = new RcclComm();
     c->rank = rank;
     c->nranks = nranks;
-    c->stream = stream;
+    c->stream = c->home_stream = stream;
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
     if (A.CommInitRank(&c->comm, nranks, id, rank) != ncclSuccess) {
@@ -155,12 +160,13 @@ inline int rccl_comm_create(RcclComm **out, const void *id128, int rank, int nra
     h.allgather = rccl_allgather;
     h.exchange_direct = rccl_exchange_direct;
     h.allreduce_inplace = rccl_allreduce_inplace;
+    h.set_stream = rccl_set_stream;
     *out = c;
     return TP_OK;
 }
 inline void rccl_comm_destroy(RcclComm *c) {
     if (!c) return;
-    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->home_stream);
     if (c->comm) rccl_api().CommDestroy(c->comm);
     (void)hipFree(c->buf);
     delete c;

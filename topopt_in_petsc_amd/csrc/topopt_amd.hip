@@ -19,7 +19,16 @@ extern "C" int tp_grid_create(tp_grid **out, const tp_grid_opts *o) {
     g->o = *o;
     g->stream = (hipStream_t)o->stream;
     g->has_comm = o->nranks > 1;
-    if (g->has_comm) g->comm = g->comm_host = *o->comm;
+    if (g->has_comm) {
+        g->comm = g->comm_host = *o->comm;
+        // second stream for the overlapped halos (TP_OVERLAP=0: every halo on the grid's stream, before its consumer)
+        const bool want = !(getenv("TP_OVERLAP") && atoi(getenv("TP_OVERLAP")) == 0);
+        if (want && hipStreamCreateWithFlags(&g->comm_stream, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&g->ev_ready, hipEventDisableTiming) == hipSuccess)
+            g->overlap = true;
+        else
+            (void)hipGetLastError();
+    }
     g->ex = o->nx - 1;
     g->ey = o->ny - 1;
     g->ez_glob = o->nz - 1;
@@ -140,6 +149,7 @@ extern "C" int tp_grid_comm_selfcheck(tp_grid *g, int *ok) {
     *ok = (good && !hook_failed) ? 1 : 0;
     return hook_failed ? TP_ERR_COMM : TP_OK;
 }
+extern "C" long tp_grid_overlapped_halos(const tp_grid *g) { return g ? g->n_overlapped : 0; }
 extern "C" int tp_grid_comm_stats(const tp_grid *g, long *ex, long *red) {
     if (!g) return TP_ERR_ARG;
     if (ex) *ex = g->rccl ? g->rccl->n_exchanges : 0;
@@ -204,6 +214,11 @@ extern "C" int tp_grid_destroy(tp_grid *g) {
     if (!g) return TP_OK;
     (void)hipStreamSynchronize(g->stream);
     rccl_comm_destroy(g->rccl);
+    if (g->comm_stream) {
+        (void)hipStreamSynchronize(g->comm_stream);
+        (void)hipStreamDestroy(g->comm_stream);
+    }
+    if (g->ev_ready) (void)hipEventDestroy(g->ev_ready);
     (void)hipFree(g->partials);
     (void)hipFree(g->scal);
     (void)hipFree(g->ticket);
@@ -891,6 +906,7 @@ extern "C" int tp_elasticity_smooth(tp_elasticity *e, int l, const double *b, do
     const size_t nb = sizeof(double) * (size_t)L.ndof();
     if (!zero_guess) TP_HIP(hipMemcpyAsync(L.x, x, nb, hipMemcpyDeviceToDevice, e->grid->stream));
     TP_TRY(e->mg.smooth(l, b, k, zero_guess != 0));
+    TP_TRY(e->mg.drain_halos());
     TP_HIP(hipMemcpyAsync(x, L.x, nb, hipMemcpyDeviceToDevice, e->grid->stream));
     return TP_OK;
 }

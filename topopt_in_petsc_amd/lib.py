@@ -39,13 +39,14 @@ EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_long)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
 DIRECT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long)
 INPLACE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int)
+SETSTREAM_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
 
 
 class Comm(C.Structure):
     _fields_ = [("user", C.c_void_p), ("send_lo", C.c_void_p), ("send_hi", C.c_void_p), ("recv_lo", C.c_void_p),
                 ("recv_hi", C.c_void_p), ("red", C.c_void_p), ("cap", C.c_long), ("exchange", EXCHANGE_FN),
                 ("allreduce_sum", ALLREDUCE_FN), ("gather", C.c_void_p), ("allgather", EXCHANGE_FN),
-                ("exchange_direct", DIRECT_FN), ("allreduce_inplace", INPLACE_FN)]
+                ("exchange_direct", DIRECT_FN), ("allreduce_inplace", INPLACE_FN), ("set_stream", SETSTREAM_FN)]
 
 
 # every symbol include/topopt_amd.h declares: (restype, argtypes)
@@ -58,6 +59,7 @@ SYMBOLS = {
     "tp_grid_use_rccl": (_i, [_vp, _vp]),
     "tp_grid_comm_stats": (_i, [_vp, C.POINTER(_l), C.POINTER(_l)]),
     "tp_grid_drop_rccl": (_i, [_vp]),
+    "tp_grid_overlapped_halos": (_l, [_vp]),
     "tp_grid_comm_selfcheck": (_i, [_vp, C.POINTER(_i)]),
     "tp_rccl_selftest": (_i, [_i, _vp, _l, C.POINTER(_d)]),
     "tp_grid_local_nodes": (_l, [_vp]),
