@@ -1,93 +1,499 @@
-// petsc_shim.cc -- implementation of include/petsc_shim.h on top of the C ABI of libtopopt_amd.so.
-// Pure host code (g++): every operation is one or two tp_* calls; no HIP, no PETSc.
-#include "../include/petsc_shim.h"
+// petsc_shim.cc -- the PETSc 3.11 subset of include/petsc_compat/petsc.h on top of the C ABI of libtopopt_amd.so.
+// Pure host code (g++): no HIP, no PETSc.  See the header for what is different behind the names: vectors live in
+// HBM, MatSetValuesLocal is a capture (no matrix is ever assembled), the KSP/PCMG object graph is recorded and the
+// configuration that is solved is CG + PCMG(V, Galerkin) + Chebyshev/Jacobi, selected through the options database
+// exactly as with real PETSc (anything else: PETSC_ERR_SUP with a message, never a silent substitution).
+#include <petsc/private/dmdaimpl.h>
 
+#include <cstdarg>
+#include <cstdint>
+#include <chrono>
 #include <cmath>
-#include <cstdio>
-#include <cstring>
+#include <map>
+#include <string>
 #include <vector>
 
-enum { ERR_ARG = 62 /* PETSC_ERR_ARG_OUTOFRANGE-like */, ERR_SUP = 56, ERR_ORDER = 58 };
+#include "../include/topopt_amd.h"
 
-struct _p_DM {
-    PetscInt M, N, P, dof, s;
-    double box[6];
-    bool have_box, nodal;
-    tp_grid *g;
+namespace {
+
+enum { CLS_DM = 1, CLS_VEC, CLS_MAT, CLS_KSP, CLS_PC, CLS_VIEWER, CLS_RANDOM, CLS_L2G };
+struct Hdr {  // 32 bytes = the void *hdr_[4] of the public struct _p_DM
+    int classid, refct;
+    const char *type_name;
+    void *r0, *r1;
 };
+static_assert(sizeof(Hdr) == 4 * sizeof(void *), "object header layout");
+
+int sup(const char *what) {
+    fprintf(stderr, "[petsc-compat] PETSC_ERR_SUP: %s\n", what);
+    return PETSC_ERR_SUP;
+}
+
+// ---- options database --------------------------------------------------------------------------------------
+std::map<std::string, std::string> &opts() {
+    static std::map<std::string, std::string> o;
+    static bool env_done = false;
+    if (!env_done) {
+        env_done = true;
+        if (const char *e = getenv("PETSC_OPTIONS")) {
+            std::vector<std::string> tok;
+            std::string cur;
+            for (const char *p = e;; p++) {
+                if (*p == ' ' || *p == '\t' || *p == 0) {
+                    if (!cur.empty()) tok.push_back(cur);
+                    cur.clear();
+                    if (!*p) break;
+                } else {
+                    cur.push_back(*p);
+                }
+            }
+            for (size_t i = 0; i < tok.size(); i++)
+                if (tok[i][0] == '-' && tok[i].size() > 1 && !(tok[i][1] >= '0' && tok[i][1] <= '9')) {
+                    const bool val = i + 1 < tok.size() && !(tok[i + 1][0] == '-' && tok[i + 1].size() > 1 &&
+                                                              !(tok[i + 1][1] >= '0' && tok[i + 1][1] <= '9') && tok[i + 1][1] != '.');
+                    o[tok[i].substr(1)] = val ? tok[i + 1] : "";
+                    if (val) i++;
+                }
+        }
+    }
+    return o;
+}
+const std::string *opt_find(const char *pre, const char *name) {
+    std::string key = (pre ? pre : "");
+    key += (name[0] == '-' ? name + 1 : name);
+    auto it = opts().find(key);
+    return it == opts().end() ? nullptr : &it->second;
+}
+
+// ---- the mesh all DMs of a program live on (one process, one GPU) ------------------------------------------
+struct Mesh {
+    int nx = 0, ny = 0, nz = 0;  // nodes
+    double box[6] = {0, 1, 0, 1, 0, 1};
+    bool have_box = false;
+    tp_grid *g = nullptr;
+    int users = 0;
+} mesh;
+
+}  // namespace
+
 struct _p_Vec {
+    Hdr h;
     long n;
-    double *d;
+    double *d;  // [dev]; NULL for a host-only vector (coordinates)
     std::vector<double> host;
-    tp_grid *g;
+    bool host_newer;  // VecSetValue* since the last assembly
+    DM dm;            // borrowed
 };
+struct DMFull : _p_DM {
+    PetscInt M, N, P, dof, sw;
+    double box[6];
+    bool have_box;
+    DM_DA da;
+    Vec coords;
+    PetscInt own[3];
+    bool uses_grid;
+};
+static DMFull *F(DM d) { return static_cast<DMFull *>(d); }
+
+enum MatKind { K_ELAST, K_HELM, K_CONE, K_TMAT, K_INTERP, K_EXT_ELAST, K_EXT_FILTER };
 struct _p_Mat {
-    int kind;  // 0: elasticity, 1: cone filter
+    Hdr h;
+    MatKind kind;
+    DM dm;  // borrowed (descriptor copied)
+    long n_rows, n_cols;
+    // capture state
+    std::vector<double> ref;     // first block seen (576 / 64 / 8 values)
+    std::vector<double> E;       // K_ELAST: per element multiplier of `ref`
+    long ncalls;
+    double coneR;                // K_CONE
+    bool assembled_since_setup;  // new values since the operator was last built
+    Vec Nvec;                    // K_ELAST: copy of the Dirichlet vector
+    bool have_bc;
     tp_elasticity *e;
     tp_filter *f;
-    tp_grid *g;
-    long n_rows;
-    bool have_bc, assembled;
+    double *dE;  // [dev] element multipliers
+    KSP ksp;     // borrowed back reference (KSPSetOperators)
+    bool ext_assembled;
 };
 struct _p_PC {
-    int dummy;
+    Hdr h;
+    std::string type;
+    int nlevels;
+    std::vector<KSP> lev;  // [0] = coarse solve
+    std::vector<Mat> interp;
+    int mgtype, cycle, galerkin;
+    KSP owner;
 };
 struct _p_KSP {
-    Mat A;
+    Hdr h;
+    std::string type, prefix;
     double rtol, atol, dtol;
-    int maxits;
-    bool nonzero_guess;
+    int maxits, restart;
+    bool nonzero_guess, from_options;
+    Mat A;
+    PC pc;
     int its;
     double rnorm;
-    _p_PC pc;
+    bool is_sub;
+};
+struct _p_PetscViewer {
+    Hdr h;
+    FILE *fp;
+    PetscFileMode mode;
+};
+struct _p_PetscRandom {
+    Hdr h;
+    uint64_t state;
+};
+struct _p_ISLocalToGlobalMapping {
+    Hdr h;
 };
 
-static tp_grid *g_default = nullptr;  // the grid element-sized vectors run their kernels on (one process)
+namespace {
 
-static int grid_of(DM da, tp_grid **out) {
-    if (!da->g) {
-        if (!da->nodal) return ERR_ORDER;
-        tp_grid_opts o;
-        memset(&o, 0, sizeof(o));
-        o.nx = da->M;
-        o.ny = da->N;
-        o.nz = da->P;
-        if (da->have_box) {
-            o.hx = (da->box[1] - da->box[0]) / (da->M - 1);
-            o.hy = (da->box[3] - da->box[2]) / (da->N - 1);
-            o.hz = (da->box[5] - da->box[4]) / (da->P - 1);
-        } else {
-            o.hx = o.hy = o.hz = 1.0;
+Mat g_last_helm = nullptr;  // the Helmholtz matrix a later MatCreateAIJ'ed T belongs to (PDEFilter.cc:143-170)
+
+void hdr_init(Hdr &h, int cls, const char *type) {
+    h.classid = cls;
+    h.refct = 1;
+    h.type_name = type;
+    h.r0 = h.r1 = nullptr;
+}
+
+int ensure_grid() {
+    if (mesh.g) return 0;
+    if (mesh.nx < 2) return PETSC_ERR_ORDER;
+    tp_grid_opts o;
+    memset(&o, 0, sizeof(o));
+    o.nx = mesh.nx;
+    o.ny = mesh.ny;
+    o.nz = mesh.nz;
+    o.hx = (mesh.box[1] - mesh.box[0]) / (mesh.nx - 1);
+    o.hy = (mesh.box[3] - mesh.box[2]) / (mesh.ny - 1);
+    o.hz = (mesh.box[5] - mesh.box[4]) / (mesh.nz - 1);
+    o.rank = 0;
+    o.nranks = 1;
+    o.device = 0;
+    return tp_grid_create(&mesh.g, &o);
+}
+bool is_nodal(const DMFull *d) { return d->M == mesh.nx && d->N == mesh.ny && d->P == mesh.nz; }
+bool is_elem(const DMFull *d) { return d->M == mesh.nx - 1 && d->N == mesh.ny - 1 && d->P == mesh.nz - 1; }
+
+int vec_create(long n, bool host_only, DM dm, Vec *out) {
+    Vec v = new _p_Vec();
+    hdr_init(v->h, CLS_VEC, "seq");
+    v->n = n;
+    v->d = nullptr;
+    v->host_newer = false;
+    v->dm = dm;
+    if (host_only) {
+        v->host.assign((size_t)n, 0.0);
+    } else {
+        int rc = ensure_grid();
+        if (!rc) rc = tp_malloc((void **)&v->d, sizeof(double) * (size_t)(n > 0 ? n : 1));
+        if (!rc) rc = tp_vec_set(mesh.g, v->d, 0.0, n);
+        if (rc) {
+            delete v;
+            return rc;
         }
-        o.rank = 0;
-        o.nranks = 1;
-        o.device = 0;
-        int rc = tp_grid_create(&da->g, &o);
-        if (rc) return rc;
-        if (!g_default) g_default = da->g;
     }
-    *out = da->g;
+    *out = v;
+    return 0;
+}
+int vec_pull(Vec x) {  // device -> host mirror
+    if (!x->d) return 0;
+    x->host.resize((size_t)x->n);
+    tp_sync(mesh.g);
+    return tp_memcpy_d2h(x->host.data(), x->d, sizeof(double) * (size_t)x->n);
+}
+int vec_push(Vec x) { return x->d ? tp_memcpy_h2d(x->d, x->host.data(), sizeof(double) * (size_t)x->n) : 0; }
+
+// ---- the solver configuration a KSP resolves to ------------------------------------------------------------
+void ksp_apply_options(KSP k, const std::vector<std::string> &prefixes) {
+    for (const std::string &p : prefixes) {
+        if (const std::string *v = opt_find(p.c_str(), "ksp_type")) k->type = *v;
+        if (const std::string *v = opt_find(p.c_str(), "ksp_rtol")) k->rtol = atof(v->c_str());
+        if (const std::string *v = opt_find(p.c_str(), "ksp_atol")) k->atol = atof(v->c_str());
+        if (const std::string *v = opt_find(p.c_str(), "ksp_divtol")) k->dtol = atof(v->c_str());
+        if (const std::string *v = opt_find(p.c_str(), "ksp_max_it")) k->maxits = atoi(v->c_str());
+        if (const std::string *v = opt_find(p.c_str(), "pc_type")) k->pc->type = *v;
+    }
+}
+const char *NEED =
+    "the MI355X path solves CG + PCMG(V-cycle, Galerkin) with Chebyshev/Jacobi smoothers; select it like with real "
+    "PETSc: -ksp_type cg -mg_levels_ksp_type chebyshev -mg_levels_pc_type jacobi -mg_coarse_ksp_type chebyshev "
+    "-mg_coarse_pc_type jacobi (argv of PetscInitialize, $PETSC_OPTIONS or PetscOptionsSetValue)";
+
+int resolve(KSP k, tp_solver_opts *o) {
+    tp_solver_default_opts(o);
+    // PETSc reads the level KSPs' options in PCSetUp_MG, AFTER the reference's hard-coded KSPSetType calls
+    PC pc = k->pc;
+    const int nl = pc->nlevels > 0 ? pc->nlevels : 1;
+    for (int l = 0; l < (int)pc->lev.size(); l++) {
+        std::vector<std::string> pre;
+        if (l == 0 && nl > 1) {
+            pre.push_back("mg_coarse_");
+        } else {
+            pre.push_back("mg_levels_");
+            pre.push_back("mg_levels_" + std::to_string(l) + "_");
+        }
+        ksp_apply_options(pc->lev[l], pre);
+    }
+    if (k->type != KSPCG) return sup((std::string("outer KSP type '") + k->type + "': " + NEED).c_str());
+    if (pc->type != PCMG) return sup((std::string("PC type '") + pc->type + "': " + NEED).c_str());
+    o->nlvls = nl;
+    o->rtol = k->rtol;
+    o->atol = k->atol;
+    o->dtol = k->dtol;
+    o->max_it = k->maxits;
+    if (pc->cycle != PC_MG_CYCLE_V || pc->mgtype != PC_MG_MULTIPLICATIVE) return sup("PCMG: only the multiplicative V-cycle");
+    if (nl > 1 && pc->galerkin != PC_MG_GALERKIN_BOTH) return sup("PCMG: only -pc_mg_galerkin both");
+    for (int l = 0; l < (int)pc->lev.size(); l++) {
+        KSP s = pc->lev[l];
+        if (s->type != KSPCHEBYSHEV || s->pc->type != PCJACOBI)
+            return sup((std::string("level ") + std::to_string(l) + " smoother '" + s->type + "/" + s->pc->type + "': " + NEED).c_str());
+        if (l == 0 && nl > 1) o->ncoarse = s->maxits;
+        else o->nsmooth = s->maxits;
+    }
+    if (nl == 1 && !pc->lev.empty()) o->ncoarse = pc->lev[0]->maxits;
     return 0;
 }
 
+int ensure_elasticity(Mat A) {
+    if (A->kind != K_ELAST) return PETSC_ERR_ARG_WRONG;
+    if (A->ref.empty()) return PETSC_ERR_ORDER;
+    DMFull *d = F(A->dm);
+    const long nel = (long)(d->M - 1) * (d->N - 1) * (d->P - 1);
+    if (!A->e) {
+        tp_solver_opts o;
+        if (A->ksp) {
+            int rc = resolve(A->ksp, &o);
+            if (rc) return rc;
+        } else {
+            tp_solver_default_opts(&o);
+            o.nlvls = 1;
+        }
+        int rc = ensure_grid();
+        if (!rc) rc = tp_elasticity_create_ke(&A->e, mesh.g, &o, A->ref.data());
+        if (rc) return rc;
+        rc = tp_malloc((void **)&A->dE, sizeof(double) * (size_t)nel);
+        if (rc) return rc;
+        A->assembled_since_setup = true;
+    }
+    if (A->assembled_since_setup) {
+        if (!A->have_bc || !A->Nvec) return sup("stiffness matrix without MatDiagonalScale(K, N, N): Dirichlet vector unknown");
+        if ((long)A->E.size() != nel || A->ncalls != nel) return sup("MatSetValuesLocal: not every element was added exactly once");
+        int rc = tp_elasticity_set_bc(A->e, A->Nvec->d);
+        if (!rc) rc = tp_memcpy_h2d(A->dE, A->E.data(), sizeof(double) * (size_t)nel);
+        // E_e = 0 + x^1 (1 - 0): the captured multipliers ARE the moduli (pow(x, 1.0) is exact)
+        if (!rc) rc = tp_elasticity_assemble(A->e, A->dE, 0.0, 1.0, 1.0);
+        if (rc) return rc;
+        A->assembled_since_setup = false;
+    }
+    return 0;
+}
+
+int ensure_pdefilter(Mat K) {
+    if (K->kind != K_HELM) return PETSC_ERR_ARG_WRONG;
+    if (K->f) return 0;
+    if (K->ref.size() != 64) return PETSC_ERR_ORDER;
+    int rc = ensure_grid();
+    if (rc) return rc;
+    const double hx = (mesh.box[1] - mesh.box[0]) / (mesh.nx - 1), hy = (mesh.box[3] - mesh.box[2]) / (mesh.ny - 1),
+                 hz = (mesh.box[5] - mesh.box[4]) / (mesh.nz - 1);
+    // KF = R^2 int grad N . grad N + int N N  (PDEFilter.cc:476-565): recover R from the trace
+    double tr = 0.0;
+    for (int a = 0; a < 8; a++) tr += K->ref[9 * a];
+    const double vol = hx * hy * hz;
+    const double R2 = (tr - 8.0 * vol / 27.0) / (8.0 / 9.0 * (hy * hz / hx + hx * hz / hy + hx * hy / hz));
+    if (!(R2 > 0)) return sup("8x8 blocks of the dof-1 matrix are not a Helmholtz filter element matrix");
+    const double rmin = std::sqrt(R2) * 2.0 * std::sqrt(3.0);
+    tp_solver_opts o;
+    if (K->ksp) {
+        rc = resolve(K->ksp, &o);
+        if (rc) return rc;
+    } else {
+        return PETSC_ERR_ORDER;
+    }
+    rc = tp_filter_create(&K->f, mesh.g, 2, rmin, &o);
+    if (rc) return rc;
+    double kf[64];
+    tp_filter_get_kf(K->f, kf);
+    double scale = 0.0, dev = 0.0;
+    for (int i = 0; i < 64; i++) {
+        scale = fmax(scale, fabs(kf[i]));
+        dev = fmax(dev, fabs(kf[i] - K->ref[i]));
+    }
+    if (dev > 1e-9 * scale) return sup("8x8 blocks of the dof-1 matrix differ from the Helmholtz element matrix of their own radius");
+    return 0;
+}
+
+}  // namespace
+
 extern "C" {
 
-PetscErrorCode PetscInitialize(int *, char ***, const char[], const char[]) { return 0; }
+// =============================================================================================== Sys
+PetscErrorCode PetscInitialize(int *argc, char ***args, const char[], const char[]) {
+    if (argc && args)
+        for (int i = 1; i < *argc; i++) {
+            const char *a = (*args)[i];
+            if (a[0] == '-' && a[1] && !(a[1] >= '0' && a[1] <= '9')) {
+                const bool val = i + 1 < *argc && !((*args)[i + 1][0] == '-' && (*args)[i + 1][1] && !((*args)[i + 1][1] >= '0' && (*args)[i + 1][1] <= '9') && (*args)[i + 1][1] != '.');
+                opts()[a + 1] = val ? (*args)[i + 1] : "";
+                if (val) i++;
+            }
+        }
+    return 0;
+}
 PetscErrorCode PetscFinalize(void) { return 0; }
+PetscErrorCode PetscOptionsSetValue(PetscOptions, const char name[], const char value[]) {
+    opts()[name[0] == '-' ? name + 1 : name] = value ? value : "";
+    return 0;
+}
+PetscErrorCode PetscOptionsClearValue(PetscOptions, const char name[]) {
+    opts().erase(name[0] == '-' ? name + 1 : name);
+    return 0;
+}
+PetscErrorCode PetscOptionsGetInt(PetscOptions, const char pre[], const char name[], PetscInt *v, PetscBool *set) {
+    const std::string *s = opt_find(pre, name);
+    if (set) *set = s ? PETSC_TRUE : PETSC_FALSE;
+    if (s) *v = atoi(s->c_str());
+    return 0;
+}
+PetscErrorCode PetscOptionsGetReal(PetscOptions, const char pre[], const char name[], PetscReal *v, PetscBool *set) {
+    const std::string *s = opt_find(pre, name);
+    if (set) *set = s ? PETSC_TRUE : PETSC_FALSE;
+    if (s) *v = atof(s->c_str());
+    return 0;
+}
+PetscErrorCode PetscOptionsGetBool(PetscOptions, const char pre[], const char name[], PetscBool *v, PetscBool *set) {
+    const std::string *s = opt_find(pre, name);
+    if (set) *set = s ? PETSC_TRUE : PETSC_FALSE;
+    if (s) *v = (s->empty() || *s == "1" || *s == "true" || *s == "yes" || *s == "TRUE") ? PETSC_TRUE : PETSC_FALSE;
+    return 0;
+}
+PetscErrorCode PetscOptionsGetString(PetscOptions, const char pre[], const char name[], char str[], size_t len, PetscBool *set) {
+    const std::string *s = opt_find(pre, name);
+    if (set) *set = s ? PETSC_TRUE : PETSC_FALSE;
+    if (s && len) {
+        strncpy(str, s->c_str(), len - 1);
+        str[len - 1] = 0;
+    }
+    return 0;
+}
+PetscErrorCode PetscPrintf(MPI_Comm, const char format[], ...) {
+    va_list ap;
+    va_start(ap, format);
+    vprintf(format, ap);
+    va_end(ap);
+    fflush(stdout);
+    return 0;
+}
+PetscErrorCode PetscErrorPrintf(const char format[], ...) {
+    va_list ap;
+    va_start(ap, format);
+    vfprintf(stderr, format, ap);
+    va_end(ap);
+    return 0;
+}
+PetscErrorCode PetscMallocCompat(size_t n, void **p) {
+    *p = malloc(n ? n : 1);
+    return *p ? 0 : 55;
+}
+PetscErrorCode PetscFreeCompat(void *p) {
+    free(p);
+    return 0;
+}
+PetscErrorCode PetscObjectTypeCompare(PetscObject obj, const char type_name[], PetscBool *same) {
+    const Hdr *h = (const Hdr *)obj;
+    const char *t = h ? h->type_name : nullptr;
+    if (h && h->classid == CLS_PC) t = ((PC)obj)->type.c_str();
+    if (h && h->classid == CLS_KSP) t = ((KSP)obj)->type.c_str();
+    *same = (t && type_name && strcmp(t, type_name) == 0) ? PETSC_TRUE : PETSC_FALSE;
+    return 0;
+}
+int MPI_Allreduce(const void *s, void *r, int count, MPI_Datatype t, MPI_Op, MPI_Comm) {
+    if (s != r) memcpy(r, s, (size_t)count * (t == MPIU_INT ? sizeof(PetscInt) : sizeof(double)));
+    return 0;
+}
+int MPI_Comm_rank(MPI_Comm, int *rank) {
+    *rank = 0;
+    return 0;
+}
+int MPI_Comm_size(MPI_Comm, int *size) {
+    *size = 1;
+    return 0;
+}
+int MPI_Barrier(MPI_Comm) { return 0; }
+double MPI_Wtime(void) {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+PetscErrorCode PetscViewerBinaryOpen(MPI_Comm, const char name[], PetscFileMode mode, PetscViewer *v) {
+    FILE *fp = fopen(name, mode == FILE_MODE_READ ? "rb" : (mode == FILE_MODE_APPEND ? "ab" : "wb"));
+    if (!fp) return PETSC_ERR_FILE_OPEN;
+    PetscViewer w = new _p_PetscViewer();
+    hdr_init(w->h, CLS_VIEWER, PETSCVIEWERBINARY);
+    w->fp = fp;
+    w->mode = mode;
+    *v = w;
+    return 0;
+}
+PetscErrorCode PetscViewerDestroy(PetscViewer *v) {
+    if (v && *v) {
+        if ((*v)->fp) fclose((*v)->fp);
+        delete *v;
+        *v = nullptr;
+    }
+    return 0;
+}
+PetscErrorCode PetscRandomCreate(MPI_Comm, PetscRandom *r) {
+    *r = new _p_PetscRandom();
+    hdr_init((*r)->h, CLS_RANDOM, PETSCRAND48);
+    (*r)->state = 0x1234ABCD330EULL;  // rand48 default seed
+    return 0;
+}
+PetscErrorCode PetscRandomSetType(PetscRandom, PetscRandomType) { return 0; }
+PetscErrorCode PetscRandomDestroy(PetscRandom *r) {
+    if (r && *r) {
+        delete *r;
+        *r = nullptr;
+    }
+    return 0;
+}
 
+// =============================================================================================== DMDA
 PetscErrorCode DMDACreate3d(MPI_Comm, DMBoundaryType, DMBoundaryType, DMBoundaryType, DMDAStencilType, PetscInt M,
                             PetscInt N, PetscInt P, PetscInt, PetscInt, PetscInt, PetscInt dof, PetscInt s,
                             const PetscInt[], const PetscInt[], const PetscInt[], DM *da) {
-    if (!da || M < 1 || N < 1 || P < 1 || dof < 1) return ERR_ARG;
-    DM d = new _p_DM();
+    if (!da || M < 1 || N < 1 || P < 1 || dof < 1) return PETSC_ERR_ARG_OUTOFRANGE;
+    DMFull *d = new DMFull();
+    Hdr h;
+    hdr_init(h, CLS_DM, "da");
+    memcpy(d->hdr_, &h, sizeof(h));
+    d->data = &d->da;
+    d->da.e = nullptr;
+    d->da.ne = 0;
+    d->da.elementtype = DMDA_ELEMENT_P1;  // PETSc's default; the reference sets Q1 itself
     d->M = M;
     d->N = N;
     d->P = P;
     d->dof = dof;
-    d->s = s;
+    d->sw = s;
     d->have_box = false;
-    d->nodal = false;
-    d->g = nullptr;
+    const double b[6] = {0, 1, 0, 1, 0, 1};
+    memcpy(d->box, b, sizeof(b));
+    d->coords = nullptr;
+    d->own[0] = M;
+    d->own[1] = N;
+    d->own[2] = P;
+    d->uses_grid = false;
+    if (mesh.nx == 0) {  // the first DMDA of a program is the node mesh (TopOpt.cc:225-262)
+        mesh.nx = M;
+        mesh.ny = N;
+        mesh.nz = P;
+    }
+    mesh.users++;
     *da = d;
     return 0;
 }
@@ -95,227 +501,558 @@ PetscErrorCode DMSetFromOptions(DM) { return 0; }
 PetscErrorCode DMSetUp(DM) { return 0; }
 PetscErrorCode DMDASetUniformCoordinates(DM da, PetscReal x0, PetscReal x1, PetscReal y0, PetscReal y1, PetscReal z0,
                                          PetscReal z1) {
-    if (!da || da->g) return ERR_ORDER;  // before the first object that needs the grid
+    DMFull *d = F(da);
     const double b[6] = {x0, x1, y0, y1, z0, z1};
-    memcpy(da->box, b, sizeof(b));
-    da->have_box = true;
+    memcpy(d->box, b, sizeof(b));
+    d->have_box = true;
+    if (d->coords) {
+        VecDestroy(&d->coords);
+    }
+    if (is_nodal(d) && !mesh.have_box && !mesh.g) {  // element size of the mesh: first nodal DM with coordinates
+        memcpy(mesh.box, b, sizeof(b));
+        mesh.have_box = true;
+    }
+    return 0;
+}
+PetscErrorCode DMDASetElementType(DM da, DMDAElementType t) {
+    F(da)->da.elementtype = t;
     return 0;
 }
 PetscErrorCode DMDAGetInfo(DM da, PetscInt *dim, PetscInt *M, PetscInt *N, PetscInt *P, PetscInt *m, PetscInt *n,
                            PetscInt *p, PetscInt *dof, PetscInt *s, DMBoundaryType *bx, DMBoundaryType *by,
                            DMBoundaryType *bz, DMDAStencilType *st) {
+    DMFull *d = F(da);
     if (dim) *dim = 3;
-    if (M) *M = da->M;
-    if (N) *N = da->N;
-    if (P) *P = da->P;
+    if (M) *M = d->M;
+    if (N) *N = d->N;
+    if (P) *P = d->P;
     if (m) *m = 1;
     if (n) *n = 1;
     if (p) *p = 1;
-    if (dof) *dof = da->dof;
-    if (s) *s = da->s;
+    if (dof) *dof = d->dof;
+    if (s) *s = d->sw;
     if (bx) *bx = DM_BOUNDARY_NONE;
     if (by) *by = DM_BOUNDARY_NONE;
     if (bz) *bz = DM_BOUNDARY_NONE;
     if (st) *st = DMDA_STENCIL_BOX;
     return 0;
 }
-static PetscErrorCode vec_create(tp_grid *g, long n, Vec *v) {
-    Vec x = new _p_Vec();
-    x->n = n;
-    x->g = g;
-    x->d = nullptr;
-    int rc = tp_malloc((void **)&x->d, sizeof(double) * (size_t)n);
-    if (rc) {
-        delete x;
-        return rc;
+PetscErrorCode DMDAGetCorners(DM da, PetscInt *x, PetscInt *y, PetscInt *z, PetscInt *m, PetscInt *n, PetscInt *p) {
+    DMFull *d = F(da);
+    if (x) *x = 0;
+    if (y) *y = 0;
+    if (z) *z = 0;
+    if (m) *m = d->M;
+    if (n) *n = d->N;
+    if (p) *p = d->P;
+    return 0;
+}
+PetscErrorCode DMDAGetGhostCorners(DM da, PetscInt *x, PetscInt *y, PetscInt *z, PetscInt *m, PetscInt *n, PetscInt *p) {
+    return DMDAGetCorners(da, x, y, z, m, n, p);  // one rank, non-periodic: no ghost points
+}
+PetscErrorCode DMDAGetOwnershipRanges(DM da, const PetscInt *lx[], const PetscInt *ly[], const PetscInt *lz[]) {
+    DMFull *d = F(da);
+    if (lx) *lx = &d->own[0];
+    if (ly) *ly = &d->own[1];
+    if (lz) *lz = &d->own[2];
+    return 0;
+}
+PetscErrorCode DMDAGetLocalInfo(DM da, DMDALocalInfo *i) {
+    DMFull *d = F(da);
+    memset(i, 0, sizeof(*i));
+    i->dim = 3;
+    i->dof = d->dof;
+    i->sw = d->sw;
+    i->mx = i->xm = i->gxm = d->M;
+    i->my = i->ym = i->gym = d->N;
+    i->mz = i->zm = i->gzm = d->P;
+    i->st = DMDA_STENCIL_BOX;
+    i->da = da;
+    return 0;
+}
+PetscErrorCode DMDAGetElements(DM da, PetscInt *nel, PetscInt *nen, const PetscInt *e[]) {
+    DMFull *d = F(da);
+    if (!d->da.e) {  // hexahedra, DMDA natural order (the numbering of LinearElasticity.cc:819-826)
+        const PetscInt ex = d->M - 1, ey = d->N - 1, ez = d->P - 1;
+        d->da.ne = ex * ey * ez;
+        d->da.e = (PetscInt *)malloc(sizeof(PetscInt) * (size_t)(1 + 8 * (long)d->da.ne));
+        long c = 0;
+        for (PetscInt k = 0; k < ez; k++)
+            for (PetscInt j = 0; j < ey; j++)
+                for (PetscInt i = 0; i < ex; i++) {
+                    const PetscInt n0 = i + d->M * (j + d->N * k), dz = d->M * d->N;
+                    const PetscInt cell[8] = {n0, n0 + 1, n0 + 1 + d->M, n0 + d->M, n0 + dz, n0 + 1 + dz, n0 + 1 + d->M + dz, n0 + d->M + dz};
+                    for (int q = 0; q < 8; q++) d->da.e[c++] = cell[q];
+                }
     }
-    *v = x;
-    return tp_vec_set(g, x->d, 0.0, n);
+    *nel = d->da.ne;
+    *nen = 8;
+    *e = d->da.e;
+    return 0;
+}
+PetscErrorCode DMDARestoreElements(DM, PetscInt *, PetscInt *, const PetscInt *[]) { return 0; }
+PetscErrorCode DMGetCoordinatesLocal(DM da, Vec *c) {
+    DMFull *d = F(da);
+    if (!d->coords) {
+        const long n = (long)d->M * d->N * d->P;
+        int rc = vec_create(3 * n, true, da, &d->coords);
+        if (rc) return rc;
+        const double hx = d->M > 1 ? (d->box[1] - d->box[0]) / (d->M - 1) : 0.0, hy = d->N > 1 ? (d->box[3] - d->box[2]) / (d->N - 1) : 0.0,
+                     hz = d->P > 1 ? (d->box[5] - d->box[4]) / (d->P - 1) : 0.0;
+        double *p = d->coords->host.data();
+        for (PetscInt k = 0; k < d->P; k++)
+            for (PetscInt j = 0; j < d->N; j++)
+                for (PetscInt i = 0; i < d->M; i++) {  // DMDASetUniformCoordinates: xmin + i * h
+                    *p++ = d->box[0] + hx * i;
+                    *p++ = d->box[2] + hy * j;
+                    *p++ = d->box[4] + hz * k;
+                }
+    }
+    *c = d->coords;
+    return 0;
+}
+PetscErrorCode DMGetLocalToGlobalMapping(DM, ISLocalToGlobalMapping *m) {
+    static _p_ISLocalToGlobalMapping identity;
+    *m = &identity;
+    return 0;
 }
 PetscErrorCode DMCreateGlobalVector(DM da, Vec *v) {
-    tp_grid *g = da->g ? da->g : g_default;
-    if (!g) {  // the first vector of a program: this DM becomes the node grid
-        da->nodal = true;
-        int rc = grid_of(da, &g);
-        if (rc) return rc;
-    }
-    return vec_create(g, (long)da->dof * da->M * da->N * da->P, v);
+    DMFull *d = F(da);
+    if (!is_nodal(d) && !is_elem(d)) return sup("vector on a DMDA that is neither the node mesh nor its element mesh");
+    d->uses_grid = true;
+    return vec_create((long)d->dof * d->M * d->N * d->P, false, da, v);
 }
 PetscErrorCode DMCreateLocalVector(DM da, Vec *v) { return DMCreateGlobalVector(da, v); }  // one rank: no ghosts
 PetscErrorCode DMGlobalToLocalBegin(DM, Vec g, InsertMode, Vec l) { return g == l ? 0 : VecCopy(g, l); }
 PetscErrorCode DMGlobalToLocalEnd(DM, Vec, InsertMode, Vec) { return 0; }
+PetscErrorCode DMCoarsenHierarchy(DM da, PetscInt nlevels, DM dac[]) {
+    DMFull *f = F(da);
+    PetscInt M = f->M, N = f->N, P = f->P;
+    for (PetscInt l = 0; l < nlevels; l++) {
+        if ((M - 1) % 2 || (N - 1) % 2 || (P - 1) % 2) return sup("DMCoarsenHierarchy: element counts not divisible by 2 (TopOpt.cc:183-201)");
+        M = (M - 1) / 2 + 1;
+        N = (N - 1) / 2 + 1;
+        P = (P - 1) / 2 + 1;
+        int rc = DMDACreate3d(0, DM_BOUNDARY_NONE, DM_BOUNDARY_NONE, DM_BOUNDARY_NONE, DMDA_STENCIL_BOX, M, N, P, 1, 1, 1, f->dof, f->sw, 0, 0, 0, &dac[l]);
+        if (rc) return rc;
+    }
+    return 0;
+}
+static Mat mat_new(MatKind kind, DM dm, long nr, long nc, const char *type) {
+    Mat A = new _p_Mat();
+    hdr_init(A->h, CLS_MAT, type);
+    A->kind = kind;
+    A->dm = dm;
+    A->n_rows = nr;
+    A->n_cols = nc;
+    A->ncalls = 0;
+    A->coneR = 0.0;
+    A->assembled_since_setup = false;
+    A->Nvec = nullptr;
+    A->have_bc = false;
+    A->e = nullptr;
+    A->f = nullptr;
+    A->dE = nullptr;
+    A->ksp = nullptr;
+    A->ext_assembled = false;
+    return A;
+}
+PetscErrorCode DMCreateInterpolation(DM dac, DM daf, Mat *P, Vec *scale) {
+    DMFull *c = F(dac), *f = F(daf);
+    if ((f->M - 1) != 2 * (c->M - 1) || (f->N - 1) != 2 * (c->N - 1) || (f->P - 1) != 2 * (c->P - 1))
+        return sup("DMCreateInterpolation: only factor-2 trilinear (Q1) interpolation between DMDAs");
+    *P = mat_new(K_INTERP, daf, (long)f->dof * f->M * f->N * f->P, (long)c->dof * c->M * c->N * c->P, "q1interp");
+    if (scale) *scale = nullptr;
+    return 0;
+}
+PetscErrorCode DMCreateMatrix(DM da, Mat *A) {
+    DMFull *d = F(da);
+    const long n = (long)d->dof * d->M * d->N * d->P;
+    if (is_nodal(d) && d->dof == 3) {
+        *A = mat_new(K_ELAST, da, n, n, "topopt-elasticity");
+    } else if (is_nodal(d) && d->dof == 1) {
+        *A = mat_new(K_HELM, da, n, n, "topopt-helmholtz");
+        g_last_helm = *A;
+    } else if (is_elem(d) && d->dof == 1) {
+        *A = mat_new(K_CONE, da, n, n, "topopt-conefilter");
+    } else {
+        return sup("DMCreateMatrix: dof-3 / dof-1 node mesh or dof-1 element mesh only");
+    }
+    return 0;
+}
 PetscErrorCode DMDestroy(DM *da) {
     if (da && *da) {
-        if ((*da)->g) {
-            if (g_default == (*da)->g) g_default = nullptr;
-            tp_grid_destroy((*da)->g);
-        }
-        delete *da;
+        DMFull *d = F(*da);
+        if (d->coords) VecDestroy(&d->coords);
+        free(d->da.e);
+        delete d;
         *da = nullptr;
+        if (--mesh.users == 0 && mesh.g) {
+            tp_grid_destroy(mesh.g);
+            mesh = Mesh();
+        }
     }
     return 0;
 }
 
-PetscErrorCode VecDuplicate(Vec v, Vec *nv) { return vec_create(v->g, v->n, nv); }
+// =============================================================================================== Vec
+PetscErrorCode VecDuplicate(Vec v, Vec *nv) { return vec_create(v->n, v->d == nullptr, v->dm, nv); }
+PetscErrorCode VecDuplicateVecs(Vec v, PetscInt m, Vec *V[]) {
+    *V = (Vec *)malloc(sizeof(Vec) * (size_t)(m > 0 ? m : 1));
+    for (PetscInt i = 0; i < m; i++) {
+        int rc = VecDuplicate(v, &(*V)[i]);
+        if (rc) return rc;
+    }
+    return 0;
+}
+PetscErrorCode VecDestroyVecs(PetscInt m, Vec *V[]) {
+    if (V && *V) {
+        for (PetscInt i = 0; i < m; i++) VecDestroy(&(*V)[i]);
+        free(*V);
+        *V = nullptr;
+    }
+    return 0;
+}
 PetscErrorCode VecDestroy(Vec *v) {
     if (v && *v) {
-        tp_free((*v)->d);
-        delete *v;
+        if (--(*v)->h.refct <= 0) {
+            if ((*v)->d) tp_free((*v)->d);
+            delete *v;
+        }
         *v = nullptr;
     }
     return 0;
 }
-PetscErrorCode VecSet(Vec v, PetscScalar a) { return tp_vec_set(v->g, v->d, a, v->n); }
-PetscErrorCode VecCopy(Vec x, Vec y) {
-    if (x->n != y->n) return ERR_ARG;
-    return tp_vec_axpby(y->g, y->d, 1.0, x->d, 0.0, y->n);
+PetscErrorCode VecSet(Vec v, PetscScalar a) {
+    if (!v->d) {
+        std::fill(v->host.begin(), v->host.end(), a);
+        return 0;
+    }
+    v->host_newer = false;
+    return tp_vec_set(mesh.g, v->d, a, v->n);
 }
-PetscErrorCode VecScale(Vec v, PetscScalar a) { return tp_vec_scale(v->g, v->d, a, v->n); }
+PetscErrorCode VecCopy(Vec x, Vec y) {
+    if (x->n != y->n) return PETSC_ERR_ARG_WRONG;
+    return tp_vec_axpby(mesh.g, y->d, 1.0, x->d, 0.0, y->n);
+}
+PetscErrorCode VecScale(Vec v, PetscScalar a) { return tp_vec_scale(mesh.g, v->d, a, v->n); }
 PetscErrorCode VecAXPY(Vec y, PetscScalar a, Vec x) {
-    if (x->n != y->n) return ERR_ARG;
-    return tp_vec_axpby(y->g, y->d, a, x->d, 1.0, y->n);
+    if (x->n != y->n) return PETSC_ERR_ARG_WRONG;
+    return tp_vec_axpby(mesh.g, y->d, a, x->d, 1.0, y->n);
+}
+PetscErrorCode VecAXPBY(Vec y, PetscScalar a, PetscScalar b, Vec x) {
+    if (x->n != y->n) return PETSC_ERR_ARG_WRONG;
+    return tp_vec_axpby(mesh.g, y->d, a, x->d, b, y->n);
 }
 PetscErrorCode VecPointwiseMult(Vec w, Vec x, Vec y) {
-    if (w->n != x->n || w->n != y->n) return ERR_ARG;
-    return tp_vec_pointwise(w->g, w->d, x->d, y->d, 0, w->n);
+    if (w->n != x->n || w->n != y->n) return PETSC_ERR_ARG_WRONG;
+    return tp_vec_pointwise(mesh.g, w->d, x->d, y->d, 0, w->n);
 }
 PetscErrorCode VecPointwiseDivide(Vec w, Vec x, Vec y) {
-    if (w->n != x->n || w->n != y->n) return ERR_ARG;
-    return tp_vec_pointwise(w->g, w->d, x->d, y->d, 1, w->n);
+    if (w->n != x->n || w->n != y->n) return PETSC_ERR_ARG_WRONG;
+    return tp_vec_pointwise(mesh.g, w->d, x->d, y->d, 1, w->n);
 }
 PetscErrorCode VecDot(Vec x, Vec y, PetscScalar *val) {
-    if (x->n != y->n) return ERR_ARG;
-    return tp_vec_dot(x->g, x->d, y->d, x->n, val);
+    if (x->n != y->n) return PETSC_ERR_ARG_WRONG;
+    return tp_vec_dot(mesh.g, x->d, y->d, x->n, val);
 }
 PetscErrorCode VecNorm(Vec x, NormType type, PetscReal *val) {
-    if (type != NORM_2) return ERR_SUP;
+    if (type != NORM_2) return sup("VecNorm: NORM_2 only");
     double s = 0.0;
-    int rc = tp_vec_dot(x->g, x->d, x->d, x->n, &s);
+    int rc = tp_vec_dot(mesh.g, x->d, x->d, x->n, &s);
     *val = std::sqrt(s);
     return rc;
 }
-PetscErrorCode VecSum(Vec x, PetscScalar *sum) { return tp_vec_dot(x->g, x->d, nullptr, x->n, sum); }
+PetscErrorCode VecSum(Vec x, PetscScalar *sum) { return tp_vec_dot(mesh.g, x->d, nullptr, x->n, sum); }
+PetscErrorCode VecMax(Vec x, PetscInt *p, PetscReal *val) {
+    int rc = vec_pull(x);
+    long at = 0;
+    for (long i = 1; i < x->n; i++)
+        if (x->host[(size_t)i] > x->host[(size_t)at]) at = i;
+    if (p) *p = (PetscInt)at;
+    if (val) *val = x->n ? x->host[(size_t)at] : 0.0;
+    return rc;
+}
+PetscErrorCode VecMin(Vec x, PetscInt *p, PetscReal *val) {
+    int rc = vec_pull(x);
+    long at = 0;
+    for (long i = 1; i < x->n; i++)
+        if (x->host[(size_t)i] < x->host[(size_t)at]) at = i;
+    if (p) *p = (PetscInt)at;
+    if (val) *val = x->n ? x->host[(size_t)at] : 0.0;
+    return rc;
+}
 PetscErrorCode VecGetSize(Vec x, PetscInt *n) {
     *n = (PetscInt)x->n;
     return 0;
 }
 PetscErrorCode VecGetLocalSize(Vec x, PetscInt *n) { return VecGetSize(x, n); }
 PetscErrorCode VecGetArray(Vec x, PetscScalar **a) {
-    x->host.resize((size_t)x->n);
-    tp_sync(x->g);
-    int rc = tp_memcpy_d2h(x->host.data(), x->d, sizeof(double) * (size_t)x->n);
+    int rc = x->host_newer ? 0 : vec_pull(x);
     *a = x->host.data();
     return rc;
 }
 PetscErrorCode VecRestoreArray(Vec x, PetscScalar **a) {
     if (a) *a = nullptr;
-    return tp_memcpy_h2d(x->d, x->host.data(), sizeof(double) * (size_t)x->n);
+    x->host_newer = false;
+    return vec_push(x);
+}
+PetscErrorCode VecSetValueLocal(Vec v, PetscInt row, PetscScalar value, InsertMode mode) {
+    if (row < 0 || row >= v->n) return PETSC_ERR_ARG_OUTOFRANGE;
+    if (!v->host_newer) {
+        int rc = vec_pull(v);
+        if (rc) return rc;
+        v->host_newer = true;
+    }
+    if (mode == ADD_VALUES) v->host[(size_t)row] += value;
+    else v->host[(size_t)row] = value;
+    return 0;
+}
+PetscErrorCode VecSetValue(Vec v, PetscInt row, PetscScalar value, InsertMode mode) { return VecSetValueLocal(v, row, value, mode); }
+PetscErrorCode VecAssemblyBegin(Vec) { return 0; }
+PetscErrorCode VecAssemblyEnd(Vec v) {
+    if (!v->host_newer) return 0;
+    v->host_newer = false;
+    return vec_push(v);
+}
+PetscErrorCode VecSetRandom(Vec v, PetscRandom r) {
+    v->host.resize((size_t)v->n);
+    for (long i = 0; i < v->n; i++) {  // drand48's linear congruential generator
+        r->state = (r->state * 0x5DEECE66DULL + 0xBULL) & ((1ULL << 48) - 1);
+        v->host[(size_t)i] = (double)r->state / (double)(1ULL << 48);
+    }
+    return vec_push(v);
+}
+// PETSc binary Vec: big-endian int32 class id 1211214, int32 n, n big-endian doubles
+PetscErrorCode VecView(Vec v, PetscViewer w) {
+    int rc = vec_pull(v);
+    if (rc) return rc;
+    auto be32 = [&](uint32_t x) {
+        unsigned char b[4] = {(unsigned char)(x >> 24), (unsigned char)(x >> 16), (unsigned char)(x >> 8), (unsigned char)x};
+        fwrite(b, 1, 4, w->fp);
+    };
+    be32(1211214u);
+    be32((uint32_t)v->n);
+    for (long i = 0; i < v->n; i++) {
+        uint64_t u;
+        memcpy(&u, &v->host[(size_t)i], 8);
+        unsigned char b[8];
+        for (int k = 0; k < 8; k++) b[k] = (unsigned char)(u >> (56 - 8 * k));
+        fwrite(b, 1, 8, w->fp);
+    }
+    return 0;
+}
+PetscErrorCode VecLoad(Vec v, PetscViewer w) {
+    unsigned char b[8];
+    auto be32 = [&](uint32_t *x) {
+        if (fread(b, 1, 4, w->fp) != 4) return false;
+        *x = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3];
+        return true;
+    };
+    uint32_t cls, n;
+    if (!be32(&cls) || !be32(&n) || cls != 1211214u || (long)n != v->n) return 79;  // PETSC_ERR_FILE_UNEXPECTED
+    v->host.resize((size_t)v->n);
+    for (long i = 0; i < v->n; i++) {
+        if (fread(b, 1, 8, w->fp) != 8) return 79;
+        uint64_t u = 0;
+        for (int k = 0; k < 8; k++) u = (u << 8) | b[k];
+        memcpy(&v->host[(size_t)i], &u, 8);
+    }
+    return vec_push(v);
 }
 PetscErrorCode VecTopOptGetDevicePointer(Vec x, PetscScalar **d) {
     *d = x->d;
     return 0;
 }
 
-PetscErrorCode MatCreateTopOptElasticity(DM da, PetscScalar nu, PetscInt nlvls, Mat *K) {
-    if (!da || da->dof != 3) return ERR_ARG;
-    da->nodal = true;
-    tp_grid *g;
-    int rc = grid_of(da, &g);
-    if (rc) return rc;
-    tp_solver_opts o;
-    tp_solver_default_opts(&o);
-    o.nlvls = nlvls;
-    o.nu = nu;
-    Mat A = new _p_Mat();
-    A->kind = 0;
-    A->g = g;
-    A->f = nullptr;
-    A->have_bc = A->assembled = false;
-    A->n_rows = 3 * tp_grid_local_nodes(g);
-    rc = tp_elasticity_create(&A->e, g, &o);
-    if (rc) {
-        delete A;
-        return rc;
-    }
-    *K = A;
+// =============================================================================================== Mat
+PetscErrorCode MatCreateAIJ(MPI_Comm, PetscInt m, PetscInt n, PetscInt, PetscInt, PetscInt, const PetscInt[], PetscInt,
+                            const PetscInt[], Mat *A) {
+    // the only AIJ matrix of the path: T (nodes x elements, PDEFilter.cc:143-170)
+    if (m != (PetscInt)((long)mesh.nx * mesh.ny * mesh.nz) || n != (PetscInt)((long)(mesh.nx - 1) * (mesh.ny - 1) * (mesh.nz - 1)))
+        return sup("MatCreateAIJ: only the nodes x elements transfer matrix of the PDE filter");
+    *A = mat_new(K_TMAT, nullptr, m, n, "topopt-elem2node");
     return 0;
 }
-PetscErrorCode MatTopOptCantilever(Mat K, Vec N, Vec RHS) {
-    if (!K || K->kind != 0 || N->n != K->n_rows || RHS->n != K->n_rows) return ERR_ARG;
-    K->have_bc = true;
-    return tp_elasticity_cantilever(K->e, N->d, RHS->d);  // also registers N
+PetscErrorCode MatSetLocalToGlobalMapping(Mat, ISLocalToGlobalMapping, ISLocalToGlobalMapping) { return 0; }
+PetscErrorCode MatZeroEntries(Mat A) {
+    A->ncalls = 0;
+    if (A->kind == K_ELAST) std::fill(A->E.begin(), A->E.end(), 0.0);
+    return 0;
 }
-PetscErrorCode MatTopOptSetDirichlet(Mat K, Vec N) {
-    if (!K || K->kind != 0 || N->n != K->n_rows) return ERR_ARG;
-    K->have_bc = true;
-    return tp_elasticity_set_bc(K->e, N->d);
+PetscErrorCode MatSetValuesLocal(Mat A, PetscInt nrow, const PetscInt irow[], PetscInt ncol, const PetscInt icol[],
+                                 const PetscScalar y[], InsertMode addv) {
+    switch (A->kind) {
+    case K_ELAST: {  // AssembleStiffnessMatrix, LinearElasticity.cc:510-524: ke = KE * dens, ADD_VALUES
+        if (nrow != 24 || ncol != 24 || addv != ADD_VALUES) return sup("dof-3 matrix: 24x24 ADD_VALUES element blocks only");
+        DMFull *d = F(A->dm);
+        const PetscInt ex = d->M - 1, ey = d->N - 1, ez = d->P - 1;
+        const PetscInt n0 = irow[0] / 3, i = n0 % d->M, j = (n0 / d->M) % d->N, k = n0 / (d->M * d->N);
+        if (irow[0] % 3 || i >= ex || j >= ey || k >= ez || icol[0] != irow[0] || irow[3] != 3 * (n0 + 1))
+            return sup("dof-3 matrix: rows are not the 24 dofs of a hexahedron in DMDA order");
+        const long el = (long)i + (long)ex * (j + (long)ey * k);
+        if (A->E.empty()) A->E.assign((size_t)ex * ey * ez, 0.0);
+        if (A->ref.empty()) A->ref.assign(y, y + 576);
+        const double s = y[0] / A->ref[0];
+        for (int q : {0, 1, 25, 300, 575})
+            if (fabs(y[q] - s * A->ref[q]) > 1e-12 * fabs(s) * (fabs(A->ref[0]) + fabs(A->ref[q])))
+                return sup("dof-3 matrix: element blocks are not multiples of one element matrix");
+        A->E[(size_t)el] += s;
+        A->ncalls++;
+        A->assembled_since_setup = true;
+        return 0;
+    }
+    case K_HELM:  // PDEFilt::MatAssemble, PDEFilter.cc:257-260: the same KF for every element
+        if (nrow != 8 || ncol != 8 || addv != ADD_VALUES) return sup("dof-1 node matrix: 8x8 ADD_VALUES element blocks only");
+        if (A->ref.empty()) A->ref.assign(y, y + 64);
+        else if (memcmp(A->ref.data(), y, sizeof(double) * 64) != 0) return sup("dof-1 node matrix: variable coefficients");
+        A->ncalls++;
+        return 0;
+    case K_TMAT:  // :262: T(8 nodes, element) = TF = 1/8
+        if (nrow != 8 || ncol != 1 || addv != ADD_VALUES) return sup("transfer matrix: 8x1 ADD_VALUES blocks only");
+        for (int q = 0; q < 8; q++)
+            if (y[q] != 0.125) return sup("transfer matrix: entries other than 1/8");
+        A->ncalls++;
+        return 0;
+    case K_CONE:  // Filter::SetUp, Filter.cc:417-433: H(row, col) = R - dist, INSERT_VALUES; H(row, row) = R
+        if (nrow != 1 || ncol != 1 || addv != INSERT_VALUES) return sup("element matrix: 1x1 INSERT_VALUES entries only");
+        if (irow[0] == icol[0]) {
+            if (A->coneR == 0.0) A->coneR = y[0];
+            else if (A->coneR != y[0]) return sup("element matrix: varying diagonal (not a cone filter of one radius)");
+        } else if (A->coneR != 0.0 && !(y[0] > 0.0 && y[0] < A->coneR)) {
+            return sup("element matrix: off-diagonal weight outside (0, R)");
+        }
+        A->ncalls++;
+        return 0;
+    default:
+        return sup("MatSetValuesLocal on this matrix");
+    }
 }
-PetscErrorCode MatTopOptAssemble(Mat K, Vec xPhys, PetscScalar Emin, PetscScalar Emax, PetscScalar penal) {
-    if (!K || K->kind != 0) return ERR_ARG;
-    if (!K->have_bc) return ERR_ORDER;
-    K->assembled = true;
-    return tp_elasticity_assemble(K->e, xPhys->d, Emin, Emax, penal);
-}
-PetscErrorCode MatTopOptComplianceSensitivity(Mat K, Vec U, Vec xPhys, PetscScalar Emin, PetscScalar Emax,
-                                              PetscScalar penal, PetscScalar volfrac, PetscScalar *fx, PetscScalar *gx,
-                                              Vec dfdx, Vec dgdx) {
-    if (!K || K->kind != 0) return ERR_ARG;
-    return tp_elasticity_objective(K->e, U->d, xPhys->d, Emin, Emax, penal, volfrac, fx, gx, dfdx ? dfdx->d : nullptr,
-                                   dgdx ? dgdx->d : nullptr);
-}
-PetscErrorCode MatCreateTopOptFilter(DM da, PetscInt filterType, PetscScalar R, Mat *H, Vec *Hs) {
-    if (!da || filterType < 0 || filterType > 1) return ERR_SUP;
-    da->nodal = true;
-    tp_grid *g;
-    int rc = grid_of(da, &g);
-    if (rc) return rc;
-    Mat A = new _p_Mat();
-    A->kind = 1;
-    A->g = g;
-    A->e = nullptr;
-    A->n_rows = tp_grid_local_elems(g);
-    A->have_bc = A->assembled = true;
-    rc = tp_filter_create(&A->f, g, filterType, R, nullptr);
-    if (rc) {
-        delete A;
+PetscErrorCode MatAssemblyBegin(Mat, MatAssemblyType) { return 0; }
+PetscErrorCode MatAssemblyEnd(Mat A, MatAssemblyType) {
+    if (A->kind == K_CONE && !A->f) {
+        if (A->coneR <= 0.0) return sup("element matrix without diagonal entries");
+        int rc = ensure_grid();
+        if (!rc) rc = tp_filter_create(&A->f, mesh.g, 1, A->coneR, nullptr);
         return rc;
     }
-    if (Hs) {
-        rc = vec_create(g, A->n_rows, Hs);
-        if (!rc) rc = tp_filter_get_hs(A->f, (*Hs)->d);
+    return 0;
+}
+PetscErrorCode MatDiagonalScale(Mat A, Vec l, Vec r) {  // K = N K N, LinearElasticity.cc:533
+    if (A->kind != K_ELAST || l != r || !l || l->n != A->n_rows) return sup("MatDiagonalScale: (K, N, N) on the stiffness matrix only");
+    if (!A->Nvec) {
+        int rc = VecDuplicate(l, &A->Nvec);
+        if (rc) return rc;
     }
-    *H = A;
-    return rc;
+    A->have_bc = true;
+    A->assembled_since_setup = true;
+    return VecCopy(l, A->Nvec);
+}
+PetscErrorCode MatDiagonalSet(Mat A, Vec D, InsertMode mode) {  // K += I - N, :534-538
+    if (A->kind != K_ELAST || mode != ADD_VALUES || !A->have_bc) return sup("MatDiagonalSet: (K, I - N, ADD_VALUES) after MatDiagonalScale only");
+    double sd = 0.0, sn = 0.0;
+    int rc = VecSum(D, &sd);
+    if (!rc) rc = VecSum(A->Nvec, &sn);
+    if (rc) return rc;
+    if (sd + sn != (double)A->n_rows) return sup("MatDiagonalSet: the vector is not I - N");
+    return 0;
 }
 PetscErrorCode MatMult(Mat A, Vec x, Vec y) {
-    if (!A || x->n != A->n_rows || y->n != A->n_rows) return ERR_ARG;
-    if (A->kind == 0) return A->assembled ? tp_elasticity_apply(A->e, x->d, y->d) : ERR_ORDER;
-    return tp_filter_mult_h(A->f, x->d, y->d);
+    if (!A || !x || !y || x->n != A->n_cols || y->n != A->n_rows) return PETSC_ERR_ARG_WRONG;
+    switch (A->kind) {
+    case K_ELAST: {
+        int rc = ensure_elasticity(A);
+        return rc ? rc : tp_elasticity_apply(A->e, x->d, y->d);
+    }
+    case K_EXT_ELAST:
+        return A->ext_assembled ? tp_elasticity_apply(A->e, x->d, y->d) : PETSC_ERR_ORDER;
+    case K_CONE:
+        return A->f ? tp_filter_mult_h(A->f, x->d, y->d) : PETSC_ERR_ORDER;
+    case K_EXT_FILTER:
+        if (A->coneR < 0.0) {  // PDE filter as one operator
+            return tp_filter_project(A->f, x->d, y->d, y->d, 0, 0.0, 0.0) ? PETSC_ERR_ARG_WRONG : 0;
+        }
+        return tp_filter_mult_h(A->f, x->d, y->d);
+    case K_HELM: {
+        int rc = ensure_pdefilter(A);
+        return rc ? rc : tp_pdefilter_apply(A->f, x->d, y->d);
+    }
+    case K_TMAT: {
+        if (!g_last_helm) return PETSC_ERR_ORDER;
+        int rc = ensure_pdefilter(g_last_helm);
+        return rc ? rc : tp_pdefilter_elem_to_node(g_last_helm->f, x->d, y->d);
+    }
+    default:
+        return sup("MatMult on this matrix");
+    }
+}
+PetscErrorCode MatMultTranspose(Mat A, Vec x, Vec y) {
+    if (!A || A->kind != K_TMAT) {
+        if (A && (A->kind == K_ELAST || A->kind == K_HELM || A->kind == K_CONE || A->kind == K_EXT_ELAST)) return MatMult(A, x, y);  // symmetric
+        return sup("MatMultTranspose on this matrix");
+    }
+    if (x->n != A->n_rows || y->n != A->n_cols || !g_last_helm) return PETSC_ERR_ARG_WRONG;
+    int rc = ensure_pdefilter(g_last_helm);
+    return rc ? rc : tp_pdefilter_node_to_elem(g_last_helm->f, x->d, y->d);
 }
 PetscErrorCode MatDestroy(Mat *A) {
     if (A && *A) {
-        if ((*A)->e) tp_elasticity_destroy((*A)->e);
-        if ((*A)->f) tp_filter_destroy((*A)->f);
-        delete *A;
+        if (--(*A)->h.refct <= 0) {
+            if ((*A)->e) tp_elasticity_destroy((*A)->e);
+            if ((*A)->f) tp_filter_destroy((*A)->f);
+            if ((*A)->dE) tp_free((*A)->dE);
+            if ((*A)->Nvec) VecDestroy(&(*A)->Nvec);
+            if (g_last_helm == *A) g_last_helm = nullptr;
+            delete *A;
+        }
         *A = nullptr;
     }
     return 0;
 }
 
-PetscErrorCode KSPCreate(MPI_Comm, KSP *ksp) {
+// =============================================================================================== KSP / PC
+static KSP ksp_new(const char *prefix, bool sub) {
     KSP k = new _p_KSP();
-    k->A = nullptr;
-    k->rtol = 1e-5;  // PETSc defaults
+    hdr_init(k->h, CLS_KSP, "ksp");
+    k->type = KSPGMRES;  // PETSc's default
+    k->prefix = prefix;
+    k->rtol = 1e-5;
     k->atol = 1e-50;
     k->dtol = 1e5;
     k->maxits = 10000;
+    k->restart = 30;
     k->nonzero_guess = false;
+    k->from_options = false;
+    k->A = nullptr;
     k->its = 0;
     k->rnorm = 0.0;
-    *ksp = k;
+    k->is_sub = sub;
+    k->pc = new _p_PC();
+    hdr_init(k->pc->h, CLS_PC, "pc");
+    k->pc->type = sub ? PCSOR : "ilu";  // PETSc's defaults (level smoothers: SOR)
+    k->pc->nlevels = 0;
+    k->pc->mgtype = PC_MG_MULTIPLICATIVE;
+    k->pc->cycle = PC_MG_CYCLE_V;
+    k->pc->galerkin = PC_MG_GALERKIN_NONE;
+    k->pc->owner = k;
+    return k;
+}
+PetscErrorCode KSPCreate(MPI_Comm, KSP *ksp) {
+    *ksp = ksp_new("", false);
     return 0;
 }
-PetscErrorCode KSPSetType(KSP, KSPType type) { return strcmp(type, KSPCG) == 0 ? 0 : ERR_SUP; }
+PetscErrorCode KSPSetType(KSP k, KSPType type) {
+    k->type = type;
+    return 0;
+}
+PetscErrorCode KSPGetType(KSP k, KSPType *type) {
+    *type = k->type.c_str();
+    return 0;
+}
+PetscErrorCode KSPGMRESSetRestart(KSP k, PetscInt restart) {
+    k->restart = restart;
+    return 0;
+}
 PetscErrorCode KSPSetTolerances(KSP k, PetscReal rtol, PetscReal abstol, PetscReal dtol, PetscInt maxits) {
     if (rtol != PETSC_DEFAULT) k->rtol = rtol;
     if (abstol != PETSC_DEFAULT) k->atol = abstol;
@@ -323,28 +1060,57 @@ PetscErrorCode KSPSetTolerances(KSP k, PetscReal rtol, PetscReal abstol, PetscRe
     if (maxits != PETSC_DEFAULT) k->maxits = maxits;
     return 0;
 }
+PetscErrorCode KSPGetTolerances(KSP k, PetscReal *rtol, PetscReal *abstol, PetscReal *dtol, PetscInt *maxits) {
+    if (rtol) *rtol = k->rtol;
+    if (abstol) *abstol = k->atol;
+    if (dtol) *dtol = k->dtol;
+    if (maxits) *maxits = k->maxits;
+    return 0;
+}
 PetscErrorCode KSPSetInitialGuessNonzero(KSP k, PetscBool flg) {
     k->nonzero_guess = flg == PETSC_TRUE;
     return 0;
 }
 PetscErrorCode KSPSetOperators(KSP k, Mat A, Mat) {
-    if (!A || A->kind != 0) return ERR_SUP;
-    k->A = A;
+    if (!A) return PETSC_ERR_ARG_WRONG;
+    if (A != k->A) {
+        A->h.refct++;
+        if (k->A) MatDestroy(&k->A);
+        k->A = A;
+    }
+    A->ksp = k;
     return 0;
 }
-PetscErrorCode KSPSetFromOptions(KSP) { return 0; }
-PetscErrorCode KSPSetUp(KSP k) { return k->A && k->A->assembled ? 0 : ERR_ORDER; }  // Galerkin operators exist already
+PetscErrorCode KSPSetFromOptions(KSP k) {
+    k->from_options = true;
+    ksp_apply_options(k, {k->prefix});
+    return 0;
+}
+PetscErrorCode KSPSetUp(KSP k) {
+    if (!k->A) return PETSC_ERR_ORDER;
+    if (k->A->kind == K_ELAST) return ensure_elasticity(k->A);
+    if (k->A->kind == K_HELM) return ensure_pdefilter(k->A);
+    if (k->A->kind == K_EXT_ELAST) return k->A->ext_assembled ? 0 : PETSC_ERR_ORDER;
+    return sup("KSP on this matrix");
+}
 PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
-    if (!k->A || !k->A->assembled) return ERR_ORDER;
-    if (b->n != k->A->n_rows || x->n != k->A->n_rows) return ERR_ARG;
-    int rc = tp_elasticity_set_tolerances(k->A->e, k->rtol, k->atol, k->dtol, k->maxits);
+    int rc = KSPSetUp(k);
     if (rc) return rc;
+    Mat A = k->A;
+    if (b->n != A->n_rows || x->n != A->n_rows) return PETSC_ERR_ARG_WRONG;
     if (!k->nonzero_guess) {
         rc = VecSet(x, 0.0);
         if (rc) return rc;
     }
+    if (A->kind == K_HELM) {
+        rc = tp_pdefilter_solve(A->f, b->d, x->d);
+        if (!rc) rc = tp_filter_last_pde_its(A->f, &k->its, &k->rnorm);
+        return rc;
+    }
+    rc = tp_elasticity_set_tolerances(A->e, k->rtol, k->atol, k->dtol, k->maxits);
+    if (rc) return rc;
     double bn = 0.0;
-    return tp_elasticity_solve(k->A->e, b->d, x->d, &k->its, &k->rnorm, &bn, nullptr, 0);
+    return tp_elasticity_solve(A->e, b->d, x->d, &k->its, &k->rnorm, &bn, nullptr, 0);
 }
 PetscErrorCode KSPGetIterationNumber(KSP k, PetscInt *its) {
     *its = k->its;
@@ -355,16 +1121,153 @@ PetscErrorCode KSPGetResidualNorm(KSP k, PetscReal *rnorm) {
     return 0;
 }
 PetscErrorCode KSPGetPC(KSP k, PC *pc) {
-    *pc = &k->pc;
+    *pc = k->pc;
     return 0;
 }
 PetscErrorCode KSPDestroy(KSP *k) {
     if (k && *k) {
-        delete *k;
+        KSP s = *k;
+        for (KSP sub : s->pc->lev) KSPDestroy(&sub);
+        for (Mat m : s->pc->interp) MatDestroy(&m);
+        if (s->A) {
+            if (s->A->ksp == s) s->A->ksp = nullptr;
+            MatDestroy(&s->A);
+        }
+        delete s->pc;
+        delete s;
         *k = nullptr;
     }
     return 0;
 }
-PetscErrorCode PCSetType(PC, PCType type) { return strcmp(type, PCMG) == 0 ? 0 : ERR_SUP; }
+PetscErrorCode PCSetType(PC pc, PCType type) {
+    pc->type = type;
+    return 0;
+}
+PetscErrorCode PCGetType(PC pc, PCType *type) {
+    *type = pc->type.c_str();
+    return 0;
+}
+PetscErrorCode PCSetReusePreconditioner(PC, PetscBool) { return 0; }
+PetscErrorCode PCMGSetLevels(PC pc, PetscInt levels, MPI_Comm *) {
+    if (levels < 1 || levels > TP_MAX_LEVELS) return PETSC_ERR_ARG_OUTOFRANGE;
+    for (KSP sub : pc->lev) KSPDestroy(&sub);
+    pc->lev.clear();
+    pc->nlevels = levels;
+    for (PetscInt l = 0; l < levels; l++) {
+        KSP s = ksp_new(l == 0 && levels > 1 ? "mg_coarse_" : "mg_levels_", true);
+        s->type = l == 0 && levels > 1 ? "preonly" : KSPCHEBYSHEV;  // PETSc's PCMG defaults
+        s->pc->type = l == 0 && levels > 1 ? "lu" : PCSOR;
+        s->maxits = l == 0 && levels > 1 ? 1 : 2;
+        pc->lev.push_back(s);
+    }
+    pc->interp.assign((size_t)levels, nullptr);
+    return 0;
+}
+PetscErrorCode PCMGSetType(PC pc, PCMGType form) {
+    pc->mgtype = form;
+    return 0;
+}
+PetscErrorCode PCMGSetCycleType(PC pc, PCMGCycleType n) {
+    pc->cycle = n;
+    return 0;
+}
+PetscErrorCode PCMGSetGalerkin(PC pc, PCMGGalerkinType use) {
+    pc->galerkin = use;
+    return 0;
+}
+PetscErrorCode PCMGSetInterpolation(PC pc, PetscInt l, Mat mat) {
+    if (l < 1 || l >= pc->nlevels || !mat) return PETSC_ERR_ARG_OUTOFRANGE;
+    if (mat->kind != K_INTERP) return sup("PCMGSetInterpolation: only the matrices of DMCreateInterpolation (trilinear Q1)");
+    mat->h.refct++;  // retained: the caller destroys its reference (LinearElasticity.cc:704-706)
+    if (pc->interp[(size_t)l]) MatDestroy(&pc->interp[(size_t)l]);
+    pc->interp[(size_t)l] = mat;
+    return 0;
+}
+PetscErrorCode PCMGGetCoarseSolve(PC pc, KSP *ksp) {
+    if (pc->lev.empty()) return PETSC_ERR_ORDER;
+    *ksp = pc->lev[0];
+    return 0;
+}
+PetscErrorCode PCMGGetSmoother(PC pc, PetscInt l, KSP *ksp) {
+    if (l < 0 || l >= (PetscInt)pc->lev.size()) return PETSC_ERR_ARG_OUTOFRANGE;
+    *ksp = pc->lev[(size_t)l];
+    return 0;
+}
+PetscErrorCode KSPTopOptGetOptionString(KSP k, char buf[], size_t len) {
+    if (!k->A || !k->A->e) return PETSC_ERR_ORDER;
+    return tp_elasticity_petsc_options(k->A->e, buf, len) < 0 ? PETSC_ERR_ORDER : 0;
+}
+
+// =============================================================================================== extension calls
+PetscErrorCode MatCreateTopOptElasticity(DM da, PetscScalar nu, PetscInt nlvls, Mat *K) {
+    DMFull *d = F(da);
+    if (!da || d->dof != 3 || !is_nodal(d)) return PETSC_ERR_ARG_WRONG;
+    if (d->have_box && !mesh.g) {
+        memcpy(mesh.box, d->box, sizeof(mesh.box));
+        mesh.have_box = true;
+    }
+    int rc = ensure_grid();
+    if (rc) return rc;
+    tp_solver_opts o;
+    tp_solver_default_opts(&o);
+    o.nlvls = nlvls;
+    o.nu = nu;
+    const long n = 3L * d->M * d->N * d->P;
+    Mat A = mat_new(K_EXT_ELAST, da, n, n, "topopt-elasticity");
+    rc = tp_elasticity_create(&A->e, mesh.g, &o);
+    if (rc) {
+        delete A;
+        return rc;
+    }
+    *K = A;
+    return 0;
+}
+PetscErrorCode MatTopOptCantilever(Mat K, Vec N, Vec RHS) {
+    if (!K || K->kind != K_EXT_ELAST || N->n != K->n_rows || RHS->n != K->n_rows) return PETSC_ERR_ARG_WRONG;
+    K->have_bc = true;
+    return tp_elasticity_cantilever(K->e, N->d, RHS->d);  // also registers N
+}
+PetscErrorCode MatTopOptSetDirichlet(Mat K, Vec N) {
+    if (!K || K->kind != K_EXT_ELAST || N->n != K->n_rows) return PETSC_ERR_ARG_WRONG;
+    K->have_bc = true;
+    return tp_elasticity_set_bc(K->e, N->d);
+}
+PetscErrorCode MatTopOptAssemble(Mat K, Vec xPhys, PetscScalar Emin, PetscScalar Emax, PetscScalar penal) {
+    if (!K || K->kind != K_EXT_ELAST) return PETSC_ERR_ARG_WRONG;
+    if (!K->have_bc) return PETSC_ERR_ORDER;
+    K->ext_assembled = true;
+    return tp_elasticity_assemble(K->e, xPhys->d, Emin, Emax, penal);
+}
+PetscErrorCode MatTopOptComplianceSensitivity(Mat K, Vec U, Vec xPhys, PetscScalar Emin, PetscScalar Emax,
+                                              PetscScalar penal, PetscScalar volfrac, PetscScalar *fx, PetscScalar *gx,
+                                              Vec dfdx, Vec dgdx) {
+    if (!K || (K->kind != K_EXT_ELAST && K->kind != K_ELAST) || !K->e) return PETSC_ERR_ARG_WRONG;
+    return tp_elasticity_objective(K->e, U->d, xPhys->d, Emin, Emax, penal, volfrac, fx, gx, dfdx ? dfdx->d : nullptr,
+                                   dgdx ? dgdx->d : nullptr);
+}
+PetscErrorCode MatCreateTopOptFilter(DM da, PetscInt filterType, PetscScalar R, Mat *H, Vec *Hs) {
+    DMFull *d = F(da);
+    if (!da || filterType < 0 || filterType > 2 || !is_nodal(d)) return sup("MatCreateTopOptFilter: types 0, 1, 2 on the node mesh");
+    if (d->have_box && !mesh.g) {
+        memcpy(mesh.box, d->box, sizeof(mesh.box));
+        mesh.have_box = true;
+    }
+    int rc = ensure_grid();
+    if (rc) return rc;
+    const long nel = tp_grid_local_elems(mesh.g);
+    Mat A = mat_new(K_EXT_FILTER, da, nel, nel, "topopt-filter");
+    A->coneR = filterType == 2 ? -1.0 : R;
+    rc = tp_filter_create(&A->f, mesh.g, filterType, R, nullptr);
+    if (rc) {
+        delete A;
+        return rc;
+    }
+    if (Hs) {
+        rc = vec_create(nel, false, nullptr, Hs);
+        if (!rc) rc = filterType == 2 ? VecSet(*Hs, 1.0) : tp_filter_get_hs(A->f, (*Hs)->d);
+    }
+    *H = A;
+    return rc;
+}
 
 }  // extern "C"

@@ -159,6 +159,9 @@ typedef struct tp_elasticity tp_elasticity;
  * 0 = clamped] and RHS [dev, local nodes*3] are the Dirichlet and load vectors;
  * tp_elasticity_cantilever fills them with the reference's load case. */
 int tp_elasticity_create(tp_elasticity **e, tp_grid *g, const tp_solver_opts *o);
+/* the same with the caller's element matrix (row-major 24x24, reference corner order) instead of the built-in
+ * Hex8Isoparametric: what a host that "assembles" with MatSetValuesLocal has computed itself (:118-123, :519-524) */
+int tp_elasticity_create_ke(tp_elasticity **e, tp_grid *g, const tp_solver_opts *o, const double *ke_host_576);
 int tp_elasticity_destroy(tp_elasticity *e);
 int tp_elasticity_get_ke(const tp_elasticity *e, double *ke_host_576);
 int tp_elasticity_cantilever(tp_elasticity *e, double *N, double *RHS);      /* :143-171 */
@@ -223,6 +226,13 @@ int tp_filter_gradients(tp_filter *f, const double *x, const double *xTilde, dou
                         int projectionFilter, double beta, double eta);
 int tp_filter_mnd(tp_filter *f, const double *x, double *mnd);   /* GetMND, :206-225 */
 int tp_filter_last_pde_its(const tp_filter *f, int *its, double *rnorm);
+/* PDE filter (type 2), the operators of PDEFilt::FilterProject one by one (PDEFilter.cc:198-210): T x (element ->
+ * node, the caller scales by the element volume), the Helmholtz solve K_f u = rhs (warm start from u), T^T u, and
+ * K_f u itself.  Nodal arrays: [dev, local nodes]; element arrays: [dev, own elements]. */
+int tp_pdefilter_elem_to_node(tp_filter *f, const double *x_elem, double *rhs_nodal);
+int tp_pdefilter_solve(tp_filter *f, const double *rhs_nodal, double *u_nodal);
+int tp_pdefilter_node_to_elem(tp_filter *f, const double *u_nodal, double *x_elem);
+int tp_pdefilter_apply(tp_filter *f, const double *u_nodal, double *y_nodal);
 
 /* ---- MMA optimizer step on the device (MMA.cc) ------------ */
 typedef struct tp_mma tp_mma;

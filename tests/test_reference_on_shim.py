@@ -1,0 +1,91 @@
+"""Acceptance of the PETSc-named boundary (include/petsc_compat/petsc.h).
+
+CPU part (build container, where /root/reference exists): the reference's LinearElasticity.cc, Filter.cc and
+PDEFilter.cc compile UNCHANGED against the compat headers and link against libtopopt_petsc_shim.so
+(host/build_ref_on_shim.sh; nothing of the reference is stored in the repository, the binary is a git-ignored
+build artefact).  GPU part: that binary -- the reference's own classes on the MI355X path -- against the product's
+Python API on the same mesh, and its refusal to run the reference's hard-coded FGMRES/GMRES/SOR configuration."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "host", "_refbuild", "ref_on_shim")
+OPTS = ("-ksp_type cg -mg_levels_ksp_type chebyshev -mg_levels_pc_type jacobi "
+        "-mg_coarse_ksp_type chebyshev -mg_coarse_pc_type jacobi").split()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference sources only exist in the build container")
+def test_reference_sources_compile_and_link_against_the_shim():
+    r = subprocess.run(["bash", os.path.join(ROOT, "host", "build_ref_on_shim.sh")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert os.path.exists(BIN)
+    # every PETSc symbol the three objects need is exported by the shim (the link above would have failed otherwise);
+    # and the shim's header declares nothing it does not define
+    src = open(os.path.join(ROOT, "include", "petsc_compat", "petsc.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = set(re.findall(r"\b((?:Petsc|Vec|Mat|KSP|PC|DM|MPI_)[A-Za-z0-9_]*)\s*\(", src))
+    names -= {"PetscMalloc", "PetscFree", "PetscMin", "PetscMax", "PetscAbsScalar", "PetscAbsReal", "PetscSqrtScalar",
+              "PetscSqrtReal", "PetscPowScalar", "PetscPowReal", "PetscRealPart"}
+    so = os.path.join(ROOT, "topopt_in_petsc_amd", "libtopopt_petsc_shim.so")
+    exported = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
+    missing = [n for n in sorted(names) if not re.search(r"\b%s\b" % n, exported)]
+    assert not missing, missing
+
+
+def _run(args, env=None):
+    return subprocess.run([BIN] + [str(a) for a in args], capture_output=True, text=True, timeout=300,
+                          env=dict(os.environ, **(env or {})))
+
+
+def _numbers(out):
+    m = re.search(r"REF_ON_SHIM fx (\S+) gx (\S+) sum_dfdx (\S+) sum_dgdx (\S+) sum_xphys (\S+) normU (\S+)", out)
+    assert m, out[-2000:]
+    return [float(v) for v in m.groups()]
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(BIN), reason="host/_refbuild/ref_on_shim not built (build container only)")
+@pytest.mark.parametrize("ftype", [1, 2])
+def test_reference_classes_on_the_mi355x_path(ftype):
+    import torch
+    import topopt_in_petsc_amd as tp
+    ex, ey, ez = 32, 16, 16
+    r = _run([ex, ey, ez, ftype] + OPTS)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    fx, gx, sdf, sdg, sxp, un = _numbers(r.stdout)
+    its = int(re.search(r"State solver:\s+iter: (\d+)", r.stdout).group(1))
+    # ---- the product's own API, same mesh / defaults (LinearElasticity.cc:22-23, :621-635; PDEFilter.cc:32, :280-283)
+    h = 1.0 / ey
+    grid = tp.Grid(ex + 1, ey + 1, ez + 1, h)
+    le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=4))
+    le.SetUpLoadAndBC()
+    popt = tp.SolverOptions(nlvls=3, rtol=1e-8, dtol=1e3, max_it=60, nsmooth=1, ncoarse=10) if ftype == 2 else None   # :371-378 one smoothing step
+    flt = tp.Filter(grid, ftype, 2.56 * h, popt)
+    x = grid.synth_density(12345)
+    xt, xp, df, dg = grid.elem_vec(), grid.elem_vec(), grid.elem_vec(), grid.elem_vec()
+    flt.FilterProject(x, xt, xp)
+    fx2, gx2 = le.ComputeObjectiveConstraintsSensitivities(df, dg, xp, 1e-9, 1.0, 3.0, 0.12)
+    flt.Gradients(x, xt, df, [dg])
+    tol = 1e-8 if ftype == 1 else 1e-6   # type 2: two iterative Helmholtz solves sit in between
+    assert its == le.last_its
+    assert sxp == pytest.approx(float(xp.sum()), rel=tol)
+    assert fx == pytest.approx(fx2, rel=tol) and gx == pytest.approx(gx2, abs=tol)
+    assert sdf == pytest.approx(float(df.sum()), rel=tol) and sdg == pytest.approx(float(dg.sum()), rel=tol)
+    assert un == pytest.approx(float(le.U.norm()), rel=tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(BIN), reason="host/_refbuild/ref_on_shim not built (build container only)")
+def test_reference_default_solver_is_refused_not_substituted():
+    """FGMRES + GMRES/SOR (LinearElasticity.cc:638, :720-746) is not implemented: the shim says so (PETSC_ERR_SUP = 56)
+    instead of silently solving with something else; $PETSC_OPTIONS selects the implemented configuration."""
+    r = _run([16, 8, 8, 1, "-nlvls", "3"])
+    assert r.returncode != 0 and "PETSC_ERR_SUP" in r.stderr and "fgmres" in r.stderr
+    assert "REF_ON_SHIM failed: 56" in r.stdout
+    r = _run([16, 8, 8, 1, "-nlvls", "3"], env={"PETSC_OPTIONS": " ".join(OPTS)})
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert np.isfinite(_numbers(r.stdout)).all()

@@ -216,6 +216,38 @@ static int pde_apply(tp_filter *f, const double *in, double *out) {
     return TP_OK;
 }
 
+// ---- the three operators of PDEFilt::FilterProject one by one (PDEFilter.cc:198-210), for a host that calls them
+// through PETSc names: MatMult(T) / KSPSolve(K_f) / MatMultTranspose(T).  Nodal vectors: local nodes of the grid.
+extern "C" int tp_pdefilter_elem_to_node(tp_filter *f, const double *x_elem, double *rhs_nodal) {
+    if (!f || f->type != 2 || !x_elem || !rhs_nodal) return TP_ERR_ARG;
+    tp_grid *g = f->grid;
+    Geom q = f->pde->lv[0].g;
+    TP_HIP(hipMemcpyAsync(f->xe, x_elem, sizeof(double) * (size_t)f->nel, hipMemcpyDeviceToDevice, g->stream));
+    TP_TRY(exchange_segments(g, f->xe, nullptr, nullptr, f->xe + f->nel, f->lay, 1, f->lay));
+    TP_LAUNCH(k_pde_elem_to_node, dim3((int)((q.owned_nodes() + BLK - 1) / BLK)), dim3(BLK), 0, g->stream, q, f->xe, 1.0,
+              rhs_nodal, f->rhs);  // vol = 1: T x itself (the caller scales, PDEFilter.cc:202)
+    count_launch(g, 8.0 * f->nel + 16.0 * q.owned_nodes(), 9.0 * q.owned_nodes());
+    return TP_OK;
+}
+extern "C" int tp_pdefilter_solve(tp_filter *f, const double *rhs_nodal, double *u_nodal) {
+    if (!f || f->type != 2 || !rhs_nodal || !u_nodal) return TP_ERR_ARG;
+    return f->pde->solve(rhs_nodal, u_nodal, &f->last_its, &f->last_rnorm, nullptr, nullptr, 0);
+}
+extern "C" int tp_pdefilter_node_to_elem(tp_filter *f, const double *u_nodal, double *x_elem) {
+    if (!f || f->type != 2 || !u_nodal || !x_elem) return TP_ERR_ARG;
+    tp_grid *g = f->grid;
+    Geom q = f->pde->lv[0].g;
+    TP_TRY(halo_nodes(g, q, const_cast<double *>(u_nodal), 1));
+    TP_LAUNCH(k_pde_node_to_elem, dim3((int)((f->nel + BLK - 1) / BLK)), dim3(BLK), 0, g->stream, q, u_nodal, x_elem);
+    count_launch(g, 8.0 * f->nel + 8.0 * q.owned_nodes(), 8.0 * f->nel);
+    return TP_OK;
+}
+// y = K_f u (the assembled Helmholtz matrix of PDEFilt::MatAssemble): MatMult on it
+extern "C" int tp_pdefilter_apply(tp_filter *f, const double *u_nodal, double *y_nodal) {
+    if (!f || f->type != 2 || !u_nodal || !y_nodal) return TP_ERR_ARG;
+    return f->pde->apply(0, const_cast<double *>(u_nodal), y_nodal);
+}
+
 // y = H x, the un-normalised cone filter (MatMult(H, x, y) of Filter.cc:68, :173, :181); types 0 and 1
 extern "C" int tp_filter_mult_h(tp_filter *f, const double *x, double *y) {
     if (!f || !x || !y || f->type > 1) return TP_ERR_ARG;

@@ -385,6 +385,11 @@ __global__ __launch_bounds__(BLK) void k_cantilever(Geom g, double *__restrict__
 }
 
 extern "C" int tp_elasticity_create(tp_elasticity **out, tp_grid *g, const tp_solver_opts *o) {
+    return tp_elasticity_create_ke(out, g, o, nullptr);
+}
+// ke_host_576 != NULL: use this element matrix instead of Hex8Isoparametric's (a host that assembles through
+// MatSetValuesLocal hands over the matrix it computed itself, LinearElasticity.cc:118-123, :519-524)
+extern "C" int tp_elasticity_create_ke(tp_elasticity **out, tp_grid *g, const tp_solver_opts *o, const double *ke_host_576) {
     if (!out || !g || !o) return TP_ERR_ARG;
     if (o->nlvls < 1 || o->nlvls > TP_MAX_LEVELS) return TP_ERR_ARG;
     // TopOpt.cc:183-201: every direction divisible by 2^(nlvls-1); here also per slab
@@ -410,7 +415,8 @@ extern "C" int tp_elasticity_create(tp_elasticity **out, tp_grid *g, const tp_so
     e->nlist2 = 0;
     e->nx_first = 0;
     e->nflag_all = 0;
-    hex8_stiffness_box(g->o.hx, g->o.hy, g->o.hz, o->nu, e->KE);
+    if (ke_host_576) std::memcpy(e->KE, ke_host_576, sizeof(e->KE));
+    else hex8_stiffness_box(g->o.hx, g->o.hy, g->o.hz, o->nu, e->KE);
     std::vector<double> M(8 * 576);
     host_child_matrices(e->KE, M.data());
     TP_TRY(e->mg.alloc_levels());

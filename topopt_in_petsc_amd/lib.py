@@ -75,6 +75,7 @@ SYMBOLS = {
     "tp_sync": (_i, [_vp]),
     "tp_solver_default_opts": (None, [C.POINTER(SolverOpts)]),
     "tp_elasticity_create": (_i, [C.POINTER(_vp), _vp, C.POINTER(SolverOpts)]),
+    "tp_elasticity_create_ke": (_i, [C.POINTER(_vp), _vp, C.POINTER(SolverOpts), _vp]),
     "tp_elasticity_destroy": (_i, [_vp]),
     "tp_elasticity_get_ke": (_i, [_vp, _vp]),
     "tp_elasticity_cantilever": (_i, [_vp, _vp, _vp]),
@@ -103,6 +104,10 @@ SYMBOLS = {
     "tp_filter_gradients": (_i, [_vp, _vp, _vp, _vp, _i, C.POINTER(_vp), _i, _d, _d]),
     "tp_filter_mnd": (_i, [_vp, _vp, C.POINTER(_d)]),
     "tp_filter_last_pde_its": (_i, [_vp, C.POINTER(_i), C.POINTER(_d)]),
+    "tp_pdefilter_elem_to_node": (_i, [_vp, _vp, _vp]),
+    "tp_pdefilter_solve": (_i, [_vp, _vp, _vp]),
+    "tp_pdefilter_node_to_elem": (_i, [_vp, _vp, _vp]),
+    "tp_pdefilter_apply": (_i, [_vp, _vp, _vp]),
     "tp_mma_create": (_i, [C.POINTER(_vp), _vp, _l, _l, _i, _vp]),
     "tp_mma_destroy": (_i, [_vp]),
     "tp_mma_set_outer_movelimit": (_i, [_vp, _d, _d, _d, _vp, _vp, _vp]),
