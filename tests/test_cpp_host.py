@@ -38,9 +38,9 @@ def test_cpp_driver_matches_python_driver():
     assert "# final volume fraction 0.1" in out.stdout
 
 
-# ---- PETSc-named adapter (include/petsc_shim.h, host/petsc_shim.cc) ---------------------------------------------
+# ---- PETSc-named surface (include/petsc_compat/petsc.h, host/petsc_shim.cc) ---------------------------------------------
 def _shim_symbols():
-    hdr = open(os.path.join(ROOT, "include", "petsc_shim.h")).read()
+    hdr = open(os.path.join(ROOT, "include", "petsc_compat", "petsc.h")).read()
     return sorted(set(re.findall(r"^PetscErrorCode\s+(\w+)\(", hdr, flags=re.M)))
 
 
