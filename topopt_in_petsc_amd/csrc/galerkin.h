@@ -20,6 +20,7 @@
 // the threads, so every load/store of a matrix is one contiguous 4.6 kB stream.
 #pragma once
 #include "common.h"
+#include "operators.h"
 
 // W[c][a][I], c = cx + 2cy + 4cz child position, a/I in reference corner order
 __device__ __constant__ double c_W[512];
@@ -440,4 +441,37 @@ __global__ __launch_bounds__(BLK) void k_macro_corr_gather(const int *__restrict
     }
 #pragma unroll
     for (int r = 0; r < 3; r++) corr[3 * n + r] = acc[r];
+}
+
+// Gather of the element-row products around every affected node (as k_macro_corr_gather) applied directly to the
+// result of the level-1 operator launch that computed them (matfree_tile.h: workgroups beyond the tiles):
+//   APPLY  y += c      RESID  r -= c      CHEB  (d, x_out) -= c2 dinv c
+template <int EPI>
+__global__ __launch_bounds__(BLK) void k_macro_corr_apply(const int *__restrict__ nodes, const int *__restrict__ adj,
+                                                          int nnodes, const double *__restrict__ tmp, int nlist,
+                                                          NodeArgs a) {
+    const int n0 = blockIdx.x * BLK + threadIdx.x;
+    if (n0 >= nnodes) return;
+    const long n = nodes[n0];
+    double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int I = 0; I < 8; I++) {
+        const int f = adj[8 * n0 + I];
+        if (f < 0) continue;
+#pragma unroll
+        for (int r = 0; r < 3; r++) acc[r] += tmp[(long)(3 * I + r) * nlist + f];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const long q = 3 * n + r;
+        if (EPI == EPI_APPLY) {
+            a.out[q] += acc[r];
+        } else if (EPI == EPI_RESID) {
+            a.out[q] -= acc[r];
+        } else if (EPI == EPI_CHEB) {
+            const double f = a.c2 * (a.dinv[q] * acc[r]);
+            a.d[q] -= f;
+            a.out[q] -= f;
+        }
+    }
 }

@@ -252,6 +252,14 @@ struct TileArgs {
     int macg_off;              // offset of the level-1 constants inside c_macG
     int r1_lo, r1_hi;          // second range of output planes (empty if r1_lo > r1_hi): the launch that produces the
                                // two boundary planes of a slab first (halo overlap); chunks of the first range come first
+    // MACRO, fused Dirichlet correction: workgroups beyond `ntiles` (0 = all are tiles) compute the element-row
+    // products dK_E[row] . x_E of the flagged elements (k_macro_corr_rows) INSIDE the operator's launch -- they fill
+    // the tail of the tile workgroups instead of a launch of their own; k_macro_corr_apply adds them afterwards
+    int ntiles;
+    const double *cr_dK;
+    const int *cr_list;
+    int cr_nflag;
+    double *cr_tmp;
 };
 // output planes [kz0, kz1] of z-chunk bzi
 __device__ inline void tile_chunk(const TileArgs &t, int bzi, int &kz0, int &kz1) {
@@ -292,8 +300,25 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
     // contiguous run of tiles so that neighbouring tiles, which share halo columns, meet in one L2
     int bxi, byi, bzi;
     {
-        const int nb = gridDim.x * gridDim.y * gridDim.z;
         const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int nb = t.ntiles > 0 ? t.ntiles : gridDim.x * gridDim.y * gridDim.z;
+        if (MACRO && lin >= nb) {  // workgroup-uniform, before any barrier
+            const long tt = (long)(lin - nb) * (TILE * TILE) + tid;
+            if (tt < (long)t.cr_nflag * 24) {
+                const int r = (int)(tt / t.cr_nflag), f = (int)(tt % t.cr_nflag);
+                const long ce = t.cr_list[f];
+                const int ci = (int)(ce % t.ex), cj = (int)((ce / t.ex) % t.ey), ck = (int)(ce / ((long)t.ex * t.ey));
+                double acc = 0.0;
+#pragma unroll
+                for (int J = 0; J < 8; J++) {
+                    const long nbn = (long)(ci + LXc(J)) + (long)t.nx * ((cj + LYc(J)) + (long)t.ny * (ck + LZc(J)));
+#pragma unroll
+                    for (int c = 0; c < 3; c++) acc = fma(t.cr_dK[(long)(r * 24 + 3 * J + c) * t.cr_nflag + f], a.x[3 * nbn + c], acc);
+                }
+                t.cr_tmp[tt] = acc;
+            }
+            return;
+        }
         const int x8 = lin & 7;
         const int m = t.xcd_remap ? x8 * (nb >> 3) + min(x8, nb & 7) + (lin >> 3) : lin;  // bijection of [0, nb)
         bxi = m % gridDim.x;

@@ -478,7 +478,8 @@ struct MGSolver {
                 const int tz = (hi - lo + kz) / kz + (r1hi - r1lo + kz) / kz;
                 last_nblocks = tx * ty * tz;
                 TileArgs ta{L.g.nx, L.g.ny, L.g.nzl, L.g.ex, L.g.ey, L.g.ezl, lo, hi, kz,
-                            L.E, L.mask, L.colmask, L.sym_slot * SYMKE_STRIDE, 0, 0, nullptr, xcd_remap(), 0, r1lo, r1hi};
+                            L.E, L.mask, L.colmask, L.sym_slot * SYMKE_STRIDE, 0, 0, nullptr, xcd_remap(), 0, r1lo, r1hi,
+                            0, nullptr, nullptr, 0, nullptr};
                 if (fine_v == 2) {
                     TP_LAUNCH((k_fine_tile<EPI>), dim3(tx, ty, tz), dim3(TILE * TILE), 0, grid->stream, ta, a);
                 } else {
@@ -498,7 +499,13 @@ struct MGSolver {
             int kz = kz_env > 0 ? kz_env : (int)((long)planes * tx * ty / 768);
             if (kz_env <= 0) kz = kz < 4 ? 4 : (kz > 64 ? 64 : kz);
             if (kz > planes) kz = planes;
-            if (L.ncorr_nodes) {
+            // Dirichlet correction of the level-1 operator.  One launch computes tiles AND element-row products
+            // (extra workgroups behind the tiles), a second one adds the gathered products to the result.  Slab runs keep
+            // the older order (products first, added by the tiles): the boundary planes of a boundary-first launch
+            // leave for the neighbour right after the first pass and must be final by then.
+            static const bool no_fuse = getenv("TP_NO_CORR_FUSE") != nullptr;
+            const bool fuse_corr = L.ncorr_nodes && !grid->has_comm && !no_fuse && EPI != EPI_APPLY_DOT;  // slabs: one order for both halo modes
+            if (L.ncorr_nodes && !fuse_corr) {
                 TP_LAUNCH(k_macro_corr_rows, dim3((L.nflag * 24 + BLK - 1) / BLK), dim3(BLK), 0, grid->stream, L.g,
                                    L.dK, L.flag_list, L.nflag, a.x, L.corr_tmp);
                 TP_LAUNCH(k_macro_corr_gather, dim3((L.ncorr_nodes + BLK - 1) / BLK), dim3(BLK), 0, grid->stream,
@@ -509,13 +516,23 @@ struct MGSolver {
             for (int pass = 0; pass < (split ? 2 : 1); pass++) {
                 int lo, hi, r1lo, r1hi;
                 tile_ranges(pass, lo, hi, r1lo, r1hi);
-                const int tz = (hi - lo + kz) / kz + (r1hi - r1lo + kz) / kz;
-                last_nblocks = tx * ty * tz;
+                int tz = (hi - lo + kz) / kz + (r1hi - r1lo + kz) / kz;
+                const int ntiles = tx * ty * tz;
+                last_nblocks = ntiles;
+                if (fuse_corr) tz += ((L.nflag * 24 + BLK - 1) / BLK + tx * ty - 1) / (tx * ty);  // row-product workgroups
                 TileArgs ta{L.g.nx, L.g.ny, L.g.nzl, L.g.ex, L.g.ey, L.g.ezl, lo, hi, kz,
                             L.E, nullptr, nullptr, L.sym_slot * SYMKE_STRIDE, L.fex, L.fey,
-                            L.ncorr_nodes ? L.corr : nullptr, xcd_remap(), L.sym_slot * MACG_STRIDE, r1lo, r1hi};
+                            (L.ncorr_nodes && !fuse_corr) ? L.corr : nullptr, xcd_remap(), L.sym_slot * MACG_STRIDE, r1lo, r1hi,
+                            ntiles, L.dK, L.flag_list, L.nflag, L.corr_tmp};
                 TP_LAUNCH((k_matfree_tile<EPI, 1>), dim3(tx, ty, tz), dim3(TILE * TILE), 0, grid->stream, ta, a);
                 if (split && pass == 0) TP_TRY(after_boundary());
+            }
+            if (fuse_corr) {
+                if constexpr (EPI != EPI_APPLY_DOT) {
+                    TP_LAUNCH((k_macro_corr_apply<EPI>), dim3((L.ncorr_nodes + BLK - 1) / BLK), dim3(BLK), 0, grid->stream,
+                              L.corr_nodes, L.corr_adj, L.ncorr_nodes, L.corr_tmp, L.nflag, a);
+                }
+                count_launch(grid);
             }
             bytes = 16.0 * DOF * nown + 8.0 * 8.0 * L.g.own_elems();
             flops = 2.0 * 576 * 8.0 * (double)L.g.own_elems();
