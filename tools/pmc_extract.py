@@ -8,7 +8,7 @@ import json
 import sys
 
 root, ex, ey, ez = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-KEYS = {"spmv": "k_matfree_tile<0, 0>", "cheb": "k_matfree_tile<2, 0>", "calib": "k_scale"}
+KEYS = {"spmv": "k_fine_tile<0>", "cheb": "k_fine_tile<2>", "calib": "k_scale"}
 
 
 def mean_counter(name):
