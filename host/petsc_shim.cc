@@ -5,6 +5,7 @@
 // exactly as with real PETSc (anything else: PETSC_ERR_SUP with a message, never a silent substitution).
 #include <petsc/private/dmdaimpl.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdint>
 #include <chrono>
@@ -82,7 +83,10 @@ struct _p_Vec {
     long n;
     double *d;  // [dev]; NULL for a host-only vector (coordinates)
     std::vector<double> host;
-    bool host_newer;  // VecSetValue* since the last assembly
+    // Lazy coherence of the host mirror and the HBM array.  VecGetArray hands out host.data() and from then on the HOST
+    // copy is the authoritative one (the reference also leaves arrays checked out for good: MMA.cc:549-550 gets p0/q0
+    // and never restores them) until a device operation needs the vector (din/dinout push it) or overwrites it (dout).
+    bool host_valid, dev_valid;
     DM dm;            // borrowed
 };
 struct DMFull : _p_DM {
@@ -141,6 +145,13 @@ struct _p_PetscViewer {
     Hdr h;
     FILE *fp;
     PetscFileMode mode;
+    bool ascii;
+};
+struct _mpi_compat_file {
+    FILE *fp;
+    long long disp;           // byte displacement of the view
+    int vec_block, vec_stride, vec_esize;  // vector filetype (0 = contiguous)
+    long long pos;            // elements written since the view was set
 };
 struct _p_PetscRandom {
     Hdr h;
@@ -185,10 +196,12 @@ int vec_create(long n, bool host_only, DM dm, Vec *out) {
     hdr_init(v->h, CLS_VEC, "seq");
     v->n = n;
     v->d = nullptr;
-    v->host_newer = false;
+    v->host_valid = false;
+    v->dev_valid = true;
     v->dm = dm;
     if (host_only) {
         v->host.assign((size_t)n, 0.0);
+        v->host_valid = true;
     } else {
         int rc = ensure_grid();
         if (!rc) rc = tp_malloc((void **)&v->d, sizeof(double) * (size_t)(n > 0 ? n : 1));
@@ -201,13 +214,35 @@ int vec_create(long n, bool host_only, DM dm, Vec *out) {
     *out = v;
     return 0;
 }
-int vec_pull(Vec x) {  // device -> host mirror
-    if (!x->d) return 0;
+int vec_pull(Vec x) {  // make the host mirror current
+    if (!x->d || x->host_valid) return 0;
     x->host.resize((size_t)x->n);
     tp_sync(mesh.g);
-    return tp_memcpy_d2h(x->host.data(), x->d, sizeof(double) * (size_t)x->n);
+    int rc = tp_memcpy_d2h(x->host.data(), x->d, sizeof(double) * (size_t)x->n);
+    x->host_valid = rc == 0;
+    return rc;
 }
-int vec_push(Vec x) { return x->d ? tp_memcpy_h2d(x->d, x->host.data(), sizeof(double) * (size_t)x->n) : 0; }
+int vec_push(Vec x) {  // make the HBM array current
+    if (!x->d || x->dev_valid) return 0;
+    int rc = tp_memcpy_h2d(x->d, x->host.data(), sizeof(double) * (size_t)x->n);
+    x->dev_valid = rc == 0;
+    return rc;
+}
+// device pointers for an operation that reads / overwrites / updates the vector
+double *din(Vec x) {
+    vec_push(x);
+    return x->d;
+}
+double *dout(Vec x) {
+    x->dev_valid = true;
+    x->host_valid = false;
+    return x->d;
+}
+double *dinout(Vec x) {
+    vec_push(x);
+    x->host_valid = false;
+    return x->d;
+}
 
 // ---- the solver configuration a KSP resolves to ------------------------------------------------------------
 void ksp_apply_options(KSP k, const std::vector<std::string> &prefixes) {
@@ -284,7 +319,7 @@ int ensure_elasticity(Mat A) {
     if (A->assembled_since_setup) {
         if (!A->have_bc || !A->Nvec) return sup("stiffness matrix without MatDiagonalScale(K, N, N): Dirichlet vector unknown");
         if ((long)A->E.size() != nel || A->ncalls != nel) return sup("MatSetValuesLocal: not every element was added exactly once");
-        int rc = tp_elasticity_set_bc(A->e, A->Nvec->d);
+        int rc = tp_elasticity_set_bc(A->e, din(A->Nvec));
         if (!rc) rc = tp_memcpy_h2d(A->dE, A->E.data(), sizeof(double) * (size_t)nel);
         // E_e = 0 + x^1 (1 - 0): the captured multipliers ARE the moduli (pow(x, 1.0) is exact)
         if (!rc) rc = tp_elasticity_assemble(A->e, A->dE, 0.0, 1.0, 1.0);
@@ -413,10 +448,96 @@ PetscErrorCode PetscObjectTypeCompare(PetscObject obj, const char type_name[], P
     *same = (t && type_name && strcmp(t, type_name) == 0) ? PETSC_TRUE : PETSC_FALSE;
     return 0;
 }
+static int mpi_esize(MPI_Datatype t) {
+    switch (t) {
+    case MPI_CHAR: return 1;
+    case MPI_INT: case MPI_FLOAT: return 4;
+    default: return 8;
+    }
+}
+struct VecType {
+    int count, block, stride, esize;
+};
+static std::vector<VecType> &vec_types() {
+    static std::vector<VecType> v;
+    return v;
+}
 int MPI_Allreduce(const void *s, void *r, int count, MPI_Datatype t, MPI_Op, MPI_Comm) {
-    if (s != r) memcpy(r, s, (size_t)count * (t == MPIU_INT ? sizeof(PetscInt) : sizeof(double)));
+    if (s != r) memcpy(r, s, (size_t)count * (size_t)mpi_esize(t));
     return 0;
 }
+int MPI_Allgather(const void *s, int sc, MPI_Datatype st, void *r, int, MPI_Datatype, MPI_Comm) {
+    if (s != r) memcpy(r, s, (size_t)sc * (size_t)mpi_esize(st));
+    return 0;
+}
+int MPI_Init(int *, char ***) { return 0; }
+int MPI_Finalize(void) { return 0; }
+int MPI_Abort(MPI_Comm, int code) {
+    fprintf(stderr, "[mpi-compat] MPI_Abort(%d)\n", code);
+    exit(code ? code : 1);
+}
+int MPI_Type_size(MPI_Datatype t, int *size) {
+    *size = mpi_esize(t);
+    return 0;
+}
+int MPI_Type_vector(int count, int blocklength, int stride, MPI_Datatype oldtype, MPI_Datatype *newtype) {
+    vec_types().push_back({count, blocklength, stride, mpi_esize(oldtype)});
+    *newtype = 1000 + (int)vec_types().size() - 1;
+    return 0;
+}
+int MPI_Type_commit(MPI_Datatype *) { return 0; }
+int MPI_Type_free(MPI_Datatype *t) {
+    *t = 0;
+    return 0;
+}
+int MPI_File_open(MPI_Comm, const char *filename, int amode, MPI_Info, MPI_File *fh) {
+    FILE *fp = fopen(filename, "r+b");  // MPI-IO never truncates: several open/close rounds build one file
+    if (!fp && (amode & MPI_MODE_CREATE)) fp = fopen(filename, "w+b");
+    if (!fp) return 1;
+    *fh = new _mpi_compat_file{fp, 0, 0, 0, 0, 0};
+    return 0;
+}
+int MPI_File_close(MPI_File *fh) {
+    if (fh && *fh) {
+        fclose((*fh)->fp);
+        delete *fh;
+        *fh = nullptr;
+    }
+    return 0;
+}
+int MPI_File_delete(const char *filename, MPI_Info) { return remove(filename) ? 1 : 0; }
+int MPI_File_set_view(MPI_File fh, MPI_Offset disp, MPI_Datatype, MPI_Datatype filetype, const char *, MPI_Info) {
+    fh->disp = disp;
+    fh->pos = 0;
+    fh->vec_block = fh->vec_stride = fh->vec_esize = 0;
+    if (filetype >= 1000) {
+        const VecType &v = vec_types()[(size_t)(filetype - 1000)];
+        fh->vec_block = v.block;
+        fh->vec_stride = v.stride;
+        fh->vec_esize = v.esize;
+    }
+    return 0;
+}
+int MPI_File_write(MPI_File fh, const void *buf, int count, MPI_Datatype t, MPI_Status *) {
+    const int es = mpi_esize(t);
+    const char *p = (const char *)buf;
+    if (!fh->vec_block) {
+        fseek(fh->fp, (long)(fh->disp + fh->pos * es), SEEK_SET);
+        fwrite(p, (size_t)es, (size_t)count, fh->fp);
+        fh->pos += count;
+        return 0;
+    }
+    for (int done = 0; done < count;) {  // blocks of vec_block elements every vec_stride elements
+        const long long blk = fh->pos / fh->vec_block, within = fh->pos % fh->vec_block;
+        const int n = (int)std::min<long long>(fh->vec_block - within, count - done);
+        fseek(fh->fp, (long)(fh->disp + (blk * fh->vec_stride + within) * es), SEEK_SET);
+        fwrite(p + (size_t)done * es, (size_t)es, (size_t)n, fh->fp);
+        done += n;
+        fh->pos += n;
+    }
+    return 0;
+}
+int MPI_File_write_all(MPI_File fh, const void *buf, int count, MPI_Datatype t, MPI_Status *st) { return MPI_File_write(fh, buf, count, t, st); }
 int MPI_Comm_rank(MPI_Comm, int *rank) {
     *rank = 0;
     return 0;
@@ -436,7 +557,38 @@ PetscErrorCode PetscViewerBinaryOpen(MPI_Comm, const char name[], PetscFileMode 
     hdr_init(w->h, CLS_VIEWER, PETSCVIEWERBINARY);
     w->fp = fp;
     w->mode = mode;
+    w->ascii = false;
     *v = w;
+    return 0;
+}
+PetscErrorCode PetscViewerCreate(MPI_Comm, PetscViewer *v) {
+    PetscViewer w = new _p_PetscViewer();
+    hdr_init(w->h, CLS_VIEWER, PETSCVIEWERASCII);
+    w->fp = nullptr;
+    w->mode = FILE_MODE_WRITE;
+    w->ascii = true;
+    *v = w;
+    return 0;
+}
+PetscErrorCode PetscViewerSetType(PetscViewer v, PetscViewerType type) {
+    v->ascii = strcmp(type, PETSCVIEWERASCII) == 0;
+    return 0;
+}
+PetscErrorCode PetscViewerFileSetMode(PetscViewer v, PetscFileMode mode) {
+    v->mode = mode;
+    return 0;
+}
+PetscErrorCode PetscViewerFileSetName(PetscViewer v, const char name[]) {
+    if (v->fp) fclose(v->fp);
+    v->fp = fopen(name, v->mode == FILE_MODE_READ ? "r" : (v->mode == FILE_MODE_APPEND ? "a" : "w"));
+    return v->fp ? 0 : PETSC_ERR_FILE_OPEN;
+}
+PetscErrorCode PetscViewerASCIIPrintf(PetscViewer v, const char format[], ...) {
+    if (!v->fp) return PETSC_ERR_ORDER;
+    va_list ap;
+    va_start(ap, format);
+    vfprintf(v->fp, format, ap);
+    va_end(ap);
     return 0;
 }
 PetscErrorCode PetscViewerDestroy(PetscViewer *v) {
@@ -728,42 +880,54 @@ PetscErrorCode VecSet(Vec v, PetscScalar a) {
         std::fill(v->host.begin(), v->host.end(), a);
         return 0;
     }
-    v->host_newer = false;
-    return tp_vec_set(mesh.g, v->d, a, v->n);
+    return tp_vec_set(mesh.g, dout(v), a, v->n);
 }
 PetscErrorCode VecCopy(Vec x, Vec y) {
     if (x->n != y->n) return PETSC_ERR_ARG_WRONG;
-    return tp_vec_axpby(mesh.g, y->d, 1.0, x->d, 0.0, y->n);
+    if (x == y) return 0;
+    const double *px = din(x);
+    return tp_vec_axpby(mesh.g, dout(y), 1.0, px, 0.0, y->n);
 }
-PetscErrorCode VecScale(Vec v, PetscScalar a) { return tp_vec_scale(mesh.g, v->d, a, v->n); }
+PetscErrorCode VecScale(Vec v, PetscScalar a) { return tp_vec_scale(mesh.g, dinout(v), a, v->n); }
 PetscErrorCode VecAXPY(Vec y, PetscScalar a, Vec x) {
     if (x->n != y->n) return PETSC_ERR_ARG_WRONG;
-    return tp_vec_axpby(mesh.g, y->d, a, x->d, 1.0, y->n);
+    const double *px = din(x);
+    return tp_vec_axpby(mesh.g, dinout(y), a, px, 1.0, y->n);
 }
 PetscErrorCode VecAXPBY(Vec y, PetscScalar a, PetscScalar b, Vec x) {
     if (x->n != y->n) return PETSC_ERR_ARG_WRONG;
-    return tp_vec_axpby(mesh.g, y->d, a, x->d, b, y->n);
+    const double *px = din(x);
+    return tp_vec_axpby(mesh.g, dinout(y), a, px, b, y->n);
+}
+PetscErrorCode VecAXPBYPCZ(Vec z, PetscScalar alpha, PetscScalar beta, PetscScalar gamma, Vec x, Vec y) {  // z = a x + b y + c z
+    const double *px = din(x), *py = din(y);
+    double *pz = gamma == 0.0 ? dout(z) : dinout(z);
+    int rc = tp_vec_axpby(mesh.g, pz, alpha, px, gamma, z->n);
+    return rc ? rc : tp_vec_axpby(mesh.g, pz, beta, py, 1.0, z->n);
 }
 PetscErrorCode VecPointwiseMult(Vec w, Vec x, Vec y) {
     if (w->n != x->n || w->n != y->n) return PETSC_ERR_ARG_WRONG;
-    return tp_vec_pointwise(mesh.g, w->d, x->d, y->d, 0, w->n);
+    const double *px = din(x), *py = din(y);
+    return tp_vec_pointwise(mesh.g, (w == x || w == y) ? dinout(w) : dout(w), px, py, 0, w->n);
 }
 PetscErrorCode VecPointwiseDivide(Vec w, Vec x, Vec y) {
     if (w->n != x->n || w->n != y->n) return PETSC_ERR_ARG_WRONG;
-    return tp_vec_pointwise(mesh.g, w->d, x->d, y->d, 1, w->n);
+    const double *px = din(x), *py = din(y);
+    return tp_vec_pointwise(mesh.g, (w == x || w == y) ? dinout(w) : dout(w), px, py, 1, w->n);
 }
 PetscErrorCode VecDot(Vec x, Vec y, PetscScalar *val) {
     if (x->n != y->n) return PETSC_ERR_ARG_WRONG;
-    return tp_vec_dot(mesh.g, x->d, y->d, x->n, val);
+    return tp_vec_dot(mesh.g, din(x), din(y), x->n, val);
 }
 PetscErrorCode VecNorm(Vec x, NormType type, PetscReal *val) {
     if (type != NORM_2) return sup("VecNorm: NORM_2 only");
     double s = 0.0;
-    int rc = tp_vec_dot(mesh.g, x->d, x->d, x->n, &s);
+    const double *px = din(x);
+    int rc = tp_vec_dot(mesh.g, px, px, x->n, &s);
     *val = std::sqrt(s);
     return rc;
 }
-PetscErrorCode VecSum(Vec x, PetscScalar *sum) { return tp_vec_dot(mesh.g, x->d, nullptr, x->n, sum); }
+PetscErrorCode VecSum(Vec x, PetscScalar *sum) { return tp_vec_dot(mesh.g, din(x), nullptr, x->n, sum); }
 PetscErrorCode VecMax(Vec x, PetscInt *p, PetscReal *val) {
     int rc = vec_pull(x);
     long at = 0;
@@ -788,39 +952,51 @@ PetscErrorCode VecGetSize(Vec x, PetscInt *n) {
 }
 PetscErrorCode VecGetLocalSize(Vec x, PetscInt *n) { return VecGetSize(x, n); }
 PetscErrorCode VecGetArray(Vec x, PetscScalar **a) {
-    int rc = x->host_newer ? 0 : vec_pull(x);
+    int rc = vec_pull(x);
+    if (x->d) x->dev_valid = false;  // the caller may write through the pointer, now or later
     *a = x->host.data();
     return rc;
 }
-PetscErrorCode VecRestoreArray(Vec x, PetscScalar **a) {
+PetscErrorCode VecRestoreArray(Vec, PetscScalar **a) {  // nothing to copy: the next device use pushes the mirror
     if (a) *a = nullptr;
-    x->host_newer = false;
-    return vec_push(x);
+    return 0;
+}
+PetscErrorCode VecGetArrays(const Vec x[], PetscInt n, PetscScalar **a[]) {
+    PetscScalar **q = (PetscScalar **)malloc(sizeof(PetscScalar *) * (size_t)(n > 0 ? n : 1));
+    for (PetscInt i = 0; i < n; i++) {
+        int rc = VecGetArray(x[i], &q[i]);
+        if (rc) return rc;
+    }
+    *a = q;
+    return 0;
+}
+PetscErrorCode VecRestoreArrays(const Vec[], PetscInt, PetscScalar **a[]) {
+    if (a && *a) {
+        free(*a);
+        *a = nullptr;
+    }
+    return 0;
 }
 PetscErrorCode VecSetValueLocal(Vec v, PetscInt row, PetscScalar value, InsertMode mode) {
     if (row < 0 || row >= v->n) return PETSC_ERR_ARG_OUTOFRANGE;
-    if (!v->host_newer) {
-        int rc = vec_pull(v);
-        if (rc) return rc;
-        v->host_newer = true;
-    }
+    int rc = vec_pull(v);
+    if (rc) return rc;
+    if (v->d) v->dev_valid = false;
     if (mode == ADD_VALUES) v->host[(size_t)row] += value;
     else v->host[(size_t)row] = value;
     return 0;
 }
 PetscErrorCode VecSetValue(Vec v, PetscInt row, PetscScalar value, InsertMode mode) { return VecSetValueLocal(v, row, value, mode); }
 PetscErrorCode VecAssemblyBegin(Vec) { return 0; }
-PetscErrorCode VecAssemblyEnd(Vec v) {
-    if (!v->host_newer) return 0;
-    v->host_newer = false;
-    return vec_push(v);
-}
+PetscErrorCode VecAssemblyEnd(Vec v) { return vec_push(v); }
 PetscErrorCode VecSetRandom(Vec v, PetscRandom r) {
     v->host.resize((size_t)v->n);
     for (long i = 0; i < v->n; i++) {  // drand48's linear congruential generator
         r->state = (r->state * 0x5DEECE66DULL + 0xBULL) & ((1ULL << 48) - 1);
         v->host[(size_t)i] = (double)r->state / (double)(1ULL << 48);
     }
+    v->host_valid = true;
+    v->dev_valid = false;
     return vec_push(v);
 }
 // PETSc binary Vec: big-endian int32 class id 1211214, int32 n, n big-endian doubles
@@ -858,10 +1034,12 @@ PetscErrorCode VecLoad(Vec v, PetscViewer w) {
         for (int k = 0; k < 8; k++) u = (u << 8) | b[k];
         memcpy(&v->host[(size_t)i], &u, 8);
     }
+    v->host_valid = true;
+    v->dev_valid = false;
     return vec_push(v);
 }
 PetscErrorCode VecTopOptGetDevicePointer(Vec x, PetscScalar **d) {
-    *d = x->d;
+    *d = dinout(x);
     return 0;
 }
 
@@ -962,25 +1140,44 @@ PetscErrorCode MatMult(Mat A, Vec x, Vec y) {
     switch (A->kind) {
     case K_ELAST: {
         int rc = ensure_elasticity(A);
-        return rc ? rc : tp_elasticity_apply(A->e, x->d, y->d);
+        if (rc) return rc;
+        const double *px = din(x);
+        return tp_elasticity_apply(A->e, px, dout(y));
     }
     case K_EXT_ELAST:
-        return A->ext_assembled ? tp_elasticity_apply(A->e, x->d, y->d) : PETSC_ERR_ORDER;
+        {
+        if (!A->ext_assembled) return PETSC_ERR_ORDER;
+        const double *px = din(x);
+        return tp_elasticity_apply(A->e, px, dout(y));
+    }
     case K_CONE:
-        return A->f ? tp_filter_mult_h(A->f, x->d, y->d) : PETSC_ERR_ORDER;
+        {
+        if (!A->f) return PETSC_ERR_ORDER;
+        const double *px = din(x);
+        return tp_filter_mult_h(A->f, px, dout(y));
+    }
     case K_EXT_FILTER:
         if (A->coneR < 0.0) {  // PDE filter as one operator
-            return tp_filter_project(A->f, x->d, y->d, y->d, 0, 0.0, 0.0) ? PETSC_ERR_ARG_WRONG : 0;
+            const double *px = din(x);
+            double *py = dout(y);
+            return tp_filter_project(A->f, px, py, py, 0, 0.0, 0.0) ? PETSC_ERR_ARG_WRONG : 0;
         }
-        return tp_filter_mult_h(A->f, x->d, y->d);
+        {
+            const double *px = din(x);
+            return tp_filter_mult_h(A->f, px, dout(y));
+        }
     case K_HELM: {
         int rc = ensure_pdefilter(A);
-        return rc ? rc : tp_pdefilter_apply(A->f, x->d, y->d);
+        if (rc) return rc;
+        const double *px = din(x);
+        return tp_pdefilter_apply(A->f, px, dout(y));
     }
     case K_TMAT: {
         if (!g_last_helm) return PETSC_ERR_ORDER;
         int rc = ensure_pdefilter(g_last_helm);
-        return rc ? rc : tp_pdefilter_elem_to_node(g_last_helm->f, x->d, y->d);
+        if (rc) return rc;
+        const double *px = din(x);
+        return tp_pdefilter_elem_to_node(g_last_helm->f, px, dout(y));
     }
     default:
         return sup("MatMult on this matrix");
@@ -993,7 +1190,9 @@ PetscErrorCode MatMultTranspose(Mat A, Vec x, Vec y) {
     }
     if (x->n != A->n_rows || y->n != A->n_cols || !g_last_helm) return PETSC_ERR_ARG_WRONG;
     int rc = ensure_pdefilter(g_last_helm);
-    return rc ? rc : tp_pdefilter_node_to_elem(g_last_helm->f, x->d, y->d);
+    if (rc) return rc;
+    const double *px = dinout(x);  // its ghost planes are refreshed
+    return tp_pdefilter_node_to_elem(g_last_helm->f, px, dout(y));
 }
 PetscErrorCode MatDestroy(Mat *A) {
     if (A && *A) {
@@ -1103,14 +1302,18 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
         if (rc) return rc;
     }
     if (A->kind == K_HELM) {
-        rc = tp_pdefilter_solve(A->f, b->d, x->d);
+        {
+            const double *pb = din(b);
+            rc = tp_pdefilter_solve(A->f, pb, dinout(x));
+        }
         if (!rc) rc = tp_filter_last_pde_its(A->f, &k->its, &k->rnorm);
         return rc;
     }
     rc = tp_elasticity_set_tolerances(A->e, k->rtol, k->atol, k->dtol, k->maxits);
     if (rc) return rc;
     double bn = 0.0;
-    return tp_elasticity_solve(A->e, b->d, x->d, &k->its, &k->rnorm, &bn, nullptr, 0);
+    const double *pb = din(b);
+    return tp_elasticity_solve(A->e, pb, dinout(x), &k->its, &k->rnorm, &bn, nullptr, 0);
 }
 PetscErrorCode KSPGetIterationNumber(KSP k, PetscInt *its) {
     *its = k->its;
@@ -1225,25 +1428,26 @@ PetscErrorCode MatCreateTopOptElasticity(DM da, PetscScalar nu, PetscInt nlvls, 
 PetscErrorCode MatTopOptCantilever(Mat K, Vec N, Vec RHS) {
     if (!K || K->kind != K_EXT_ELAST || N->n != K->n_rows || RHS->n != K->n_rows) return PETSC_ERR_ARG_WRONG;
     K->have_bc = true;
-    return tp_elasticity_cantilever(K->e, N->d, RHS->d);  // also registers N
+    return tp_elasticity_cantilever(K->e, dout(N), dout(RHS));  // also registers N
 }
 PetscErrorCode MatTopOptSetDirichlet(Mat K, Vec N) {
     if (!K || K->kind != K_EXT_ELAST || N->n != K->n_rows) return PETSC_ERR_ARG_WRONG;
     K->have_bc = true;
-    return tp_elasticity_set_bc(K->e, N->d);
+    return tp_elasticity_set_bc(K->e, din(N));
 }
 PetscErrorCode MatTopOptAssemble(Mat K, Vec xPhys, PetscScalar Emin, PetscScalar Emax, PetscScalar penal) {
     if (!K || K->kind != K_EXT_ELAST) return PETSC_ERR_ARG_WRONG;
     if (!K->have_bc) return PETSC_ERR_ORDER;
     K->ext_assembled = true;
-    return tp_elasticity_assemble(K->e, xPhys->d, Emin, Emax, penal);
+    return tp_elasticity_assemble(K->e, din(xPhys), Emin, Emax, penal);
 }
 PetscErrorCode MatTopOptComplianceSensitivity(Mat K, Vec U, Vec xPhys, PetscScalar Emin, PetscScalar Emax,
                                               PetscScalar penal, PetscScalar volfrac, PetscScalar *fx, PetscScalar *gx,
                                               Vec dfdx, Vec dgdx) {
     if (!K || (K->kind != K_EXT_ELAST && K->kind != K_ELAST) || !K->e) return PETSC_ERR_ARG_WRONG;
-    return tp_elasticity_objective(K->e, U->d, xPhys->d, Emin, Emax, penal, volfrac, fx, gx, dfdx ? dfdx->d : nullptr,
-                                   dgdx ? dgdx->d : nullptr);
+    const double *pu = dinout(U), *px = din(xPhys);
+    return tp_elasticity_objective(K->e, pu, px, Emin, Emax, penal, volfrac, fx, gx, dfdx ? dout(dfdx) : nullptr,
+                                   dgdx ? dout(dgdx) : nullptr);
 }
 PetscErrorCode MatCreateTopOptFilter(DM da, PetscInt filterType, PetscScalar R, Mat *H, Vec *Hs) {
     DMFull *d = F(da);
@@ -1264,7 +1468,7 @@ PetscErrorCode MatCreateTopOptFilter(DM da, PetscInt filterType, PetscScalar R, 
     }
     if (Hs) {
         rc = vec_create(nel, false, nullptr, Hs);
-        if (!rc) rc = filterType == 2 ? VecSet(*Hs, 1.0) : tp_filter_get_hs(A->f, (*Hs)->d);
+        if (!rc) rc = filterType == 2 ? VecSet(*Hs, 1.0) : tp_filter_get_hs(A->f, dout(*Hs));
     }
     *H = A;
     return rc;

@@ -2,9 +2,11 @@
  * (the calls of LinearElasticity.cc, Filter.cc and PDEFilter.cc), implemented on the MI355X
  * library (libtopopt_petsc_shim.so, host/petsc_shim.cc -> libtopopt_amd.so).
  *
- * Put  -I include/petsc_compat  where a PETSc build would put  -I $PETSC_DIR/include : the reference's three
- * classes compile UNCHANGED against this header (tests/test_reference_compiles.py does exactly that, in the build
- * container, storing nothing).  Same names, argument order, ownership rules (XxxDestroy nulls the handle,
+ * Put  -I include/petsc_compat  where a PETSc build would put  -I $PETSC_DIR/include : ALL EIGHT sources of the
+ * reference (main.cc, TopOpt.cc, MMA.cc, MPIIO.cc and the three hot-path classes) compile UNCHANGED against this
+ * header and the single-process mpi.h beside it (host/build_ref_on_shim.sh and tests/test_reference_on_shim.py do
+ * exactly that, in the build container, storing nothing), and the resulting program runs the reference's
+ * optimisation loop on the GPU.  Same names, argument order, ownership rules (XxxDestroy nulls the handle,
  * reference counted where the reference relies on it: PCMGSetInterpolation / KSPSetOperators retain) and error
  * convention (PetscErrorCode, 0 = success, CHKERRQ = return on non-zero).
  *
@@ -45,25 +47,17 @@ typedef double PetscScalar;
 typedef double PetscReal;
 typedef double PetscLogDouble;
 typedef enum { PETSC_FALSE, PETSC_TRUE } PetscBool;
-typedef int MPI_Comm;
-typedef int MPI_Datatype;
-typedef int MPI_Op;
-#define PETSC_COMM_WORLD 0
-#define PETSC_COMM_SELF 1
-#define MPI_COMM_WORLD 0
+#include <mpi.h> /* the single-process MPI subset of this directory */
+#define PETSC_COMM_WORLD MPI_COMM_WORLD
+#define PETSC_COMM_SELF MPI_COMM_SELF
 #define PETSC_DECIDE (-1)
 #define PETSC_DETERMINE PETSC_DECIDE
 #define PETSC_DEFAULT (-2)
 #define PETSC_MAX_PATH_LEN 4096
 #define PETSC_NULL NULL
-#define MPIU_SCALAR 1
-#define MPIU_REAL 1
-#define MPIU_INT 2
-#define MPI_DOUBLE 1
-#define MPI_INT 2
-#define MPI_SUM 1
-#define MPI_MAX 2
-#define MPI_MIN 3
+#define MPIU_SCALAR MPI_DOUBLE
+#define MPIU_REAL MPI_DOUBLE
+#define MPIU_INT MPI_INT
 #define PETSC_ERR_SUP 56
 #define PETSC_ERR_ORDER 58
 #define PETSC_ERR_ARG_OUTOFRANGE 63
@@ -151,12 +145,12 @@ PetscErrorCode PetscFreeCompat(void *p);
 #define PetscMalloc(n, p) PetscMallocCompat((size_t)(n), (void **)(p))
 #define PetscFree(p) (PetscFreeCompat((void *)(p)), (p) = 0, 0)
 PetscErrorCode PetscObjectTypeCompare(PetscObject obj, const char type_name[], PetscBool *same);
-int MPI_Allreduce(const void *sendbuf, void *recvbuf, int count, MPI_Datatype t, MPI_Op op, MPI_Comm comm);
-int MPI_Comm_rank(MPI_Comm comm, int *rank);
-int MPI_Comm_size(MPI_Comm comm, int *size);
-int MPI_Barrier(MPI_Comm comm);
-double MPI_Wtime(void);
 PetscErrorCode PetscViewerBinaryOpen(MPI_Comm comm, const char name[], PetscFileMode mode, PetscViewer *v);
+PetscErrorCode PetscViewerCreate(MPI_Comm comm, PetscViewer *v);
+PetscErrorCode PetscViewerSetType(PetscViewer v, PetscViewerType type);
+PetscErrorCode PetscViewerFileSetMode(PetscViewer v, PetscFileMode mode);
+PetscErrorCode PetscViewerFileSetName(PetscViewer v, const char name[]);
+PetscErrorCode PetscViewerASCIIPrintf(PetscViewer v, const char format[], ...);
 PetscErrorCode PetscViewerDestroy(PetscViewer *v);
 PetscErrorCode PetscRandomCreate(MPI_Comm comm, PetscRandom *r);
 PetscErrorCode PetscRandomSetType(PetscRandom r, PetscRandomType type);
@@ -212,6 +206,9 @@ PetscErrorCode VecGetSize(Vec x, PetscInt *n);
 PetscErrorCode VecGetLocalSize(Vec x, PetscInt *n);
 PetscErrorCode VecGetArray(Vec x, PetscScalar **a);
 PetscErrorCode VecRestoreArray(Vec x, PetscScalar **a);
+PetscErrorCode VecGetArrays(const Vec x[], PetscInt n, PetscScalar **a[]);
+PetscErrorCode VecRestoreArrays(const Vec x[], PetscInt n, PetscScalar **a[]);
+PetscErrorCode VecAXPBYPCZ(Vec z, PetscScalar alpha, PetscScalar beta, PetscScalar gamma, Vec x, Vec y);
 PetscErrorCode VecSetValueLocal(Vec v, PetscInt row, PetscScalar value, InsertMode mode);
 PetscErrorCode VecSetValue(Vec v, PetscInt row, PetscScalar value, InsertMode mode);
 PetscErrorCode VecAssemblyBegin(Vec v);

@@ -1,0 +1,2 @@
+/* petscdm.h (compat): everything lives in petsc.h */
+#include <petsc.h>

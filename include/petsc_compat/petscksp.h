@@ -1,0 +1,2 @@
+/* petscksp.h (compat): everything lives in petsc.h */
+#include <petsc.h>

@@ -1,0 +1,2 @@
+/* petscmat.h (compat): everything lives in petsc.h */
+#include <petsc.h>

@@ -1,0 +1,2 @@
+/* petscsys.h (compat): everything lives in petsc.h */
+#include <petsc.h>

@@ -1,0 +1,2 @@
+/* petscvec.h (compat): everything lives in petsc.h */
+#include <petsc.h>

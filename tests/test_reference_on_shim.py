@@ -2,8 +2,8 @@
 
 CPU part (build container, where /root/reference exists): the reference's LinearElasticity.cc, Filter.cc and
 PDEFilter.cc compile UNCHANGED against the compat headers and link against libtopopt_petsc_shim.so
-(host/build_ref_on_shim.sh; nothing of the reference is stored in the repository, the binary is a git-ignored
-build artefact).  GPU part: that binary -- the reference's own classes on the MI355X path -- against the product's
+(host/build_ref_on_shim.sh; nothing of the reference is stored in the repository, the binaries are git-ignored
+build artefacts) -- and so do main.cc, TopOpt.cc, MMA.cc and MPIIO.cc: the reference's WHOLE program.  GPU part: that binary -- the reference's own classes on the MI355X path -- against the product's
 Python API on the same mesh, and its refusal to run the reference's hard-coded FGMRES/GMRES/SOR configuration."""
 import os
 import re
@@ -22,7 +22,7 @@ OPTS = ("-ksp_type cg -mg_levels_ksp_type chebyshev -mg_levels_pc_type jacobi "
 def test_reference_sources_compile_and_link_against_the_shim():
     r = subprocess.run(["bash", os.path.join(ROOT, "host", "build_ref_on_shim.sh")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert os.path.exists(BIN)
+    assert os.path.exists(BIN) and os.path.exists(os.path.join(ROOT, "host", "_refbuild", "topopt_ref"))
     # every PETSc symbol the three objects need is exported by the shim (the link above would have failed otherwise);
     # and the shim's header declares nothing it does not define
     src = open(os.path.join(ROOT, "include", "petsc_compat", "petsc.h")).read()
@@ -89,3 +89,39 @@ def test_reference_default_solver_is_refused_not_substituted():
     r = _run([16, 8, 8, 1, "-nlvls", "3"], env={"PETSC_OPTIONS": " ".join(OPTS)})
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     assert np.isfinite(_numbers(r.stdout)).all()
+
+
+TOPOPT_REF = os.path.join(ROOT, "host", "_refbuild", "topopt_ref")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(TOPOPT_REF), reason="host/_refbuild/topopt_ref not built (build container only)")
+def test_whole_reference_program_unchanged_on_the_gpu_path(tmp_path):
+    """ALL eight sources of the reference (main.cc, TopOpt.cc, MMA.cc, MPIIO.cc, LinearElasticity.cc, Filter.cc,
+    PDEFilter.cc), compiled unchanged against include/petsc_compat and linked against the shim, run the
+    optimisation loop on the MI355X path; the product's own driver (device MMA) produces the same history.
+    The reference prints 6 decimals: that is the comparison."""
+    import topopt_in_petsc_amd as tp
+    nit = 6
+    r = subprocess.run([TOPOPT_REF, "-nx", "65", "-ny", "33", "-nz", "33", "-maxItr", str(nit)] + OPTS, capture_output=True,
+                       text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    ref = [[float(v) for v in m] for m in re.findall(
+        r"It\.: \d+, True fx: (\S+), Scaled fx: (\S+), gx\[0\]: (\S+), ch\.: (\S+), mnd\.: (\S+),", r.stdout)]
+    its = [int(v) for v in re.findall(r"State solver:\s+iter: (\d+)", r.stdout)]
+    assert len(ref) == nit and len(its) == nit
+    ex, ey, ez, nlv = 64, 32, 32, 4
+    h = 1.0 / ey
+    opt = tp.TopOpt(nxyz=(ex + 1, ey + 1, ez + 1), xc=(0, ex * h, 0, 1, 0, ez * h), nlvls=nlv, rmin=2.56 * h, filter=1,
+                    solver=tp.SolverOptions(nlvls=nlv))
+    for it in range(nit):
+        rec = opt.step()
+        fx, sfx, gx, ch, mnd = ref[it]
+        assert rec["ksp_its"] == its[it]
+        assert fx == pytest.approx(rec["fx"], rel=2e-6, abs=2e-6)
+        assert gx == pytest.approx(rec["gx"], abs=2e-6)
+        assert ch == pytest.approx(rec["ch"], abs=2e-6)
+        assert mnd == pytest.approx(rec["mnd"], abs=2e-6)
+    # the result container the reference's MPIIO wrote through the compat MPI-IO has the documented layout
+    out = os.path.join(str(tmp_path), "output_00000.dat")
+    assert os.path.exists(out) and open(out, "rb").read(26) == b"TopOpt result version 1.1\n"
