@@ -206,6 +206,41 @@ extern "C" int tp_rccl_selftest(int device, void *stream, long n, double *max_er
         for (int i = 0; i < 16; i++) err = fmax(err, fabs(r16[i] - (3.0 + i)));
         for (long i = 0; i < n; i++) err = fmax(err, fabs(a[i] - (11000.0 + i)));
     }
+    // The overlapped-halo pattern (grid.h: halo_nodes_begin): in-place exchanges issued on a SECOND stream, ordered
+    // by events against fills on the first one, interleaved with all-reduces on the first stream -- several rounds,
+    // the way a smoother chain issues them.
+    if (!rc) {
+        hipStream_t cs = nullptr;
+        hipEvent_t ready = nullptr, done = nullptr;
+        if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ready, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess)
+            rc = TP_ERR_HIP;
+        for (int round = 0; round < 4 && !rc; round++) {
+            TP_LAUNCH(k_selftest_fill, dim3(64), dim3(256), 0, st, h.recv_lo, n, 100.0 * round + 1.0);  // "to_lo" plane
+            TP_LAUNCH(k_selftest_fill, dim3(64), dim3(256), 0, st, h.recv_hi, n, 100.0 * round + 2.0);  // "to_hi" plane
+            (void)hipEventRecord(ready, st);
+            (void)hipStreamWaitEvent(cs, ready, 0);
+            h.set_stream(h.user, cs);
+            rc = h.exchange_direct(h.user, h.recv_lo, h.send_lo, h.recv_hi, h.send_hi, n);  // from_lo <- to_hi, from_hi <- to_lo
+            h.set_stream(h.user, nullptr);
+            (void)hipEventRecord(done, cs);
+            TP_LAUNCH(k_selftest_fill, dim3(1), dim3(64), 0, st, h.red, 8, 5.0);   // "interior" work + a reduction meanwhile
+            if (!rc) rc = h.allreduce_inplace(h.user, h.red, 8);
+            (void)hipStreamWaitEvent(st, done, 0);
+            (void)hipMemcpyAsync(a.data(), h.send_lo, sizeof(double) * n, hipMemcpyDeviceToHost, st);
+            (void)hipMemcpyAsync(b.data(), h.send_hi, sizeof(double) * n, hipMemcpyDeviceToHost, st);
+            if (hipStreamSynchronize(st) != hipSuccess) rc = TP_ERR_HIP;
+            for (long i = 0; i < n && !rc; i++)
+                err = fmax(err, fmax(fabs(a[i] - (100.0 * round + 2.0 + i)), fabs(b[i] - (100.0 * round + 1.0 + i))));
+        }
+        if (cs) {
+            (void)hipStreamSynchronize(cs);
+            (void)hipStreamDestroy(cs);
+        }
+        if (ready) (void)hipEventDestroy(ready);
+        if (done) (void)hipEventDestroy(done);
+    }
     rccl_comm_destroy(c);
     *max_err = err;
     return rc ? TP_ERR_COMM : TP_OK;
