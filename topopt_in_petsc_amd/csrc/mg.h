@@ -607,27 +607,27 @@ struct MGSolver {
 
     // Chebyshev(k)-Jacobi; the iterate ping-pongs between L.x and L.x2, on exit L.x holds it
     // dot_slot >= 0: the LAST step also leaves b . x in scal[dot_slot] (this rank's part; fine tile kernel only)
-    int smooth(int l, const double *b, int k, bool zero_guess, int dot_slot = -1) {
+    int smooth(int l, const double *b, int k, bool zero_guess, int dot_slot = -1, bool first_done = false) {
         if (replicate && l == nlv - 1) {
             // coarsest level replicated on every rank: one all-gather of the right-hand side instead of a
             // halo exchange per Chebyshev step; the result comes back with its ghost planes filled
             Level<DOF> &R = lv[nlv];
             TP_TRY(gather_owned(lv[l], b, R, R.b, 1));
-            TP_TRY(smooth(nlv, R.b, k, zero_guess));
+            TP_TRY(smooth(nlv, R.b, k, zero_guess));  // (first_done never holds here: vcycle does not fuse on this path)
             Level<DOF> &L = lv[l];
             TP_HIP(hipMemcpyAsync(L.x, R.x + (long)DOF * L.g.plane() * L.g.gz0, sizeof(double) * (size_t)L.ndof(),
                                   hipMemcpyDeviceToDevice, grid->stream));
             return TP_OK;
         }
         Level<DOF> &L = lv[l];
-        // the coarsest level is a SOLVE (the reference runs a Krylov method there,
-        // LinearElasticity.cc:720-731): its window spans the whole spectrum
-        const bool coarsest = (l == nlv - 1 && l > 0) || l == nlv;
-        const double lmin = coarsest ? L.lam_min : opt.cheb_lo * L.lam, lmax = opt.cheb_hi * L.lam;
-        const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+        double theta, delta;
+        cheb_window(l, &theta, &delta);
+        const double sigma = theta / delta;
         double rho = 1.0 / sigma;
         int it = 0;
-        if (zero_guess) {
+        if (zero_guess && first_done) {
+            it = 1;  // x = dinv b / theta is already there (written by the restriction that produced b)
+        } else if (zero_guess) {
             TP_LAUNCH(k_cheb_first, dim3(grid_for(L.own_n())), dim3(BLK), 0, grid->stream, L.x,
                                three_term(L) ? nullptr : L.d, b, L.dinv, 1.0 / theta, L.own_off(), L.own_n());
             count_launch(grid, 32.0 * L.own_n(), 2.0 * L.own_n());
@@ -662,6 +662,15 @@ struct MGSolver {
             std::swap(L.x, L.x2);
         }
         return TP_OK;
+    }
+    // Chebyshev window of level l.  The coarsest level is a SOLVE (the reference runs a Krylov method there,
+    // LinearElasticity.cc:720-731): its window spans the whole spectrum
+    void cheb_window(int l, double *theta, double *delta) const {
+        const Level<DOF> &L = lv[l];
+        const bool coarsest = (l == nlv - 1 && l > 0) || l == nlv;
+        const double lmin = coarsest ? L.lam_min : opt.cheb_lo * L.lam, lmax = opt.cheb_hi * L.lam;
+        *theta = 0.5 * (lmax + lmin);
+        *delta = 0.5 * (lmax - lmin);
     }
     // can the last post-smoothing step of a V-cycle return r . z ?  (fine tile kernel, at least one fused step)
     bool can_fuse_rz() const {
@@ -707,10 +716,10 @@ struct MGSolver {
     }
 
     // PCMG multiplicative V-cycle with zero initial guesses; result in lv[l].x
-    int vcycle(int l, const double *b, int dot_slot = -1) {
+    int vcycle(int l, const double *b, int dot_slot = -1, bool first_done = false) {
         Level<DOF> &L = lv[l];
-        if (l == nlv - 1) return smooth(l, b, opt.ncoarse, true);
-        TP_TRY(smooth(l, b, opt.nsmooth, true));
+        if (l == nlv - 1) return smooth(l, b, opt.ncoarse, true, -1, first_done);
+        TP_TRY(smooth(l, b, opt.nsmooth, true, -1, first_done));
         {
             NodeArgs a{};
             a.x = L.x;
@@ -721,10 +730,18 @@ struct MGSolver {
         }
         Level<DOF> &C = lv[l + 1];
         TP_TRY(halo(l, L.r));
+        // the restriction also takes the coarse level's first Chebyshev step from the zero guess (one launch less per
+        // level and V-cycle); not when the coarse level is the replicated copy, whose right-hand side is gathered first
+        static const bool no_fuse_first = getenv("TP_NO_FUSE_FIRST") != nullptr;
+        const bool fuse_first = !no_fuse_first && !(replicate && l + 1 == nlv - 1) &&
+                                (l + 1 == nlv - 1 ? opt.ncoarse : opt.nsmooth) >= 1;
+        double th = 1.0, de = 1.0;
+        if (fuse_first) cheb_window(l + 1, &th, &de);
         TP_LAUNCH((k_restrict<DOF>), dim3((int)((C.g.owned_nodes() + BLK - 1) / BLK)), dim3(BLK), 0,
-                           grid->stream, C.g, L.g, L.r, C.b);
+                           grid->stream, C.g, L.g, L.r, C.b, fuse_first ? C.dinv : nullptr, fuse_first ? C.x : nullptr,
+                           fuse_first && !three_term(C) ? C.d : nullptr, 1.0 / th);
         count_launch(grid, 8.0 * DOF * (L.g.owned_nodes() + C.g.owned_nodes()), 2.0 * 27 * DOF * C.g.owned_nodes());
-        TP_TRY(vcycle(l + 1, C.b));
+        TP_TRY(vcycle(l + 1, C.b, -1, fuse_first));
         if (!(replicate && l + 1 == nlv - 1)) TP_TRY(halo(l + 1, C.x));  // the replicated solve returns its ghosts
         TP_LAUNCH((k_prolong_add<DOF>), dim3((int)((L.g.owned_nodes() + BLK - 1) / BLK)), dim3(BLK), 0,
                            grid->stream, C.g, L.g, C.x, L.x);

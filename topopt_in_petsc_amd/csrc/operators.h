@@ -200,9 +200,13 @@ __global__ __launch_bounds__(BLK) void k_matfree_diag(MatfreeOp<DOF> op, double 
 // (DMCreateInterpolation on a DMDA, LinearElasticity.cc:704); restriction = P^T.
 // ---------------------------------------------------------------------------
 // coarse b_c[I] = sum over the 27 fine neighbours of 2I of w * r_f ; owned coarse nodes
+// first != NULL: also the first Chebyshev step of the coarse level from a zero guess (k_cheb_first fused in):
+// x_c = dinv_c * b_c * inv_theta (and d_c = x_c where the level keeps a direction vector)
 template <int DOF>
 __global__ __launch_bounds__(BLK) void k_restrict(Geom gc, Geom gf, const double *__restrict__ rf,
-                                                  double *__restrict__ bc) {
+                                                  double *__restrict__ bc, const double *__restrict__ dinv_c = nullptr,
+                                                  double *__restrict__ x_c = nullptr, double *__restrict__ d_c = nullptr,
+                                                  double inv_theta = 0.0) {
     const long plane = gc.plane();
     const long t = blockIdx.x * (long)BLK + threadIdx.x;
     if (t >= gc.owned_nodes()) return;
@@ -233,7 +237,14 @@ __global__ __launch_bounds__(BLK) void k_restrict(Geom gc, Geom gf, const double
         }
     }
 #pragma unroll
-    for (int r = 0; r < DOF; r++) bc[nc * DOF + r] = s[r];
+    for (int r = 0; r < DOF; r++) {
+        bc[nc * DOF + r] = s[r];
+        if (x_c) {
+            const double v = dinv_c[nc * DOF + r] * s[r] * inv_theta;
+            x_c[nc * DOF + r] = v;
+            if (d_c) d_c[nc * DOF + r] = v;
+        }
+    }
 }
 
 // fine x_f += P x_c ; owned fine nodes
