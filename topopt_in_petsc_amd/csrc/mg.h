@@ -587,6 +587,27 @@ struct MGSolver {
         for (int l = 0; l <= nlv; l++) TP_TRY(drain_halo(l));
         return TP_OK;
     }
+    // A kernel that writes whole owned planes of `out` one node at a time (vector updates, grid transfers), issued so
+    // that the ghost planes of `out` travel while its interior is computed: launch(p0, np) covers the owned planes
+    // [p0, p0 + np).  Tile levels of a slab run with the overlap available: boundary plane(s) first, exchange started
+    // on the second stream, then the interior; everywhere else one launch over all owned planes (the consumer's
+    // halo() exchanges).
+    template <class F>
+    int planes_split(int l, double *out, F launch) {
+        Level<DOF> &L = lv[l];
+        const int lo = L.g.own_lo, hi = L.g.own_hi;
+        const int n_bnd = (L.g.has_lo ? 1 : 0) + (L.g.has_hi ? 1 : 0);
+        const bool tile_level = DOF == 3 && ((L.kind == LV_MATFREE && L.use_tile) || L.kind == LV_MACRO);
+        if (pend[l].ptr) TP_TRY(drain_halo(l));
+        if (!(tile_level && !L.no_comm && n_bnd > 0 && halo_can_overlap(grid) && hi - lo + 1 > n_bnd)) return launch(lo, hi - lo + 1);
+        if (L.g.has_lo) TP_TRY(launch(lo, 1));
+        if (L.g.has_hi) TP_TRY(launch(hi, 1));
+        if (!pend_ev[l]) TP_HIP(hipEventCreateWithFlags(&pend_ev[l], hipEventDisableTiming));
+        const int rc = halo_nodes_begin(grid, L.g, out, DOF, pend_ev[l]);
+        if (rc == TP_OK) pend[l].ptr = out;
+        else if (rc != 2) return rc;
+        return launch(lo + (L.g.has_lo ? 1 : 0), hi - lo + 1 - n_bnd);
+    }
     // Fine tile kernel: Chebyshev in its 3-term form  u+ = u + c1 (u - u-) + c2 D^-1 (b - A u); u- sits in the output
     // buffer (read and overwritten by the same thread), so no direction vector is streamed.
     static bool three_term(const Level<DOF> &L) { return DOF == 3 && L.kind == LV_MATFREE && L.use_tile; }
@@ -628,8 +649,12 @@ struct MGSolver {
         if (zero_guess && first_done) {
             it = 1;  // x = dinv b / theta is already there (written by the restriction that produced b)
         } else if (zero_guess) {
-            TP_LAUNCH(k_cheb_first, dim3(grid_for(L.own_n())), dim3(BLK), 0, grid->stream, L.x,
-                               three_term(L) ? nullptr : L.d, b, L.dinv, 1.0 / theta, L.own_off(), L.own_n());
+            const long pl = (long)DOF * L.g.plane();
+            TP_TRY(planes_split(l, L.x, [&](int p0, int np) -> int {
+                TP_LAUNCH(k_cheb_first, dim3(grid_for(pl * np)), dim3(BLK), 0, grid->stream, L.x,
+                          three_term(L) ? nullptr : L.d, b, L.dinv, 1.0 / theta, pl * p0, pl * np);
+                return TP_OK;
+            }));
             count_launch(grid, 32.0 * L.own_n(), 2.0 * L.own_n());
             it = 1;
         }
@@ -737,14 +762,24 @@ struct MGSolver {
                                 (l + 1 == nlv - 1 ? opt.ncoarse : opt.nsmooth) >= 1;
         double th = 1.0, de = 1.0;
         if (fuse_first) cheb_window(l + 1, &th, &de);
-        TP_LAUNCH((k_restrict<DOF>), dim3((int)((C.g.owned_nodes() + BLK - 1) / BLK)), dim3(BLK), 0,
-                           grid->stream, C.g, L.g, L.r, C.b, fuse_first ? C.dinv : nullptr, fuse_first ? C.x : nullptr,
-                           fuse_first && !three_term(C) ? C.d : nullptr, 1.0 / th);
+        auto restrict_planes = [&](int p0, int np) -> int {
+            const long cpl = C.g.plane();
+            TP_LAUNCH((k_restrict<DOF>), dim3((int)((cpl * np + BLK - 1) / BLK)), dim3(BLK), 0, grid->stream, C.g, L.g, L.r, C.b,
+                      fuse_first ? C.dinv : nullptr, fuse_first ? C.x : nullptr, fuse_first && !three_term(C) ? C.d : nullptr,
+                      1.0 / th, cpl * (p0 - C.g.own_lo), cpl * np);
+            return TP_OK;
+        };
+        if (fuse_first) TP_TRY(planes_split(l + 1, C.x, restrict_planes));  // the coarse level's first iterate is read with ghosts next
+        else TP_TRY(restrict_planes(C.g.own_lo, C.g.own_hi - C.g.own_lo + 1));
         count_launch(grid, 8.0 * DOF * (L.g.owned_nodes() + C.g.owned_nodes()), 2.0 * 27 * DOF * C.g.owned_nodes());
         TP_TRY(vcycle(l + 1, C.b, -1, fuse_first));
         if (!(replicate && l + 1 == nlv - 1)) TP_TRY(halo(l + 1, C.x));  // the replicated solve returns its ghosts
-        TP_LAUNCH((k_prolong_add<DOF>), dim3((int)((L.g.owned_nodes() + BLK - 1) / BLK)), dim3(BLK), 0,
-                           grid->stream, C.g, L.g, C.x, L.x);
+        TP_TRY(planes_split(l, L.x, [&](int p0, int np) -> int {
+            const long fpl = L.g.plane();
+            TP_LAUNCH((k_prolong_add<DOF>), dim3((int)((fpl * np + BLK - 1) / BLK)), dim3(BLK), 0, grid->stream, C.g, L.g, C.x,
+                      L.x, fpl * (p0 - L.g.own_lo), fpl * np);
+            return TP_OK;
+        }));
         count_launch(grid, 8.0 * DOF * (2 * L.g.owned_nodes() + C.g.owned_nodes()), 2.0 * 8 * DOF * L.g.owned_nodes());
         return smooth(l, b, opt.nsmooth, false, l == 0 ? dot_slot : -1);
     }
@@ -955,8 +990,14 @@ struct MGSolver {
                     TP_TRY(precond(r, &z));
                     TP_TRY(dot_to_slot(grid, r + off, z + off, n, rz_cur));
                 }
-                TP_LAUNCH(k_cg_update_p, dim3(grid_for(n)), dim3(BLK), 0, s, p, z, grid->scal, rz_cur, rz_old,
-                                   its == 1 ? 1 : 0, off, n);
+                {
+                    const long pl = (long)DOF * L.g.plane();
+                    TP_TRY(planes_split(0, p, [&](int p0, int np) -> int {
+                        TP_LAUNCH(k_cg_update_p, dim3(grid_for(pl * np)), dim3(BLK), 0, s, p, z, grid->scal, rz_cur, rz_old,
+                                  its == 1 ? 1 : 0, pl * p0, pl * np);
+                        return TP_OK;
+                    }));
+                }
                 count_launch(grid, 24.0 * n, 2.0 * n);
                 {
                     NodeArgs a{};

@@ -206,10 +206,11 @@ template <int DOF>
 __global__ __launch_bounds__(BLK) void k_restrict(Geom gc, Geom gf, const double *__restrict__ rf,
                                                   double *__restrict__ bc, const double *__restrict__ dinv_c = nullptr,
                                                   double *__restrict__ x_c = nullptr, double *__restrict__ d_c = nullptr,
-                                                  double inv_theta = 0.0) {
+                                                  double inv_theta = 0.0, long t0 = 0, long tn = -1) {
+    // owned coarse nodes [t0, t0 + tn) counted from the first owned plane (tn < 0: all)
     const long plane = gc.plane();
-    const long t = blockIdx.x * (long)BLK + threadIdx.x;
-    if (t >= gc.owned_nodes()) return;
+    const long t = t0 + blockIdx.x * (long)BLK + threadIdx.x;
+    if (t >= (tn < 0 ? gc.owned_nodes() : t0 + tn)) return;
     const int K = gc.own_lo + (int)(t / plane);
     const int rem = (int)(t % plane);
     const int J = rem / gc.nx, I = rem % gc.nx;
@@ -250,10 +251,11 @@ __global__ __launch_bounds__(BLK) void k_restrict(Geom gc, Geom gf, const double
 // fine x_f += P x_c ; owned fine nodes
 template <int DOF>
 __global__ __launch_bounds__(BLK) void k_prolong_add(Geom gc, Geom gf, const double *__restrict__ xc,
-                                                     double *__restrict__ xf) {
+                                                     double *__restrict__ xf, long t0 = 0, long tn = -1) {
+    // owned fine nodes [t0, t0 + tn) counted from the first owned plane (tn < 0: all)
     const long plane = gf.plane();
-    const long t = blockIdx.x * (long)BLK + threadIdx.x;
-    if (t >= gf.owned_nodes()) return;
+    const long t = t0 + blockIdx.x * (long)BLK + threadIdx.x;
+    if (t >= (tn < 0 ? gf.owned_nodes() : t0 + tn)) return;
     const int k = gf.own_lo + (int)(t / plane);
     const int rem = (int)(t % plane);
     const int j = rem / gf.nx, i = rem % gf.nx;
