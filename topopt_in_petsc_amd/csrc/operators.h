@@ -280,6 +280,16 @@ __global__ __launch_bounds__(BLK) void k_prolong_add(Geom gc, Geom gf, const dou
 // ---------------------------------------------------------------------------
 // Stencil levels, one thread per matrix ROW (node x dof): the coarse grids are
 // small (17^3 .. 65^3 nodes), so the finer decomposition is what fills the chip.
+// ---------------------------------------------------------------------------
+// Chebyshev direction update of the stored-stencil kernels, d+ = c1 d + c2 dinv (b - y), in ONE spelled-out operation
+// order: the compiler's own contraction of `c1 * d + c2 * t` differs from kernel to kernel, and the row kernels
+// below (one or the other is picked by the size of the level) must agree bit for bit
+__device__ inline double cheb_dn(double c1, double d, double c2, double dinv, double b, double y) {
+#pragma clang fp contract(off)
+    const double t = c2 * (dinv * (b - y));
+    return fma(c1, d, t);
+}
+
 template <int DOF, int EPI>
 __global__ __launch_bounds__(BLK) void k_dia_row(DiaOp<DOF> op, NodeArgs a) {
     const Geom &g = op.g;
@@ -317,7 +327,7 @@ __global__ __launch_bounds__(BLK) void k_dia_row(DiaOp<DOF> op, NodeArgs a) {
         } else if (EPI == EPI_RESID) {
             a.out[q] = a.b[q] - y;
         } else if (EPI == EPI_CHEB) {
-            const double dn = a.c1 * a.d[q] + a.c2 * (a.dinv[q] * (a.b[q] - y));
+            const double dn = cheb_dn(a.c1, a.d[q], a.c2, a.dinv[q], a.b[q], y);
             a.d[q] = dn;
             a.out[q] = u[q] + dn;
         } else {
@@ -352,6 +362,14 @@ __global__ __launch_bounds__(BLK) void k_dia_row_split(DiaOp<DOF> op, NodeArgs a
     const bool valid = part < SPLIT && t < g.owned_nodes() * DOF;
     const long q = t + plane * g.own_lo * DOF;  // row
     const double *__restrict__ u = a.x;
+    // epilogue operands of the row: requested BEFORE the stencil loads, not after the barrier (these kernels run at
+    // the latency floor on the coarse levels: one memory round trip instead of two)
+    double e_b = 0.0, e_d = 0.0, e_di = 0.0, e_u = 0.0;
+    if (valid && part == 0) {
+        if (EPI == EPI_RESID || EPI == EPI_CHEB) e_b = a.b[q];
+        if (EPI == EPI_CHEB) e_d = a.d[q], e_di = a.dinv[q];
+        if (EPI == EPI_CHEB || EPI == EPI_APPLY_DOT) e_u = u[q];
+    }
     if (valid) {
         const long n = q / DOF;
         const int k = (int)(n / plane);
@@ -390,14 +408,14 @@ __global__ __launch_bounds__(BLK) void k_dia_row_split(DiaOp<DOF> op, NodeArgs a
         if (EPI == EPI_APPLY) {
             a.out[q] = y;
         } else if (EPI == EPI_RESID) {
-            a.out[q] = a.b[q] - y;
+            a.out[q] = e_b - y;
         } else if (EPI == EPI_CHEB) {
-            const double dn = a.c1 * a.d[q] + a.c2 * (a.dinv[q] * (a.b[q] - y));
+            const double dn = cheb_dn(a.c1, e_d, a.c2, e_di, e_b, y);
             a.d[q] = dn;
-            a.out[q] = u[q] + dn;
+            a.out[q] = e_u + dn;
         } else {
             a.out[q] = y;
-            pdot = u[q] * y;
+            pdot = e_u * y;
         }
     }
     if (EPI == EPI_APPLY_DOT) {
