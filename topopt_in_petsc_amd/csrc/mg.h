@@ -274,7 +274,8 @@ inline int fine_kz(int planes, int tiles, int fine_v) {
     kz = kz < 8 ? 8 : (kz > 32 ? 32 : kz);
     // small grids: shorter chunks until the workgroup slots of the chip are filled once
     if ((long)tiles * ((planes + 7) / 8) < SLOTS) kz = (int)((long)planes * tiles / SLOTS);
-    if (kz < 4) kz = 4;
+    const int kmin = (long)tiles * ((planes + 3) / 4) < 256 ? 2 : 4;  // 64x32x32 elements: kz 2 beats 4 by 5 % of the step
+    if (kz < kmin) kz = kmin;
     return kz > planes ? planes : kz;
 }
 
@@ -497,7 +498,13 @@ struct MGSolver {
             const int planes = L.g.own_hi - L.g.own_lo + 1;
             static const int kz_env = getenv("TP_MACRO_KZ") ? atoi(getenv("TP_MACRO_KZ")) : 0;
             int kz = kz_env > 0 ? kz_env : (int)((long)planes * tx * ty / 768);
-            if (kz_env <= 0) kz = kz < 4 ? 4 : (kz > 64 ? 64 : kz);
+            if (kz_env <= 0) {
+                // small levels: chunks short enough for about one workgroup per CU (64^3..192x64x64 elements: kz 1-2
+                // instead of 4 is 3-9 % of the whole design iteration), never longer than 4 below one round of slots
+                int kmin = (int)(((long)planes * tx * ty + 128) / 256);
+                kmin = kmin < 1 ? 1 : (kmin > 4 ? 4 : kmin);
+                kz = kz < kmin ? kmin : (kz > 64 ? 64 : kz);
+            }
             if (kz > planes) kz = planes;
             // Dirichlet correction of the level-1 operator.  One launch computes tiles AND element-row products
             // (extra workgroups behind the tiles), a second one adds the gathered products to the result.  Slab runs keep
