@@ -121,7 +121,11 @@ __device__ inline double block_sum(double v) {
 // dirty L2 once per workgroup -- measured +40 % on the design iteration when every block of the CG update did it.
 // Arrivals are counted on 8 shard counters (workgroup b -> shard b & 7, i.e. its XCD under round-robin dispatch) and
 // the last arriver of a shard on a top counter: same-address atomics serialise at ~12 ns each, which a single counter
-// turns into 100 us for an 8192-workgroup grid.  `ticket[0..8]` are left at 0.
+// turns into 100 us for an 8192-workgroup grid -- and so do counters that share a cache line (one atomic unit serves
+// the line: 8 adjacent words measured like one, 28 us for a 2048-workgroup dot product), hence TICKET_STRIDE.
+// The counters are left at 0.
+constexpr int TICKET_STRIDE = 1024;              // unsigned words between two counters (4 KB: another channel)
+constexpr int TICKET_WORDS = 9 * TICKET_STRIDE;  // allocation: 8 shards + top
 template <int NV>
 __device__ inline void reduce_tail(const double (&mine)[NV], double *__restrict__ partials, int nb, int b,
                                    unsigned *ticket, double *__restrict__ out) {
@@ -134,10 +138,11 @@ __device__ inline void reduce_tail(const double (&mine)[NV], double *__restrict_
         const int sh = b & 7;
         const unsigned in_shard = (unsigned)((nb + 7 - sh) >> 3);  // workgroups b' < nb with b' & 7 == sh
         int last = 0;
-        if (__hip_atomic_fetch_add(ticket + sh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1) {
-            __hip_atomic_store(ticket + sh, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned *mine_t = ticket + sh * TICKET_STRIDE, *top_t = ticket + 8 * TICKET_STRIDE;
+        if (__hip_atomic_fetch_add(mine_t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1) {
+            __hip_atomic_store(mine_t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned shards = (unsigned)(nb < 8 ? nb : 8);
-            last = __hip_atomic_fetch_add(ticket + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards - 1;
+            last = __hip_atomic_fetch_add(top_t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards - 1;
         }
         s_last = last;
     }
@@ -146,12 +151,23 @@ __device__ inline void reduce_tail(const double (&mine)[NV], double *__restrict_
 #pragma unroll
     for (int v = 0; v < NV; v++) {
         double s = 0.0;
-        for (int i = threadIdx.x; i < nb; i += BLK)
-            s += __hip_atomic_load(&partials[(long)v * nb + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // eight loads in flight per thread, added in index order (the order of the plain loop): the loads go past
+        // the L2 to memory, one at a time they cost the last workgroup ~1.5 us each
+        for (int i0 = threadIdx.x; i0 < nb; i0 += 8 * BLK) {
+            double w[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int i = i0 + k * BLK;
+                w[k] = __hip_atomic_load(&partials[(long)v * nb + (i < nb ? i : i0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (i0 + k * BLK < nb) s += w[k];
+        }
         s = block_sum(s);
         if (threadIdx.x == 0) out[v] = s;
     }
-    if (threadIdx.x == 0) __hip_atomic_store(ticket + 8, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store(ticket + 8 * TICKET_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // partials laid out [value][block]; out[v] = sum_b partials[v*nblocks + b]

@@ -42,13 +42,13 @@ extern "C" int tp_grid_create(tp_grid **out, const tp_grid_opts *o) {
     if (nblk < MAX_RED_BLOCKS) nblk = MAX_RED_BLOCKS;
     if (hipMalloc((void **)&g->partials, sizeof(double) * 4 * (size_t)nblk) != hipSuccess ||
         hipMalloc((void **)&g->scal, sizeof(double) * 64) != hipSuccess ||
-        hipMalloc((void **)&g->ticket, sizeof(unsigned) * 16) != hipSuccess ||
+        hipMalloc((void **)&g->ticket, sizeof(unsigned) * TICKET_WORDS) != hipSuccess ||
         hipHostMalloc((void **)&g->h_scal, sizeof(double) * 64) != hipSuccess) {
         delete g;
         return TP_ERR_HIP + (int)hipErrorOutOfMemory;
     }
     (void)hipMemsetAsync(g->scal, 0, sizeof(double) * 64, g->stream);
-    (void)hipMemsetAsync(g->ticket, 0, sizeof(unsigned) * 16, g->stream);
+    (void)hipMemsetAsync(g->ticket, 0, sizeof(unsigned) * TICKET_WORDS, g->stream);
     double W[512];
     host_W(W);
     TP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_W), W, sizeof(W)));
