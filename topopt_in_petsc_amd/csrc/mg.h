@@ -154,14 +154,18 @@ __global__ void k_lanczos_alpha(const double *__restrict__ h1, const double *__r
                                 double *__restrict__ alpha) {
     if (threadIdx.x == 0 && blockIdx.x == 0) alpha[j] = h1[j] + h2[j];
 }
-// beta[j] = sqrt(bb[0]);  v_next = w / beta
+// beta[j] = sqrt(bb[0]);  v_next = w / beta;  t = dis .* v_next (the scaled input of the next operator application)
 __global__ __launch_bounds__(BLK) void k_lanczos_next(const double *__restrict__ w, const double *__restrict__ bb, int j,
                                                       double *__restrict__ beta, double *__restrict__ vnext, long off,
-                                                      long n) {
+                                                      long n, const double *__restrict__ dis, double *__restrict__ t) {
     const double bt = sqrt(bb[0]);
     if (blockIdx.x == 0 && threadIdx.x == 0) beta[j] = bt;
     const double inv = bt > 0.0 ? 1.0 / bt : 0.0;
-    for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) vnext[off + i] = w[off + i] * inv;
+    for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
+        const double v = w[off + i] * inv;
+        vnext[off + i] = v;
+        t[off + i] = dis[off + i] * v;
+    }
 }
 
 // largest eigenvalue of a symmetric tridiagonal matrix, Sturm bisection
@@ -857,12 +861,22 @@ struct MGSolver {
         TP_LAUNCH((k_lanczos_init<DOF>), dim3(gn), dim3(BLK), 0, s, L.g, V, dis, L.dinv);
         TP_TRY(multi_dot(V, 1, V, bb));
         TP_TRY(allreduce_dev(bb, 1, L.no_comm));
-        TP_LAUNCH(k_lanczos_next, dim3(grid_for(n)), dim3(BLK), 0, s, V, bb, 0, be, V, off, n);  // normalise v0
+        TP_LAUNCH(k_lanczos_next, dim3(grid_for(n)), dim3(BLK), 0, s, V, bb, 0, be, V, off, n, dis, t);  // normalise v0
+        // w = D^-1/2 A D^-1/2 v_j: the first scaling is written by k_lanczos_next together with v_j, the second one
+        // by the operator's epilogue where the level is a stored stencil (NodeArgs::dinv of EPI_APPLY)
+        const bool scaled_apply = L.kind == LV_DIA;
         for (int j = 0; j < steps; j++) {
-            double *vj = V + (size_t)j * nd;
-            TP_LAUNCH(k_pw_mult, dim3(grid_for(n)), dim3(BLK), 0, s, t + off, dis + off, vj + off, n);
-            TP_TRY(apply(l, t, w));
-            TP_LAUNCH(k_pw_mult, dim3(grid_for(n)), dim3(BLK), 0, s, w + off, dis + off, w + off, n);
+            if (scaled_apply) {
+                TP_TRY(halo(l, t));
+                NodeArgs a{};
+                a.x = t;
+                a.out = w;
+                a.dinv = dis;
+                TP_TRY(op<EPI_APPLY>(l, a));
+            } else {
+                TP_TRY(apply(l, t, w));
+                TP_LAUNCH(k_pw_mult, dim3(grid_for(n)), dim3(BLK), 0, s, w + off, dis + off, w + off, n);
+            }
             for (int pass = 0; pass < 2; pass++) {
                 double *h = pass ? h2 : h1;
                 TP_TRY(multi_dot(V, j + 1, w, h));
@@ -874,8 +888,8 @@ struct MGSolver {
             TP_TRY(multi_dot(w, 1, w, bb));
             TP_TRY(allreduce_dev(bb, 1, L.no_comm));
             TP_LAUNCH(k_lanczos_next, dim3(grid_for(n)), dim3(BLK), 0, s, w, bb, j, be, V + (size_t)(j + 1) * nd,
-                               off, n);
-            grid->launches += nb == 1 ? 9 : 12;
+                               off, n, dis, t);
+            grid->launches += (nb == 1 ? 8 : 11) - (scaled_apply ? 1 : 0);
         }
         B.m = steps;
         TP_HIP(hipMemcpyAsync(B.hc, coef, sizeof(double) * 520, hipMemcpyDeviceToHost, s));

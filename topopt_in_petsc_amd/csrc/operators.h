@@ -110,7 +110,7 @@ struct NodeArgs {
     double *out;         // APPLY: y | RESID: r | CHEB: x_out | APPLY_DOT: w
     const double *b;     // RESID, CHEB
     double *d;           // CHEB direction (in/out)
-    const double *dinv;  // CHEB Jacobi
+    const double *dinv;  // CHEB Jacobi | APPLY on stored-stencil levels: optional pointwise scale of y (Lanczos)
     double c1, c2;       // CHEB recurrence coefficients
     int prev_zero;       // CHEB, 3-term form: the previous iterate is the zero guess (not read)
     double *partials;    // APPLY_DOT / CHEB_DOT: per-block partials of x . (A x) / b . x_out
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(BLK) void k_dia_row(DiaOp<DOF> op, NodeArgs a) {
             }
         }
         if (EPI == EPI_APPLY) {
-            a.out[q] = y;
+            a.out[q] = a.dinv ? a.dinv[q] * y : y;
         } else if (EPI == EPI_RESID) {
             a.out[q] = a.b[q] - y;
         } else if (EPI == EPI_CHEB) {
@@ -368,6 +368,7 @@ __global__ __launch_bounds__(BLK) void k_dia_row_split(DiaOp<DOF> op, NodeArgs a
     if (valid && part == 0) {
         if (EPI == EPI_RESID || EPI == EPI_CHEB) e_b = a.b[q];
         if (EPI == EPI_CHEB) e_d = a.d[q], e_di = a.dinv[q];
+        if (EPI == EPI_APPLY && a.dinv) e_di = a.dinv[q];
         if (EPI == EPI_CHEB || EPI == EPI_APPLY_DOT) e_u = u[q];
     }
     if (valid) {
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(BLK) void k_dia_row_split(DiaOp<DOF> op, NodeArgs a
 #pragma unroll
         for (int p = 1; p < SPLIT; p++) y += s_part[p][r];
         if (EPI == EPI_APPLY) {
-            a.out[q] = y;
+            a.out[q] = a.dinv ? e_di * y : y;
         } else if (EPI == EPI_RESID) {
             a.out[q] = e_b - y;
         } else if (EPI == EPI_CHEB) {
