@@ -38,8 +38,8 @@ WORKLOADS = {
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=3)
-    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--workload", default="cantilever128", choices=sorted(WORKLOADS))
     p.add_argument("--rtol", type=float, default=1e-5)
     p.add_argument("--fine-eig", type=int, default=0, help="1: Lanczos estimate for the fine-level Chebyshev window")
