@@ -22,6 +22,7 @@ struct tp_grid {
     double *scal;       // [dev] 64 device scalars
     unsigned *ticket;   // [dev] arrival counter of the in-kernel reduction tails (common.h: reduce_tail), rests at 0
     double *h_scal;     // pinned host mirror
+    hipEvent_t ev_scal; // marks the read-back of read_scal_begin
     // accounting (algorithmic model)
     double alg_bytes, flops;
     long launches;
@@ -79,6 +80,20 @@ inline int reduce_partials(tp_grid *g, int nblocks, int slot) {
 inline int read_scal(tp_grid *g, int slot, int n, double *out) {
     TP_HIP(hipMemcpyAsync(g->h_scal, g->scal + slot, sizeof(double) * n, hipMemcpyDeviceToHost, g->stream));
     TP_HIP(hipStreamSynchronize(g->stream));
+    for (int i = 0; i < n; i++) out[i] = g->h_scal[i];
+    return TP_OK;
+}
+
+// the same in two halves: the copy is enqueued (and marked by an event) where the value is ready, more work may be
+// enqueued behind it, and the host waits for the event only -- not for what it put on the stream in between
+inline int read_scal_begin(tp_grid *g, int slot, int n) {
+    TP_HIP(hipMemcpyAsync(g->h_scal, g->scal + slot, sizeof(double) * n, hipMemcpyDeviceToHost, g->stream));
+    if (!g->ev_scal) TP_HIP(hipEventCreateWithFlags(&g->ev_scal, hipEventDisableTiming));
+    TP_HIP(hipEventRecord(g->ev_scal, g->stream));
+    return TP_OK;
+}
+inline int read_scal_end(tp_grid *g, int n, double *out) {
+    TP_HIP(hipEventSynchronize(g->ev_scal));
     for (int i = 0; i < n; i++) out[i] = g->h_scal[i];
     return TP_OK;
 }

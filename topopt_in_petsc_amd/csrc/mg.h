@@ -752,10 +752,23 @@ struct MGSolver {
     }
 
     // PCMG multiplicative V-cycle with zero initial guesses; result in lv[l].x
+    // the fine level's pre-smoothing of a V-cycle for the right-hand side `b`, enqueued AHEAD of the cycle: the Krylov
+    // loop issues it for the next iteration before it waits for this iteration's residual norm, so that the device
+    // has ~200 us of work while the host wakes up (vcycle(0, b) then starts behind it).  It writes multigrid scratch
+    // only; if the iteration turns out to be the last one, it was for nothing.
+    const double *head_for = nullptr;
+    int vcycle_head(const double *b) {
+        head_for = nullptr;
+        if (nlv < 2) return TP_OK;
+        TP_TRY(smooth(0, b, opt.nsmooth, true));
+        head_for = b;
+        return TP_OK;
+    }
     int vcycle(int l, const double *b, int dot_slot = -1, bool first_done = false) {
         Level<DOF> &L = lv[l];
         if (l == nlv - 1) return smooth(l, b, opt.ncoarse, true, -1, first_done);
-        TP_TRY(smooth(l, b, opt.nsmooth, true, -1, first_done));
+        if (l == 0 && head_for == b) head_for = nullptr;  // pre-smoothed already (vcycle_head)
+        else TP_TRY(smooth(l, b, opt.nsmooth, true, -1, first_done));
         {
             NodeArgs a{};
             a.x = L.x;
@@ -1001,6 +1014,8 @@ struct MGSolver {
         if (hist && hist_cap > 0) hist[0] = rnorm;
         int its = 0, rc = TP_OK;
         int rz_cur = S_RZ0, rz_old = S_RZ1;
+        static const bool spec_head = getenv("TP_NO_SPEC_HEAD") == nullptr;
+        head_for = nullptr;
         if (rnorm > ttol) {
             for (its = 1; its <= opt.max_it; its++) {
                 double *z;
@@ -1036,7 +1051,9 @@ struct MGSolver {
                 count_launch(grid, 48.0 * n, 6.0 * n);
                 TP_TRY(finish_reduction<1>(grid, S_RR));
                 double rr;
-                TP_TRY(read_scal(grid, S_RR, 1, &rr));
+                TP_TRY(read_scal_begin(grid, S_RR, 1));
+                if (spec_head && its < opt.max_it) TP_TRY(vcycle_head(r));  // next iteration's first kernels, then wait
+                TP_TRY(read_scal_end(grid, 1, &rr));
                 rnorm = sqrt(rr);
                 if (hist && its < hist_cap) hist[its] = rnorm;
                 if (rnorm <= ttol) break;
@@ -1048,6 +1065,7 @@ struct MGSolver {
                 std::swap(rz_cur, rz_old);
             }
         }
+        head_for = nullptr;
         TP_TRY(drain_halos());
         if (its_out) *its_out = its;
         if (rnorm_out) *rnorm_out = rnorm;

@@ -254,6 +254,7 @@ extern "C" int tp_grid_destroy(tp_grid *g) {
         (void)hipStreamDestroy(g->comm_stream);
     }
     if (g->ev_ready) (void)hipEventDestroy(g->ev_ready);
+    if (g->ev_scal) (void)hipEventDestroy(g->ev_scal);
     (void)hipFree(g->partials);
     (void)hipFree(g->scal);
     (void)hipFree(g->ticket);
