@@ -189,3 +189,35 @@ def test_petsc_option_string_numbers(tp, orc):
         else:
             assert 0 < lo < 0.1 * hi and "-mg_coarse_ksp_max_it 30" in opts
     assert "-pc_mg_galerkin both" in opts and "-ksp_norm_type unpreconditioned" in opts
+
+
+@pytest.mark.gpu
+def test_graphed_coarsest_smoothing_bits(tp):
+    """TP_SMOOTH_GRAPH=1: the 30 coarsest-level Chebyshev steps of a V-cycle replayed from a hipGraph (captured on a
+    stream of the library's own, replayed on the grid's stream, two role-alternating variants) -- same bits as the
+    direct launches, fewer launches."""
+    ex, ey, ez, nl = 64, 32, 32, 4
+    g = tp.Grid(ex + 1, ey + 1, ez + 1, 1.0 / ey)
+    le = tp.LinearElasticity(g, tp.SolverOptions(nlvls=nl))
+    le.SetUpLoadAndBC()
+    res = []
+    for graph in (False, True, False):
+        if graph:
+            os.environ["TP_SMOOTH_GRAPH"] = "1"
+        else:
+            os.environ.pop("TP_SMOOTH_GRAPH", None)
+        try:
+            runs = []
+            for seed in (1, 2):   # a second design: the Chebyshev windows change, the graphs are captured again
+                le.AssembleStiffnessMatrix(g.synth_density(seed), 1e-9, 1.0, 3.0)
+                le.pop_stats()
+                le.U.zero_()              # cold start: the same initial guess in every mode
+                le.KSPSolve()
+                runs.append((host(le.U), le.last_its, le.pop_stats()[2]))
+            res.append(runs)
+        finally:
+            os.environ.pop("TP_SMOOTH_GRAPH", None)
+    for k in range(2):
+        assert np.array_equal(res[0][k][0], res[1][k][0]) and np.array_equal(res[0][k][0], res[2][k][0])
+        assert res[0][k][1] == res[1][k][1] and res[0][k][1] > 4
+        assert res[1][k][2] < res[0][k][2], (res[1][k][2], res[0][k][2])
