@@ -2,10 +2,14 @@
 // construct -> initial filter -> { solve + sensitivities, scale, filter gradients, move limits, MMA,
 // change, filter, MND, print }.  Command line: -nx -ny -nz (node counts, TopOpt.cc:154-160), -nlvls,
 // -maxItr, -filter, -rmin, -volfrac, -penal.  Output/restart files are out of scope.
+// One process per GPU: `host/slabrun -n N ./host/topopt ...` starts the z-slab ranks (slab_comm.h: shared-memory
+// hooks, upgraded to the library's RCCL path where every rank has a GPU of its own).
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstring>
 
+#include "slab_comm.h"
 #include "topopt_host.h"
 
 static double opt_d(int argc, char **argv, const char *k, double d) {
@@ -25,14 +29,20 @@ int main(int argc, char **argv) {
     const bool projectionFilter = false;
     double beta = 0.1, eta = 0.0;
 
+    SlabComm sc;
+    if (slab_comm_init(&sc, std::max(4L * 3 * nx * ny, 1L << 16))) return 1;
+    const bool root = sc.rank == 0;
     tp_grid_opts go = {nx, ny, nz, (xc[1] - xc[0]) / (nx - 1), (xc[3] - xc[2]) / (ny - 1), (xc[5] - xc[4]) / (nz - 1),
-                       0, 1, 0, nullptr, nullptr};
+                       sc.rank, sc.nranks, sc.device, nullptr, sc.nranks > 1 ? &sc.hooks : nullptr};
     tp_grid *grid = nullptr;
     PetscErrorCode ierr = tp_grid_create(&grid, &go);
     CHKERRQ(ierr);
+    sc.grid = grid;
+    slab_comm_try_rccl(&sc, grid);
     const long nel = tp_grid_local_elems(grid);
-    printf("# nodes %d x %d x %d, %ld elements, %ld DOF, nlvls %d, filter %d, rmin %g\n", nx, ny, nz, nel,
-           3 * tp_grid_local_nodes(grid), nlvls, filterType, rmin);
+    if (root)
+        printf("# nodes %d x %d x %d, %ld elements and %ld DOF on rank 0 of %d, nlvls %d, filter %d, rmin %g\n", nx, ny, nz, nel,
+               3 * tp_grid_owned_nodes(grid), sc.nranks, nlvls, filterType, rmin);
 
     LinearElasticity *physics = new LinearElasticity(grid, nlvls, nu);
     CHKERRQ(physics->err);
@@ -69,9 +79,11 @@ int main(int argc, char **argv) {
         const double mnd = filter->GetMND(xPhys);
         tp_sync(grid);
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
-        printf("State solver:  iter: %i, rerr.: %e\n", physics->niter, physics->rerr);
-        printf("It.: %i, True fx: %f, Scaled fx: %f, gx[0]: %f, ch.: %f, mnd.: %f, time: %f\n", itr, fx / fscale, fx, gx[0],
-               ch, mnd, dt);
+        if (root) {
+            printf("State solver:  iter: %i, rerr.: %e\n", physics->niter, physics->rerr);
+            printf("It.: %i, True fx: %f, Scaled fx: %f, gx[0]: %f, ch.: %f, mnd.: %f, time: %f\n", itr, fx / fscale, fx,
+                   gx[0], ch, mnd, dt);
+        }
     }
     // a host-side look at the design through the Vec mirror (what MPIIO would dump)
     double *xp;
@@ -79,11 +91,14 @@ int main(int argc, char **argv) {
     double s = 0.0;
     for (long i = 0; i < nel; i++) s += xp[i];
     VecRestoreArray(xPhys, &xp);
-    printf("# final volume fraction %.6f\n", s / (double)nel);
+    double tot[2] = {s, (double)nel};
+    slab_detail::host_reduce(&sc, tot, 2, 0);
+    if (root) printf("# final volume fraction %.6f\n", tot[0] / tot[1]);
     delete mma;
     delete filter;
     delete physics;
     for (Vec *v : {&x, &xTilde, &xPhys, &dfdx, &dgdx[0], &xmin, &xmax, &xold}) VecDestroy(v);
     tp_grid_destroy(grid);
+    slab_comm_free(&sc);
     return 0;
 }

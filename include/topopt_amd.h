@@ -133,6 +133,7 @@ int tp_grid_comm_selfcheck(tp_grid *g, int *ok);
 int tp_rccl_selftest(int device, void *stream, long n, double *max_err);
 
 /* ---- device memory helpers (for hosts without a GPU framework) ---------- */
+int tp_set_device(int device);             /* hipSetDevice: before tp_malloc of the tp_comm staging buffers */
 int tp_malloc(void **p, size_t bytes);
 int tp_free(void *p);
 int tp_memcpy_h2d(void *dst, const void *src, size_t bytes);

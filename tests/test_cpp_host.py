@@ -38,6 +38,27 @@ def test_cpp_driver_matches_python_driver():
     assert "# final volume fraction 0.1" in out.stdout
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("filt", [1, 2])
+def test_cpp_driver_slab_ranks_match_one_rank(filt):
+    """host/slabrun starts the C++ driver as 2 and 4 z-slab processes (shared-memory tp_comm hooks of
+    host/slab_comm.h, every rank on GPU 0; the RCCL upgrade is attempted and, on one GPU, collectively declined):
+    the printed optimisation history equals the one-rank run's (same solver iteration counts, values to the printed digits)."""
+    exe = _build()
+    run = os.path.join(ROOT, "host", "slabrun")
+    args = ["-nx", "33", "-ny", "17", "-nz", "33", "-nlvls", "3", "-maxItr", "4", "-rmin", "0.16", "-filter", str(filt)]
+    hist = {}
+    for n in (1, 2, 4):
+        out = subprocess.run([run, "-n", str(n), "--same-device", exe] + args, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        lines = [re.sub(r", time: .*", "", ln) for ln in out.stdout.splitlines() if ln.startswith(("It.:", "State solver", "# final"))]
+        assert len(lines) == 9, out.stdout
+        hist[n] = [[float(v) for v in re.findall(r"-?\d+\.?\d*(?:[eE][+-]?\d+)?", ln)] for ln in lines]
+    for n in (2, 4):   # iteration counts equal, printed numbers to the last printed digits (sums are ordered differently)
+        for a, b in zip(hist[n], hist[1]):
+            assert len(a) == len(b) and a == pytest.approx(b, rel=2e-5, abs=2e-6), (n, a, b)
+
+
 # ---- PETSc-named surface (include/petsc_compat/petsc.h, host/petsc_shim.cc) ---------------------------------------------
 def _shim_symbols():
     hdr = open(os.path.join(ROOT, "include", "petsc_compat", "petsc.h")).read()

@@ -272,6 +272,10 @@ extern "C" long tp_grid_owned_nodes(const tp_grid *g) { return make_geom(g, 0).o
 extern "C" int tp_grid_node_z0(const tp_grid *g) { return make_geom(g, 0).gz0; }
 extern "C" int tp_grid_elem_z0(const tp_grid *g) { return g->rank * g->ez_own; }
 
+extern "C" int tp_set_device(int device) {
+    TP_HIP(hipSetDevice(device));
+    return TP_OK;
+}
 extern "C" int tp_malloc(void **p, size_t bytes) {
     TP_HIP(hipMalloc(p, bytes));
     return TP_OK;

@@ -68,6 +68,7 @@ SYMBOLS = {
     "tp_grid_owned_nodes": (_l, [_vp]),
     "tp_grid_node_z0": (_i, [_vp]),
     "tp_grid_elem_z0": (_i, [_vp]),
+    "tp_set_device": (_i, [C.c_int]),
     "tp_malloc": (_i, [C.POINTER(_vp), C.c_size_t]),
     "tp_free": (_i, [_vp]),
     "tp_memcpy_h2d": (_i, [_vp, _vp, C.c_size_t]),
