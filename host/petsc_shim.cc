@@ -5,6 +5,9 @@
 // exactly as with real PETSc (anything else: PETSC_ERR_SUP with a message, never a silent substitution).
 #include <petsc/private/dmdaimpl.h>
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstdarg>
 #include <cstdint>
@@ -15,6 +18,7 @@
 #include <vector>
 
 #include "../include/topopt_amd.h"
+#include "slab_comm.h"
 
 namespace {
 
@@ -67,7 +71,7 @@ const std::string *opt_find(const char *pre, const char *name) {
     return it == opts().end() ? nullptr : &it->second;
 }
 
-// ---- the mesh all DMs of a program live on (one process, one GPU) ------------------------------------------
+// ---- the mesh all DMs of a program live on (one process per GPU; z-slabs over the ranks of the job) ---------
 struct Mesh {
     int nx = 0, ny = 0, nz = 0;  // nodes
     double box[6] = {0, 1, 0, 1, 0, 1};
@@ -76,11 +80,48 @@ struct Mesh {
     int users = 0;
 } mesh;
 
+// ---- the ranks of the job (host/slabrun sets TP_RANK / TP_NRANKS / TP_SHM / TP_DEVICE; absent: one rank).  The shared
+// segment is attached at the first collective: by then the options database knows -nx / -ny, which size the mailboxes.
+SlabComm sc;
+bool sc_ready = false;
+int job_rank() {
+    static const int r = getenv("TP_RANK") ? atoi(getenv("TP_RANK")) : 0;
+    return r;
+}
+int job_size() {
+    static const int n = getenv("TP_NRANKS") ? atoi(getenv("TP_NRANKS")) : 1;
+    return n < 1 ? 1 : n;
+}
+const std::string *opt_find(const char *pre, const char *name);
+int comm_ready() {
+    if (sc_ready) return 0;
+    long nx = mesh.nx, ny = mesh.ny;
+    if (nx == 0) {
+        const std::string *ox = opt_find(nullptr, "nx"), *oy = opt_find(nullptr, "ny");
+        nx = ox ? atol(ox->c_str()) : 65;  // TopOpt.cc:106-108 defaults
+        ny = oy ? atol(oy->c_str()) : 33;
+    }
+    long cap = std::max(12L * nx * ny, 1L << 16);
+    if (getenv("TP_SLAB_CAP")) cap = std::max(cap, atol(getenv("TP_SLAB_CAP")));
+    if (slab_comm_init(&sc, cap)) return PETSC_ERR_LIB;
+    sc_ready = true;
+    return 0;
+}
+
 }  // namespace
 
 struct _p_Vec {
     Hdr h;
-    long n;
+    // Layout.  A nodal vector is stored like the library stores it: this rank's z-slab WITH its ghost planes (n_alloc
+    // entries, = PETSc's ghosted local numbering for stencil width 1); the GLOBAL vector's local part is the window
+    // [off, off + n) of the owned planes, the LOCAL (ghosted) vector of DMCreateLocalVector is the whole array.  Element
+    // vectors hold the owned elements only (off = 0, n = n_alloc).  One rank: off = 0, n = n_alloc = nglob.
+    long n;        // length as PETSc sees it on this rank (VecGetLocalSize)
+    long n_alloc;  // entries stored
+    long off;      // first entry of the window
+    long nglob;    // VecGetSize of a global vector
+    long goff;     // global index of entry `off` (natural = PETSc ordering: slabs are contiguous in z)
+    bool is_local; // sequential vector (ghosted local vector, coordinates): VecGetSize = n
     double *d;  // [dev]; NULL for a host-only vector (coordinates)
     std::vector<double> host;
     // Lazy coherence of the host mirror and the HBM array.  VecGetArray hands out host.data() and from then on the HOST
@@ -91,6 +132,8 @@ struct _p_Vec {
 };
 struct DMFull : _p_DM {
     PetscInt M, N, P, dof, sw;
+    int zkind;                 // partition in z: 0 like nodes (P - 1 = R e: rank 0 owns e + 1 planes, the others e), 1 like elements (P = R e)
+    std::vector<PetscInt> lzv; // planes per rank
     double box[6];
     bool have_box;
     DM_DA da;
@@ -108,6 +151,7 @@ struct _p_Mat {
     long n_rows, n_cols;
     // capture state
     std::vector<double> ref;     // first block seen (576 / 64 / 8 values)
+    std::vector<double> ref0;    // K_ELAST: rank 0's first block = the element matrix of the operator
     std::vector<double> E;       // K_ELAST: per element multiplier of `ref`
     long ncalls;
     double coneR;                // K_CONE
@@ -146,6 +190,7 @@ struct _p_PetscViewer {
     FILE *fp;
     PetscFileMode mode;
     bool ascii;
+    long long pos;  // binary: byte position of the next object (every rank keeps it; the ranks write their own parts)
 };
 struct _mpi_compat_file {
     FILE *fp;
@@ -183,29 +228,76 @@ int ensure_grid() {
     o.hx = (mesh.box[1] - mesh.box[0]) / (mesh.nx - 1);
     o.hy = (mesh.box[3] - mesh.box[2]) / (mesh.ny - 1);
     o.hz = (mesh.box[5] - mesh.box[4]) / (mesh.nz - 1);
-    o.rank = 0;
-    o.nranks = 1;
-    o.device = 0;
-    return tp_grid_create(&mesh.g, &o);
+    int rc = comm_ready();
+    if (rc) return rc;
+    if (sc.nranks > 1 && sc.hooks.cap < std::max(3L * mesh.nx * mesh.ny, 4L * (mesh.nx - 1) * (mesh.ny - 1))) {
+        fprintf(stderr, "[petsc-compat] the mailboxes of the job were sized before the mesh was known (%ld doubles): pass -nx/-ny or set TP_SLAB_CAP\n", sc.hooks.cap);
+        return PETSC_ERR_LIB;
+    }
+    o.rank = sc.rank;
+    o.nranks = sc.nranks;
+    o.device = sc.device;
+    o.comm = sc.nranks > 1 ? &sc.hooks : nullptr;
+    rc = tp_grid_create(&mesh.g, &o);
+    if (rc) return rc;
+    sc.grid = mesh.g;
+    slab_comm_try_rccl(&sc, mesh.g);  // one process per GPU: the library's own RCCL path; else the mailboxes stay
+    return 0;
 }
 bool is_nodal(const DMFull *d) { return d->M == mesh.nx && d->N == mesh.ny && d->P == mesh.nz; }
 bool is_elem(const DMFull *d) { return d->M == mesh.nx - 1 && d->N == mesh.ny - 1 && d->P == mesh.nz - 1; }
 
-int vec_create(long n, bool host_only, DM dm, Vec *out) {
+// this rank's part of a DMDA along z (x and y are never split): owned range [zs, zs + zm), ghosted range [gzs, gzs + gzm)
+// for stencil width sw (DMDAGetCorners / DMDAGetGhostCorners of a DM_BOUNDARY_NONE DMDA on a 1 x 1 x R process grid)
+struct ZBox {
+    PetscInt zs, zm, gzs, gzm;
+};
+ZBox zbox(const DMFull *d, PetscInt sw) {
+    const int R = job_size(), r = job_rank();
+    ZBox b;
+    if (R == 1) {
+        b.zs = b.gzs = 0;
+        b.zm = b.gzm = d->P;
+        return b;
+    }
+    if (d->zkind == 0) {
+        const PetscInt e = (d->P - 1) / R;
+        b.zs = r == 0 ? 0 : r * e + 1;
+        b.zm = e + (r == 0 ? 1 : 0);
+    } else {
+        const PetscInt e = d->P / R;
+        b.zs = r * e;
+        b.zm = e;
+    }
+    b.gzs = std::max<PetscInt>(b.zs - sw, 0);
+    b.gzm = std::min<PetscInt>(b.zs + b.zm + sw, d->P) - b.gzs;
+    return b;
+}
+
+int vec_create_layout(long n_alloc, long off, long n, long nglob, long goff, bool is_local, bool host_only, DM dm, Vec *out);
+int vec_create(long n, bool host_only, DM dm, Vec *out) {  // a vector that is not split (one rank, or sequential)
+    return vec_create_layout(n, 0, n, n, 0, true, host_only, dm, out);
+}
+int vec_create_layout(long n_alloc, long off, long n, long nglob, long goff, bool is_local, bool host_only, DM dm, Vec *out) {
     Vec v = new _p_Vec();
-    hdr_init(v->h, CLS_VEC, "seq");
+    hdr_init(v->h, CLS_VEC, is_local ? "seq" : "mpi");
     v->n = n;
+    v->n_alloc = n_alloc;
+    v->off = off;
+    v->nglob = nglob;
+    v->goff = goff;
+    v->is_local = is_local;
     v->d = nullptr;
     v->host_valid = false;
     v->dev_valid = true;
     v->dm = dm;
     if (host_only) {
-        v->host.assign((size_t)n, 0.0);
+        v->host.assign((size_t)n_alloc, 0.0);
         v->host_valid = true;
     } else {
         int rc = ensure_grid();
-        if (!rc) rc = tp_malloc((void **)&v->d, sizeof(double) * (size_t)(n > 0 ? n : 1));
-        if (!rc) rc = tp_vec_set(mesh.g, v->d, 0.0, n);
+        if (!rc) rc = tp_malloc((void **)&v->d, sizeof(double) * (size_t)(n_alloc > 0 ? n_alloc : 1));
+        if (!rc) rc = tp_vec_set(mesh.g, v->d, 0.0, n_alloc);
         if (rc) {
             delete v;
             return rc;
@@ -216,33 +308,38 @@ int vec_create(long n, bool host_only, DM dm, Vec *out) {
 }
 int vec_pull(Vec x) {  // make the host mirror current
     if (!x->d || x->host_valid) return 0;
-    x->host.resize((size_t)x->n);
+    x->host.resize((size_t)x->n_alloc);
     tp_sync(mesh.g);
-    int rc = tp_memcpy_d2h(x->host.data(), x->d, sizeof(double) * (size_t)x->n);
+    int rc = tp_memcpy_d2h(x->host.data(), x->d, sizeof(double) * (size_t)x->n_alloc);
     x->host_valid = rc == 0;
     return rc;
 }
 int vec_push(Vec x) {  // make the HBM array current
     if (!x->d || x->dev_valid) return 0;
-    int rc = tp_memcpy_h2d(x->d, x->host.data(), sizeof(double) * (size_t)x->n);
+    int rc = tp_memcpy_h2d(x->d, x->host.data(), sizeof(double) * (size_t)x->n_alloc);
     x->dev_valid = rc == 0;
     return rc;
 }
-// device pointers for an operation that reads / overwrites / updates the vector
+// device pointers for an operation that reads / overwrites / updates the vector: the WINDOW PETSc sees (owned entries) ...
 double *din(Vec x) {
     vec_push(x);
-    return x->d;
+    return x->d + x->off;
 }
 double *dout(Vec x) {
+    if (x->n != x->n_alloc) vec_push(x);  // the entries outside the window keep their values
     x->dev_valid = true;
     x->host_valid = false;
-    return x->d;
+    return x->d + x->off;
 }
 double *dinout(Vec x) {
     vec_push(x);
     x->host_valid = false;
-    return x->d;
+    return x->d + x->off;
 }
+// ... and the whole slab array, for the library calls that take nodal vectors with their ghost planes
+double *bin(Vec x) { return din(x) - x->off; }
+double *bout(Vec x) { return dout(x) - x->off; }
+double *binout(Vec x) { return dinout(x) - x->off; }
 
 // ---- the solver configuration a KSP resolves to ------------------------------------------------------------
 void ksp_apply_options(KSP k, const std::vector<std::string> &prefixes) {
@@ -299,7 +396,7 @@ int ensure_elasticity(Mat A) {
     if (A->kind != K_ELAST) return PETSC_ERR_ARG_WRONG;
     if (A->ref.empty()) return PETSC_ERR_ORDER;
     DMFull *d = F(A->dm);
-    const long nel = (long)(d->M - 1) * (d->N - 1) * (d->P - 1);
+    const long nel = (long)(d->M - 1) * (d->N - 1) * ((d->P - 1) / job_size());  // this rank's elements
     if (!A->e) {
         tp_solver_opts o;
         if (A->ksp) {
@@ -310,7 +407,18 @@ int ensure_elasticity(Mat A) {
             o.nlvls = 1;
         }
         int rc = ensure_grid();
-        if (!rc) rc = tp_elasticity_create_ke(&A->e, mesh.g, &o, A->ref.data());
+        // the element matrix every rank hands to the library is rank 0's first block; a rank's own multipliers (relative
+        // to ITS first block) are rescaled by the ratio of the two
+        A->ref0 = A->ref;
+        if (!rc && job_size() > 1) {
+            if (job_rank() != 0) std::fill(A->ref0.begin(), A->ref0.end(), 0.0);
+            rc = MPI_Allreduce(A->ref0.data(), A->ref0.data(), 576, MPI_DOUBLE, MPI_SUM, MPI_COMM_WORLD);
+            const double f = A->ref[0] / A->ref0[0];
+            for (int q : {1, 25, 300, 575})
+                if (fabs(A->ref[q] - f * A->ref0[q]) > 1e-12 * fabs(f) * (fabs(A->ref0[0]) + fabs(A->ref0[q])))
+                    return sup("dof-3 matrix: the ranks' element blocks are not multiples of one element matrix");
+        }
+        if (!rc) rc = tp_elasticity_create_ke(&A->e, mesh.g, &o, A->ref0.data());
         if (rc) return rc;
         rc = tp_malloc((void **)&A->dE, sizeof(double) * (size_t)nel);
         if (rc) return rc;
@@ -319,8 +427,19 @@ int ensure_elasticity(Mat A) {
     if (A->assembled_since_setup) {
         if (!A->have_bc || !A->Nvec) return sup("stiffness matrix without MatDiagonalScale(K, N, N): Dirichlet vector unknown");
         if ((long)A->E.size() != nel || A->ncalls != nel) return sup("MatSetValuesLocal: not every element was added exactly once");
-        int rc = tp_elasticity_set_bc(A->e, din(A->Nvec));
-        if (!rc) rc = tp_memcpy_h2d(A->dE, A->E.data(), sizeof(double) * (size_t)nel);
+        // N arrived through window copies: its ghost planes are refreshed before the library reads the whole slab
+        int rc = job_size() > 1 ? tp_grid_halo_nodes(mesh.g, binout(A->Nvec), 3) : 0;
+        if (!rc) rc = tp_elasticity_set_bc(A->e, bin(A->Nvec));
+        if (!rc) {
+            const double f = A->ref[0] / A->ref0[0];
+            if (f != 1.0) {
+                std::vector<double> Es(A->E);
+                for (double &v : Es) v *= f;
+                rc = tp_memcpy_h2d(A->dE, Es.data(), sizeof(double) * (size_t)nel);
+            } else {
+                rc = tp_memcpy_h2d(A->dE, A->E.data(), sizeof(double) * (size_t)nel);
+            }
+        }
         // E_e = 0 + x^1 (1 - 0): the captured multipliers ARE the moduli (pow(x, 1.0) is exact)
         if (!rc) rc = tp_elasticity_assemble(A->e, A->dE, 0.0, 1.0, 1.0);
         if (rc) return rc;
@@ -417,7 +536,8 @@ PetscErrorCode PetscOptionsGetString(PetscOptions, const char pre[], const char 
     }
     return 0;
 }
-PetscErrorCode PetscPrintf(MPI_Comm, const char format[], ...) {
+PetscErrorCode PetscPrintf(MPI_Comm comm, const char format[], ...) {
+    if (comm == MPI_COMM_WORLD && job_rank() != 0) return 0;  // the first rank of the communicator prints
     va_list ap;
     va_start(ap, format);
     vprintf(format, ap);
@@ -462,12 +582,54 @@ static std::vector<VecType> &vec_types() {
     static std::vector<VecType> v;
     return v;
 }
-int MPI_Allreduce(const void *s, void *r, int count, MPI_Datatype t, MPI_Op, MPI_Comm) {
-    if (s != r) memcpy(r, s, (size_t)count * (size_t)mpi_esize(t));
+// the element types of the reference's reductions as doubles and back (counts stay far below 2^53)
+static double mpi_load(const void *p, int i, MPI_Datatype t) {
+    switch (t) {
+    case MPI_INT: return (double)((const int *)p)[i];
+    case MPI_FLOAT: return (double)((const float *)p)[i];
+    case MPI_UNSIGNED_LONG: return (double)((const unsigned long *)p)[i];
+    case MPI_LONG: return (double)((const long *)p)[i];
+    case MPI_CHAR: return (double)((const char *)p)[i];
+    default: return ((const double *)p)[i];
+    }
+}
+static void mpi_store(void *p, int i, MPI_Datatype t, double v) {
+    switch (t) {
+    case MPI_INT: ((int *)p)[i] = (int)v; break;
+    case MPI_FLOAT: ((float *)p)[i] = (float)v; break;
+    case MPI_UNSIGNED_LONG: ((unsigned long *)p)[i] = (unsigned long)v; break;
+    case MPI_LONG: ((long *)p)[i] = (long)v; break;
+    case MPI_CHAR: ((char *)p)[i] = (char)v; break;
+    default: ((double *)p)[i] = v; break;
+    }
+}
+int MPI_Allreduce(const void *s, void *r, int count, MPI_Datatype t, MPI_Op op, MPI_Comm comm) {
+    if (comm == MPI_COMM_SELF || job_size() == 1) {
+        if (s != r) memcpy(r, s, (size_t)count * (size_t)mpi_esize(t));
+        return 0;
+    }
+    if (comm_ready()) return 1;
+    const int how = op == MPI_SUM ? 0 : (op == MPI_MAX ? 1 : 2);
+    for (int i0 = 0; i0 < count; i0 += 1024) {  // sums in rank order on every rank: the same bits everywhere
+        const int c = std::min(1024, count - i0);
+        double v[1024];
+        for (int i = 0; i < c; i++) v[i] = mpi_load(s, i0 + i, t);
+        slab_detail::host_reduce(&sc, v, c, how);
+        for (int i = 0; i < c; i++) mpi_store(r, i0 + i, t, v[i]);
+    }
     return 0;
 }
-int MPI_Allgather(const void *s, int sc, MPI_Datatype st, void *r, int, MPI_Datatype, MPI_Comm) {
-    if (s != r) memcpy(r, s, (size_t)sc * (size_t)mpi_esize(st));
+int MPI_Allgather(const void *s, int scount, MPI_Datatype st, void *r, int, MPI_Datatype, MPI_Comm comm) {
+    if (comm == MPI_COMM_SELF || job_size() == 1) {
+        if (s != r) memcpy(r, s, (size_t)scount * (size_t)mpi_esize(st));
+        return 0;
+    }
+    if (comm_ready() || scount > sc.hooks.cap) return 1;
+    for (int i = 0; i < scount; i++) sc.mailbox(sc.rank, 0)[i] = mpi_load(s, i, st);
+    sc.barrier();
+    for (int q = 0; q < sc.nranks; q++)
+        for (int i = 0; i < scount; i++) mpi_store(r, q * scount + i, st, sc.mailbox(q, 0)[i]);
+    sc.barrier();
     return 0;
 }
 int MPI_Init(int *, char ***) { return 0; }
@@ -491,8 +653,10 @@ int MPI_Type_free(MPI_Datatype *t) {
     return 0;
 }
 int MPI_File_open(MPI_Comm, const char *filename, int amode, MPI_Info, MPI_File *fh) {
-    FILE *fp = fopen(filename, "r+b");  // MPI-IO never truncates: several open/close rounds build one file
-    if (!fp && (amode & MPI_MODE_CREATE)) fp = fopen(filename, "w+b");
+    // MPI-IO never truncates: several open/close rounds -- and several ranks, each writing through its own view --
+    // build one file
+    const int fd = open(filename, O_RDWR | ((amode & MPI_MODE_CREATE) ? O_CREAT : 0), 0644);
+    FILE *fp = fd >= 0 ? fdopen(fd, "r+b") : nullptr;
     if (!fp) return 1;
     *fh = new _mpi_compat_file{fp, 0, 0, 0, 0, 0};
     return 0;
@@ -538,26 +702,47 @@ int MPI_File_write(MPI_File fh, const void *buf, int count, MPI_Datatype t, MPI_
     return 0;
 }
 int MPI_File_write_all(MPI_File fh, const void *buf, int count, MPI_Datatype t, MPI_Status *st) { return MPI_File_write(fh, buf, count, t, st); }
-int MPI_Comm_rank(MPI_Comm, int *rank) {
-    *rank = 0;
+int MPI_Comm_rank(MPI_Comm comm, int *rank) {
+    *rank = comm == MPI_COMM_SELF ? 0 : job_rank();
     return 0;
 }
-int MPI_Comm_size(MPI_Comm, int *size) {
-    *size = 1;
+int MPI_Comm_size(MPI_Comm comm, int *size) {
+    *size = comm == MPI_COMM_SELF ? 1 : job_size();
     return 0;
 }
-int MPI_Barrier(MPI_Comm) { return 0; }
+int MPI_Barrier(MPI_Comm comm) {
+    if (comm == MPI_COMM_SELF || job_size() == 1) return 0;
+    if (comm_ready()) return 1;
+    sc.barrier();
+    return 0;
+}
 double MPI_Wtime(void) {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
-PetscErrorCode PetscViewerBinaryOpen(MPI_Comm, const char name[], PetscFileMode mode, PetscViewer *v) {
-    FILE *fp = fopen(name, mode == FILE_MODE_READ ? "rb" : (mode == FILE_MODE_APPEND ? "ab" : "wb"));
+PetscErrorCode PetscViewerBinaryOpen(MPI_Comm comm, const char name[], PetscFileMode mode, PetscViewer *v) {
+    FILE *fp = nullptr;
+    long long pos0 = 0;
+    if (job_size() == 1 || comm == MPI_COMM_SELF) {
+        fp = fopen(name, mode == FILE_MODE_READ ? "rb" : (mode == FILE_MODE_APPEND ? "ab" : "wb"));
+    } else {  // rank 0 creates / truncates, then every rank has the file open for positioned writes of its own part
+        if (mode != FILE_MODE_READ && job_rank() == 0) {
+            FILE *t = fopen(name, mode == FILE_MODE_APPEND ? "ab" : "wb");
+            if (t) fclose(t);
+        }
+        MPI_Barrier(comm);
+        fp = fopen(name, mode == FILE_MODE_READ ? "rb" : "r+b");
+        if (fp && mode == FILE_MODE_APPEND) {
+            fseek(fp, 0, SEEK_END);
+            pos0 = ftell(fp);
+        }
+    }
     if (!fp) return PETSC_ERR_FILE_OPEN;
     PetscViewer w = new _p_PetscViewer();
     hdr_init(w->h, CLS_VIEWER, PETSCVIEWERBINARY);
     w->fp = fp;
     w->mode = mode;
     w->ascii = false;
+    w->pos = pos0;
     *v = w;
     return 0;
 }
@@ -567,6 +752,7 @@ PetscErrorCode PetscViewerCreate(MPI_Comm, PetscViewer *v) {
     w->fp = nullptr;
     w->mode = FILE_MODE_WRITE;
     w->ascii = true;
+    w->pos = 0;
     *v = w;
     return 0;
 }
@@ -580,10 +766,15 @@ PetscErrorCode PetscViewerFileSetMode(PetscViewer v, PetscFileMode mode) {
 }
 PetscErrorCode PetscViewerFileSetName(PetscViewer v, const char name[]) {
     if (v->fp) fclose(v->fp);
+    if (v->ascii && v->mode != FILE_MODE_READ && job_rank() != 0) {  // an ASCII viewer prints from the first rank only
+        v->fp = nullptr;
+        return 0;
+    }
     v->fp = fopen(name, v->mode == FILE_MODE_READ ? "r" : (v->mode == FILE_MODE_APPEND ? "a" : "w"));
     return v->fp ? 0 : PETSC_ERR_FILE_OPEN;
 }
 PetscErrorCode PetscViewerASCIIPrintf(PetscViewer v, const char format[], ...) {
+    if (!v->fp && v->ascii && job_rank() != 0) return 0;
     if (!v->fp) return PETSC_ERR_ORDER;
     va_list ap;
     va_start(ap, format);
@@ -616,10 +807,26 @@ PetscErrorCode PetscRandomDestroy(PetscRandom *r) {
 
 // =============================================================================================== DMDA
 PetscErrorCode DMDACreate3d(MPI_Comm, DMBoundaryType, DMBoundaryType, DMBoundaryType, DMDAStencilType, PetscInt M,
-                            PetscInt N, PetscInt P, PetscInt, PetscInt, PetscInt, PetscInt dof, PetscInt s,
-                            const PetscInt[], const PetscInt[], const PetscInt[], DM *da) {
+                            PetscInt N, PetscInt P, PetscInt m, PetscInt n, PetscInt p, PetscInt dof, PetscInt s,
+                            const PetscInt[], const PetscInt[], const PetscInt lz[], DM *da) {
     if (!da || M < 1 || N < 1 || P < 1 || dof < 1) return PETSC_ERR_ARG_OUTOFRANGE;
+    // the process grid is 1 x 1 x R (z-slabs): PETSC_DECIDE resolves to it, anything else is refused
+    const int R = job_size();
+    if ((m != PETSC_DECIDE && m != 1) || (n != PETSC_DECIDE && n != 1) || (p != PETSC_DECIDE && p != R))
+        return sup("DMDACreate3d: the ranks of the job form a 1 x 1 x R process grid (z-slabs)");
+    int zkind = 0;
+    if (R > 1) {
+        if ((P - 1) % R == 0) zkind = 0;
+        else if (P % R == 0) zkind = 1;
+        else return sup("DMDACreate3d: the z extent does not split into equal slabs of elements over the ranks");
+        const PetscInt e = zkind == 0 ? (P - 1) / R : P / R;
+        if (lz)
+            for (int q = 0; q < R; q++)
+                if (lz[q] != e + ((zkind == 0 && q == 0) ? 1 : 0)) return sup("DMDACreate3d: lz[] is not the slab partition of the node mesh");
+    }
     DMFull *d = new DMFull();
+    d->zkind = zkind;
+    for (int q = 0; q < R; q++) d->lzv.push_back(R == 1 ? P : (zkind == 0 ? (P - 1) / R + (q == 0 ? 1 : 0) : P / R));
     Hdr h;
     hdr_init(h, CLS_DM, "da");
     memcpy(d->hdr_, &h, sizeof(h));
@@ -680,7 +887,7 @@ PetscErrorCode DMDAGetInfo(DM da, PetscInt *dim, PetscInt *M, PetscInt *N, Petsc
     if (P) *P = d->P;
     if (m) *m = 1;
     if (n) *n = 1;
-    if (p) *p = 1;
+    if (p) *p = job_size();
     if (dof) *dof = d->dof;
     if (s) *s = d->sw;
     if (bx) *bx = DM_BOUNDARY_NONE;
@@ -691,22 +898,31 @@ PetscErrorCode DMDAGetInfo(DM da, PetscInt *dim, PetscInt *M, PetscInt *N, Petsc
 }
 PetscErrorCode DMDAGetCorners(DM da, PetscInt *x, PetscInt *y, PetscInt *z, PetscInt *m, PetscInt *n, PetscInt *p) {
     DMFull *d = F(da);
+    const ZBox b = zbox(d, d->sw);
     if (x) *x = 0;
     if (y) *y = 0;
-    if (z) *z = 0;
+    if (z) *z = b.zs;
     if (m) *m = d->M;
     if (n) *n = d->N;
-    if (p) *p = d->P;
+    if (p) *p = b.zm;
     return 0;
 }
 PetscErrorCode DMDAGetGhostCorners(DM da, PetscInt *x, PetscInt *y, PetscInt *z, PetscInt *m, PetscInt *n, PetscInt *p) {
-    return DMDAGetCorners(da, x, y, z, m, n, p);  // one rank, non-periodic: no ghost points
+    DMFull *d = F(da);  // non-periodic, x and y unsplit: ghost points only towards the neighbouring slabs
+    const ZBox b = zbox(d, d->sw);
+    if (x) *x = 0;
+    if (y) *y = 0;
+    if (z) *z = b.gzs;
+    if (m) *m = d->M;
+    if (n) *n = d->N;
+    if (p) *p = b.gzm;
+    return 0;
 }
 PetscErrorCode DMDAGetOwnershipRanges(DM da, const PetscInt *lx[], const PetscInt *ly[], const PetscInt *lz[]) {
     DMFull *d = F(da);
     if (lx) *lx = &d->own[0];
     if (ly) *ly = &d->own[1];
-    if (lz) *lz = &d->own[2];
+    if (lz) *lz = d->lzv.data();
     return 0;
 }
 PetscErrorCode DMDAGetLocalInfo(DM da, DMDALocalInfo *i) {
@@ -715,21 +931,28 @@ PetscErrorCode DMDAGetLocalInfo(DM da, DMDALocalInfo *i) {
     i->dim = 3;
     i->dof = d->dof;
     i->sw = d->sw;
+    const ZBox b = zbox(d, d->sw);
     i->mx = i->xm = i->gxm = d->M;
     i->my = i->ym = i->gym = d->N;
-    i->mz = i->zm = i->gzm = d->P;
+    i->mz = d->P;
+    i->zs = b.zs;
+    i->zm = b.zm;
+    i->gzs = b.gzs;
+    i->gzm = b.gzm;
     i->st = DMDA_STENCIL_BOX;
     i->da = da;
     return 0;
 }
 PetscErrorCode DMDAGetElements(DM da, PetscInt *nel, PetscInt *nen, const PetscInt *e[]) {
     DMFull *d = F(da);
-    if (!d->da.e) {  // hexahedra, DMDA natural order (the numbering of LinearElasticity.cc:819-826)
-        const PetscInt ex = d->M - 1, ey = d->N - 1, ez = d->P - 1;
-        d->da.ne = ex * ey * ez;
+    if (!d->da.e) {  // hexahedra, DMDA natural order (the numbering of LinearElasticity.cc:819-826), ghosted local node numbers
+        const ZBox b = zbox(d, d->sw);
+        const PetscInt ex = d->M - 1, ey = d->N - 1;
+        const PetscInt k0 = (b.zs != b.gzs ? b.zs - 1 : b.zs) - b.gzs, ez = k0 + (b.zs + b.zm - 1 - (b.zs != b.gzs ? b.zs - 1 : b.zs));
+        d->da.ne = ex * ey * (ez - k0);
         d->da.e = (PetscInt *)malloc(sizeof(PetscInt) * (size_t)(1 + 8 * (long)d->da.ne));
         long c = 0;
-        for (PetscInt k = 0; k < ez; k++)
+        for (PetscInt k = k0; k < ez; k++)
             for (PetscInt j = 0; j < ey; j++)
                 for (PetscInt i = 0; i < ex; i++) {
                     const PetscInt n0 = i + d->M * (j + d->N * k), dz = d->M * d->N;
@@ -745,14 +968,15 @@ PetscErrorCode DMDAGetElements(DM da, PetscInt *nel, PetscInt *nen, const PetscI
 PetscErrorCode DMDARestoreElements(DM, PetscInt *, PetscInt *, const PetscInt *[]) { return 0; }
 PetscErrorCode DMGetCoordinatesLocal(DM da, Vec *c) {
     DMFull *d = F(da);
-    if (!d->coords) {
-        const long n = (long)d->M * d->N * d->P;
+    if (!d->coords) {  // the ghosted local box of this rank
+        const ZBox b = zbox(d, d->sw);
+        const long n = (long)d->M * d->N * b.gzm;
         int rc = vec_create(3 * n, true, da, &d->coords);
         if (rc) return rc;
         const double hx = d->M > 1 ? (d->box[1] - d->box[0]) / (d->M - 1) : 0.0, hy = d->N > 1 ? (d->box[3] - d->box[2]) / (d->N - 1) : 0.0,
                      hz = d->P > 1 ? (d->box[5] - d->box[4]) / (d->P - 1) : 0.0;
         double *p = d->coords->host.data();
-        for (PetscInt k = 0; k < d->P; k++)
+        for (PetscInt k = b.gzs; k < b.gzs + b.gzm; k++)
             for (PetscInt j = 0; j < d->N; j++)
                 for (PetscInt i = 0; i < d->M; i++) {  // DMDASetUniformCoordinates: xmin + i * h
                     *p++ = d->box[0] + hx * i;
@@ -768,14 +992,34 @@ PetscErrorCode DMGetLocalToGlobalMapping(DM, ISLocalToGlobalMapping *m) {
     *m = &identity;
     return 0;
 }
-PetscErrorCode DMCreateGlobalVector(DM da, Vec *v) {
+static int dm_vector(DM da, bool local, Vec *v) {
     DMFull *d = F(da);
     if (!is_nodal(d) && !is_elem(d)) return sup("vector on a DMDA that is neither the node mesh nor its element mesh");
     d->uses_grid = true;
-    return vec_create((long)d->dof * d->M * d->N * d->P, false, da, v);
+    const long per = (long)d->dof * d->M * d->N;  // entries per z-plane
+    const long nglob = per * d->P;
+    if (job_size() == 1) return vec_create_layout(nglob, 0, nglob, nglob, 0, local, false, da, v);
+    const ZBox own = zbox(d, 0);
+    if (is_elem(d)) {
+        if (local) return sup("DMCreateLocalVector on the element mesh across ranks");
+        return vec_create_layout(per * own.zm, 0, per * own.zm, nglob, per * own.zs, false, false, da, v);
+    }
+    const ZBox gb = zbox(d, 1);  // the library's slab layout: one ghost plane towards each neighbour
+    if (d->sw != 1) return sup("node mesh with a stencil width other than 1 across ranks");
+    if (local) return vec_create_layout(per * gb.gzm, 0, per * gb.gzm, nglob, per * gb.gzs, true, false, da, v);
+    return vec_create_layout(per * gb.gzm, per * (own.zs - gb.gzs), per * own.zm, nglob, per * own.zs, false, false, da, v);
 }
-PetscErrorCode DMCreateLocalVector(DM da, Vec *v) { return DMCreateGlobalVector(da, v); }  // one rank: no ghosts
-PetscErrorCode DMGlobalToLocalBegin(DM, Vec g, InsertMode, Vec l) { return g == l ? 0 : VecCopy(g, l); }
+PetscErrorCode DMCreateGlobalVector(DM da, Vec *v) { return dm_vector(da, false, v); }
+PetscErrorCode DMCreateLocalVector(DM da, Vec *v) { return dm_vector(da, true, v); }
+// global -> ghosted local: both are slab arrays; copy the slab, then fetch the ghost planes from the neighbours
+PetscErrorCode DMGlobalToLocalBegin(DM da, Vec g, InsertMode, Vec l) {
+    if (g == l) return 0;
+    if (g->n_alloc != l->n_alloc) return PETSC_ERR_ARG_WRONG;
+    const double *pg = bin(g);
+    int rc = tp_vec_axpby(mesh.g, bout(l), 1.0, pg, 0.0, l->n_alloc);
+    if (!rc && job_size() > 1) rc = tp_grid_halo_nodes(mesh.g, l->d, (int)F(da)->dof);
+    return rc;
+}
 PetscErrorCode DMGlobalToLocalEnd(DM, Vec, InsertMode, Vec) { return 0; }
 PetscErrorCode DMCoarsenHierarchy(DM da, PetscInt nlevels, DM dac[]) {
     DMFull *f = F(da);
@@ -785,7 +1029,7 @@ PetscErrorCode DMCoarsenHierarchy(DM da, PetscInt nlevels, DM dac[]) {
         M = (M - 1) / 2 + 1;
         N = (N - 1) / 2 + 1;
         P = (P - 1) / 2 + 1;
-        int rc = DMDACreate3d(0, DM_BOUNDARY_NONE, DM_BOUNDARY_NONE, DM_BOUNDARY_NONE, DMDA_STENCIL_BOX, M, N, P, 1, 1, 1, f->dof, f->sw, 0, 0, 0, &dac[l]);
+        int rc = DMDACreate3d(0, DM_BOUNDARY_NONE, DM_BOUNDARY_NONE, DM_BOUNDARY_NONE, DMDA_STENCIL_BOX, M, N, P, 1, 1, job_size(), f->dof, f->sw, 0, 0, 0, &dac[l]);
         if (rc) return rc;
     }
     return 0;
@@ -813,13 +1057,13 @@ PetscErrorCode DMCreateInterpolation(DM dac, DM daf, Mat *P, Vec *scale) {
     DMFull *c = F(dac), *f = F(daf);
     if ((f->M - 1) != 2 * (c->M - 1) || (f->N - 1) != 2 * (c->N - 1) || (f->P - 1) != 2 * (c->P - 1))
         return sup("DMCreateInterpolation: only factor-2 trilinear (Q1) interpolation between DMDAs");
-    *P = mat_new(K_INTERP, daf, (long)f->dof * f->M * f->N * f->P, (long)c->dof * c->M * c->N * c->P, "q1interp");
+    *P = mat_new(K_INTERP, daf, (long)f->dof * f->M * f->N * zbox(f, 0).zm, (long)c->dof * c->M * c->N * zbox(c, 0).zm, "q1interp");
     if (scale) *scale = nullptr;
     return 0;
 }
 PetscErrorCode DMCreateMatrix(DM da, Mat *A) {
     DMFull *d = F(da);
-    const long n = (long)d->dof * d->M * d->N * d->P;
+    const long n = (long)d->dof * d->M * d->N * zbox(d, 0).zm;  // local rows
     if (is_nodal(d) && d->dof == 3) {
         *A = mat_new(K_ELAST, da, n, n, "topopt-elasticity");
     } else if (is_nodal(d) && d->dof == 1) {
@@ -848,7 +1092,9 @@ PetscErrorCode DMDestroy(DM *da) {
 }
 
 // =============================================================================================== Vec
-PetscErrorCode VecDuplicate(Vec v, Vec *nv) { return vec_create(v->n, v->d == nullptr, v->dm, nv); }
+PetscErrorCode VecDuplicate(Vec v, Vec *nv) {
+    return vec_create_layout(v->n_alloc, v->off, v->n, v->nglob, v->goff, v->is_local, v->d == nullptr, v->dm, nv);
+}
 PetscErrorCode VecDuplicateVecs(Vec v, PetscInt m, Vec *V[]) {
     *V = (Vec *)malloc(sizeof(Vec) * (size_t)(m > 0 ? m : 1));
     for (PetscInt i = 0; i < m; i++) {
@@ -928,33 +1174,36 @@ PetscErrorCode VecNorm(Vec x, NormType type, PetscReal *val) {
     return rc;
 }
 PetscErrorCode VecSum(Vec x, PetscScalar *sum) { return tp_vec_dot(mesh.g, din(x), nullptr, x->n, sum); }
-PetscErrorCode VecMax(Vec x, PetscInt *p, PetscReal *val) {
+static int vec_extreme(Vec x, bool want_max, PetscInt *p, PetscReal *val) {
     int rc = vec_pull(x);
+    const double *h = x->host.data() + x->off;
     long at = 0;
     for (long i = 1; i < x->n; i++)
-        if (x->host[(size_t)i] > x->host[(size_t)at]) at = i;
+        if (want_max ? h[i] > h[at] : h[i] < h[at]) at = i;
+    double v = x->n ? h[at] : (want_max ? -1e300 : 1e300);
+    if (!x->is_local && job_size() > 1) {
+        if (p) return sup("VecMax / VecMin: the location of the extremum across ranks");
+        if (comm_ready()) return PETSC_ERR_LIB;
+        slab_detail::host_reduce(&sc, &v, 1, want_max ? 1 : 2);
+    }
     if (p) *p = (PetscInt)at;
-    if (val) *val = x->n ? x->host[(size_t)at] : 0.0;
+    if (val) *val = v;
     return rc;
 }
-PetscErrorCode VecMin(Vec x, PetscInt *p, PetscReal *val) {
-    int rc = vec_pull(x);
-    long at = 0;
-    for (long i = 1; i < x->n; i++)
-        if (x->host[(size_t)i] < x->host[(size_t)at]) at = i;
-    if (p) *p = (PetscInt)at;
-    if (val) *val = x->n ? x->host[(size_t)at] : 0.0;
-    return rc;
-}
+PetscErrorCode VecMax(Vec x, PetscInt *p, PetscReal *val) { return vec_extreme(x, true, p, val); }
+PetscErrorCode VecMin(Vec x, PetscInt *p, PetscReal *val) { return vec_extreme(x, false, p, val); }
 PetscErrorCode VecGetSize(Vec x, PetscInt *n) {
+    *n = (PetscInt)(x->is_local ? x->n : x->nglob);
+    return 0;
+}
+PetscErrorCode VecGetLocalSize(Vec x, PetscInt *n) {
     *n = (PetscInt)x->n;
     return 0;
 }
-PetscErrorCode VecGetLocalSize(Vec x, PetscInt *n) { return VecGetSize(x, n); }
 PetscErrorCode VecGetArray(Vec x, PetscScalar **a) {
     int rc = vec_pull(x);
     if (x->d) x->dev_valid = false;  // the caller may write through the pointer, now or later
-    *a = x->host.data();
+    *a = x->host.data() + x->off;
     return rc;
 }
 PetscErrorCode VecRestoreArray(Vec, PetscScalar **a) {  // nothing to copy: the next device use pushes the mirror
@@ -977,8 +1226,11 @@ PetscErrorCode VecRestoreArrays(const Vec[], PetscInt, PetscScalar **a[]) {
     }
     return 0;
 }
+// local numbering = PETSc's ghosted local numbering of the DMDA = the position in the stored slab.  An entry set on a
+// ghost node stays local: the owner sets the same entry itself (the reference's set-up loops run over all local nodes
+// on every rank, LinearElasticity.cc:148-172), which is what VecAssembly would deliver.
 PetscErrorCode VecSetValueLocal(Vec v, PetscInt row, PetscScalar value, InsertMode mode) {
-    if (row < 0 || row >= v->n) return PETSC_ERR_ARG_OUTOFRANGE;
+    if (row < 0 || row >= v->n_alloc) return PETSC_ERR_ARG_OUTOFRANGE;
     int rc = vec_pull(v);
     if (rc) return rc;
     if (v->d) v->dev_valid = false;
@@ -986,14 +1238,19 @@ PetscErrorCode VecSetValueLocal(Vec v, PetscInt row, PetscScalar value, InsertMo
     else v->host[(size_t)row] = value;
     return 0;
 }
-PetscErrorCode VecSetValue(Vec v, PetscInt row, PetscScalar value, InsertMode mode) { return VecSetValueLocal(v, row, value, mode); }
+PetscErrorCode VecSetValue(Vec v, PetscInt row, PetscScalar value, InsertMode mode) {  // global index
+    if (row < v->goff || row >= v->goff + v->n) return job_size() > 1 ? sup("VecSetValue on an entry of another rank") : PETSC_ERR_ARG_OUTOFRANGE;
+    return VecSetValueLocal(v, (PetscInt)(row - v->goff + v->off), value, mode);
+}
 PetscErrorCode VecAssemblyBegin(Vec) { return 0; }
 PetscErrorCode VecAssemblyEnd(Vec v) { return vec_push(v); }
 PetscErrorCode VecSetRandom(Vec v, PetscRandom r) {
-    v->host.resize((size_t)v->n);
-    for (long i = 0; i < v->n; i++) {  // drand48's linear congruential generator
+    int rc0 = vec_pull(v);
+    if (rc0) return rc0;
+    // drand48's linear congruential generator; one global sequence in natural order whatever the partition
+    for (long i = 0; i < v->nglob; i++) {
         r->state = (r->state * 0x5DEECE66DULL + 0xBULL) & ((1ULL << 48) - 1);
-        v->host[(size_t)i] = (double)r->state / (double)(1ULL << 48);
+        if (i >= v->goff && i < v->goff + v->n) v->host[(size_t)(i - v->goff + v->off)] = (double)r->state / (double)(1ULL << 48);
     }
     v->host_valid = true;
     v->dev_valid = false;
@@ -1007,15 +1264,23 @@ PetscErrorCode VecView(Vec v, PetscViewer w) {
         unsigned char b[4] = {(unsigned char)(x >> 24), (unsigned char)(x >> 16), (unsigned char)(x >> 8), (unsigned char)x};
         fwrite(b, 1, 4, w->fp);
     };
-    be32(1211214u);
-    be32((uint32_t)v->n);
+    // every rank writes its own part at its place (natural ordering = the slab order); rank 0 also the header
+    const long ng = v->is_local ? v->n : v->nglob, g0 = v->is_local ? 0 : v->goff;
+    fseek(w->fp, (long)w->pos, SEEK_SET);
+    if (job_rank() == 0 || v->is_local) {
+        be32(1211214u);
+        be32((uint32_t)ng);
+    }
+    fseek(w->fp, (long)(w->pos + 8 + 8 * g0), SEEK_SET);
     for (long i = 0; i < v->n; i++) {
         uint64_t u;
-        memcpy(&u, &v->host[(size_t)i], 8);
+        memcpy(&u, &v->host[(size_t)(v->off + i)], 8);
         unsigned char b[8];
         for (int k = 0; k < 8; k++) b[k] = (unsigned char)(u >> (56 - 8 * k));
         fwrite(b, 1, 8, w->fp);
     }
+    fflush(w->fp);
+    w->pos += 8 + 8 * ng;
     return 0;
 }
 PetscErrorCode VecLoad(Vec v, PetscViewer w) {
@@ -1026,14 +1291,19 @@ PetscErrorCode VecLoad(Vec v, PetscViewer w) {
         return true;
     };
     uint32_t cls, n;
-    if (!be32(&cls) || !be32(&n) || cls != 1211214u || (long)n != v->n) return 79;  // PETSC_ERR_FILE_UNEXPECTED
-    v->host.resize((size_t)v->n);
+    const long ng = v->is_local ? v->n : v->nglob, g0 = v->is_local ? 0 : v->goff;
+    fseek(w->fp, (long)w->pos, SEEK_SET);
+    if (!be32(&cls) || !be32(&n) || cls != 1211214u || (long)n != ng) return 79;  // PETSC_ERR_FILE_UNEXPECTED
+    int rc0 = vec_pull(v);
+    if (rc0) return rc0;
+    fseek(w->fp, (long)(w->pos + 8 + 8 * g0), SEEK_SET);
     for (long i = 0; i < v->n; i++) {
         if (fread(b, 1, 8, w->fp) != 8) return 79;
         uint64_t u = 0;
         for (int k = 0; k < 8; k++) u = (u << 8) | b[k];
-        memcpy(&v->host[(size_t)i], &u, 8);
+        memcpy(&v->host[(size_t)(v->off + i)], &u, 8);
     }
+    w->pos += 8 + 8 * ng;
     v->host_valid = true;
     v->dev_valid = false;
     return vec_push(v);
@@ -1047,7 +1317,10 @@ PetscErrorCode VecTopOptGetDevicePointer(Vec x, PetscScalar **d) {
 PetscErrorCode MatCreateAIJ(MPI_Comm, PetscInt m, PetscInt n, PetscInt, PetscInt, PetscInt, const PetscInt[], PetscInt,
                             const PetscInt[], Mat *A) {
     // the only AIJ matrix of the path: T (nodes x elements, PDEFilter.cc:143-170)
-    if (m != (PetscInt)((long)mesh.nx * mesh.ny * mesh.nz) || n != (PetscInt)((long)(mesh.nx - 1) * (mesh.ny - 1) * (mesh.nz - 1)))
+    // local sizes: this rank's owned nodes x owned elements
+    const int R = job_size(), r = job_rank();
+    const long ezl = (mesh.nz - 1) / R, own_planes = R == 1 ? mesh.nz : ezl + (r == 0 ? 1 : 0);
+    if (m != (PetscInt)((long)mesh.nx * mesh.ny * own_planes) || n != (PetscInt)((long)(mesh.nx - 1) * (mesh.ny - 1) * ezl))
         return sup("MatCreateAIJ: only the nodes x elements transfer matrix of the PDE filter");
     *A = mat_new(K_TMAT, nullptr, m, n, "topopt-elem2node");
     return 0;
@@ -1064,7 +1337,8 @@ PetscErrorCode MatSetValuesLocal(Mat A, PetscInt nrow, const PetscInt irow[], Pe
     case K_ELAST: {  // AssembleStiffnessMatrix, LinearElasticity.cc:510-524: ke = KE * dens, ADD_VALUES
         if (nrow != 24 || ncol != 24 || addv != ADD_VALUES) return sup("dof-3 matrix: 24x24 ADD_VALUES element blocks only");
         DMFull *d = F(A->dm);
-        const PetscInt ex = d->M - 1, ey = d->N - 1, ez = d->P - 1;
+        // local numbering: node planes counted from the first stored (ghost) plane, whose element layer is this rank's first
+        const PetscInt ex = d->M - 1, ey = d->N - 1, ez = (d->P - 1) / job_size();
         const PetscInt n0 = irow[0] / 3, i = n0 % d->M, j = (n0 / d->M) % d->N, k = n0 / (d->M * d->N);
         if (irow[0] % 3 || i >= ex || j >= ey || k >= ez || icol[0] != irow[0] || irow[3] != 3 * (n0 + 1))
             return sup("dof-3 matrix: rows are not the 24 dofs of a hexahedron in DMDA order");
@@ -1132,7 +1406,7 @@ PetscErrorCode MatDiagonalSet(Mat A, Vec D, InsertMode mode) {  // K += I - N, :
     int rc = VecSum(D, &sd);
     if (!rc) rc = VecSum(A->Nvec, &sn);
     if (rc) return rc;
-    if (sd + sn != (double)A->n_rows) return sup("MatDiagonalSet: the vector is not I - N");
+    if (sd + sn != (double)A->Nvec->nglob) return sup("MatDiagonalSet: the vector is not I - N");
     return 0;
 }
 PetscErrorCode MatMult(Mat A, Vec x, Vec y) {
@@ -1141,14 +1415,14 @@ PetscErrorCode MatMult(Mat A, Vec x, Vec y) {
     case K_ELAST: {
         int rc = ensure_elasticity(A);
         if (rc) return rc;
-        const double *px = din(x);
-        return tp_elasticity_apply(A->e, px, dout(y));
+        const double *px = binout(x);  // (the library refreshes the ghost planes of its input)
+        return tp_elasticity_apply(A->e, px, bout(y));
     }
     case K_EXT_ELAST:
         {
         if (!A->ext_assembled) return PETSC_ERR_ORDER;
-        const double *px = din(x);
-        return tp_elasticity_apply(A->e, px, dout(y));
+        const double *px = binout(x);
+        return tp_elasticity_apply(A->e, px, bout(y));
     }
     case K_CONE:
         {
@@ -1169,15 +1443,15 @@ PetscErrorCode MatMult(Mat A, Vec x, Vec y) {
     case K_HELM: {
         int rc = ensure_pdefilter(A);
         if (rc) return rc;
-        const double *px = din(x);
-        return tp_pdefilter_apply(A->f, px, dout(y));
+        const double *px = binout(x);
+        return tp_pdefilter_apply(A->f, px, bout(y));
     }
     case K_TMAT: {
         if (!g_last_helm) return PETSC_ERR_ORDER;
         int rc = ensure_pdefilter(g_last_helm);
         if (rc) return rc;
         const double *px = din(x);
-        return tp_pdefilter_elem_to_node(g_last_helm->f, px, dout(y));
+        return tp_pdefilter_elem_to_node(g_last_helm->f, px, bout(y));
     }
     default:
         return sup("MatMult on this matrix");
@@ -1191,7 +1465,7 @@ PetscErrorCode MatMultTranspose(Mat A, Vec x, Vec y) {
     if (x->n != A->n_rows || y->n != A->n_cols || !g_last_helm) return PETSC_ERR_ARG_WRONG;
     int rc = ensure_pdefilter(g_last_helm);
     if (rc) return rc;
-    const double *px = dinout(x);  // its ghost planes are refreshed
+    const double *px = binout(x);  // its ghost planes are refreshed
     return tp_pdefilter_node_to_elem(g_last_helm->f, px, dout(y));
 }
 PetscErrorCode MatDestroy(Mat *A) {
@@ -1303,8 +1577,8 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
     }
     if (A->kind == K_HELM) {
         {
-            const double *pb = din(b);
-            rc = tp_pdefilter_solve(A->f, pb, dinout(x));
+            const double *pb = bin(b);
+            rc = tp_pdefilter_solve(A->f, pb, binout(x));
         }
         if (!rc) rc = tp_filter_last_pde_its(A->f, &k->its, &k->rnorm);
         return rc;
@@ -1312,8 +1586,8 @@ PetscErrorCode KSPSolve(KSP k, Vec b, Vec x) {
     rc = tp_elasticity_set_tolerances(A->e, k->rtol, k->atol, k->dtol, k->maxits);
     if (rc) return rc;
     double bn = 0.0;
-    const double *pb = din(b);
-    return tp_elasticity_solve(A->e, pb, dinout(x), &k->its, &k->rnorm, &bn, nullptr, 0);
+    const double *pb = bin(b);
+    return tp_elasticity_solve(A->e, pb, binout(x), &k->its, &k->rnorm, &bn, nullptr, 0);
 }
 PetscErrorCode KSPGetIterationNumber(KSP k, PetscInt *its) {
     *its = k->its;
@@ -1415,7 +1689,7 @@ PetscErrorCode MatCreateTopOptElasticity(DM da, PetscScalar nu, PetscInt nlvls, 
     tp_solver_default_opts(&o);
     o.nlvls = nlvls;
     o.nu = nu;
-    const long n = 3L * d->M * d->N * d->P;
+    const long n = 3L * d->M * d->N * zbox(d, 0).zm;
     Mat A = mat_new(K_EXT_ELAST, da, n, n, "topopt-elasticity");
     rc = tp_elasticity_create(&A->e, mesh.g, &o);
     if (rc) {
@@ -1428,12 +1702,13 @@ PetscErrorCode MatCreateTopOptElasticity(DM da, PetscScalar nu, PetscInt nlvls, 
 PetscErrorCode MatTopOptCantilever(Mat K, Vec N, Vec RHS) {
     if (!K || K->kind != K_EXT_ELAST || N->n != K->n_rows || RHS->n != K->n_rows) return PETSC_ERR_ARG_WRONG;
     K->have_bc = true;
-    return tp_elasticity_cantilever(K->e, dout(N), dout(RHS));  // also registers N
+    return tp_elasticity_cantilever(K->e, bout(N), bout(RHS));  // also registers N
 }
 PetscErrorCode MatTopOptSetDirichlet(Mat K, Vec N) {
     if (!K || K->kind != K_EXT_ELAST || N->n != K->n_rows) return PETSC_ERR_ARG_WRONG;
     K->have_bc = true;
-    return tp_elasticity_set_bc(K->e, din(N));
+    int rc = job_size() > 1 ? tp_grid_halo_nodes(mesh.g, binout(N), 3) : 0;
+    return rc ? rc : tp_elasticity_set_bc(K->e, bin(N));
 }
 PetscErrorCode MatTopOptAssemble(Mat K, Vec xPhys, PetscScalar Emin, PetscScalar Emax, PetscScalar penal) {
     if (!K || K->kind != K_EXT_ELAST) return PETSC_ERR_ARG_WRONG;
@@ -1445,7 +1720,7 @@ PetscErrorCode MatTopOptComplianceSensitivity(Mat K, Vec U, Vec xPhys, PetscScal
                                               PetscScalar penal, PetscScalar volfrac, PetscScalar *fx, PetscScalar *gx,
                                               Vec dfdx, Vec dgdx) {
     if (!K || (K->kind != K_EXT_ELAST && K->kind != K_ELAST) || !K->e) return PETSC_ERR_ARG_WRONG;
-    const double *pu = dinout(U), *px = din(xPhys);
+    const double *pu = binout(U), *px = din(xPhys);
     return tp_elasticity_objective(K->e, pu, px, Emin, Emax, penal, volfrac, fx, gx, dfdx ? dout(dfdx) : nullptr,
                                    dgdx ? dout(dgdx) : nullptr);
 }
@@ -1467,7 +1742,8 @@ PetscErrorCode MatCreateTopOptFilter(DM da, PetscInt filterType, PetscScalar R, 
         return rc;
     }
     if (Hs) {
-        rc = vec_create(nel, false, nullptr, Hs);
+        const long per = (long)(d->M - 1) * (d->N - 1);
+        rc = vec_create_layout(nel, 0, nel, per * (d->P - 1), per * ((d->P - 1) / job_size()) * job_rank(), job_size() == 1, false, nullptr, Hs);
         if (!rc) rc = filterType == 2 ? VecSet(*Hs, 1.0) : tp_filter_get_hs(A->f, dout(*Hs));
     }
     *H = A;

@@ -34,8 +34,10 @@ int main(int argc, char **argv) {
     DMSetUp(da_nodes);
     DMDASetUniformCoordinates(da_nodes, 0.0, ex * h, 0.0, ey * h, 0.0, ez * h);
     DMDASetElementType(da_nodes, DMDA_ELEMENT_Q1);
+    PetscInt md, nd, pd;  // the element mesh lives on the process grid of the node mesh (TopOpt.cc:254-290)
+    DMDAGetInfo(da_nodes, NULL, NULL, NULL, NULL, &md, &nd, &pd, NULL, NULL, NULL, NULL, NULL, NULL);
     ierr = DMDACreate3d(PETSC_COMM_WORLD, DM_BOUNDARY_NONE, DM_BOUNDARY_NONE, DM_BOUNDARY_NONE, DMDA_STENCIL_BOX, ex, ey, ez,
-                        1, 1, 1, 1, 0, 0, 0, 0, &da_elem);
+                        md, nd, pd, 1, 0, 0, 0, 0, &da_elem);
     CHKERRQ(ierr);
     DMSetUp(da_elem);
     Vec x, xTilde, xPhys, dfdx, dgdx;
@@ -49,13 +51,16 @@ int main(int argc, char **argv) {
         PetscScalar *xp;
         VecGetArray(x, &xp);
         const double pi = 3.14159265358979323846;
-        for (PetscInt k = 0; k < ez; k++)
-            for (PetscInt j = 0; j < ey; j++)
-                for (PetscInt i = 0; i < ex; i++) {
+        PetscInt xs, ys, zs, xm, ym, zm;  // this rank's elements
+        DMDAGetCorners(da_elem, &xs, &ys, &zs, &xm, &ym, &zm);
+        long at = 0;
+        for (PetscInt k = zs; k < zs + zm; k++)
+            for (PetscInt j = ys; j < ys + ym; j++)
+                for (PetscInt i = xs; i < xs + xm; i++) {
                     const uint64_t gid = (uint64_t)i + (uint64_t)ex * ((uint64_t)j + (uint64_t)ey * (uint64_t)k);
                     double v = 0.12 + 0.4 * sin(7 * pi * (i + 0.5) * h) * sin(5 * pi * (j + 0.5) * h) * sin(3 * pi * (k + 0.5) * h) +
                                0.3 * (hash_u01(gid, 12345) - 0.5);
-                    xp[gid] = v < 1e-3 ? 1e-3 : (v > 1.0 ? 1.0 : v);
+                    xp[at++] = v < 1e-3 ? 1e-3 : (v > 1.0 ? 1.0 : v);
                 }
         VecRestoreArray(x, &xp);
     }
@@ -78,7 +83,8 @@ int main(int argc, char **argv) {
     VecSum(dgdx, &sdg);
     VecSum(xPhys, &sxp);
     VecNorm(physics->GetStateField(), NORM_2, &un);
-    printf("REF_ON_SHIM fx %.16e gx %.16e sum_dfdx %.16e sum_dgdx %.16e sum_xphys %.16e normU %.16e\n", fx, gx, sdf, sdg, sxp, un);
+    PetscInt its = 0;
+    PetscPrintf(PETSC_COMM_WORLD, "REF_ON_SHIM fx %.16e gx %.16e sum_dfdx %.16e sum_dgdx %.16e sum_xphys %.16e normU %.16e\n", fx, gx, sdf, sdg, sxp, un);
     delete filter;
     delete physics;
     VecDestroy(&x);

@@ -59,6 +59,7 @@ typedef enum { PETSC_FALSE, PETSC_TRUE } PetscBool;
 #define MPIU_REAL MPI_DOUBLE
 #define MPIU_INT MPI_INT
 #define PETSC_ERR_SUP 56
+#define PETSC_ERR_LIB 76
 #define PETSC_ERR_ORDER 58
 #define PETSC_ERR_ARG_OUTOFRANGE 63
 #define PETSC_ERR_ARG_WRONG 62

@@ -107,6 +107,9 @@ long tp_grid_local_elems(const tp_grid *g);     /* own elements */
 long tp_grid_owned_node_offset(const tp_grid *g); /* first owned node in the local array */
 long tp_grid_owned_nodes(const tp_grid *g);
 int tp_grid_node_z0(const tp_grid *g);          /* global z index of local node plane 0 */
+/* refresh the ghost node planes of a slab-local nodal array with `dof` values per node (DMGlobalToLocalBegin/End,
+ * LinearElasticity.cc:249-250); a no-op on one rank */
+int tp_grid_halo_nodes(tp_grid *g, double *v, int dof);
 int tp_grid_elem_z0(const tp_grid *g);          /* global z index of local element layer 0 */
 
 /* ---- optional: the slab exchange issued directly to RCCL -------------------------------------

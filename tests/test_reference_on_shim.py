@@ -125,3 +125,63 @@ def test_whole_reference_program_unchanged_on_the_gpu_path(tmp_path):
     # the result container the reference's MPIIO wrote through the compat MPI-IO has the documented layout
     out = os.path.join(str(tmp_path), "output_00000.dat")
     assert os.path.exists(out) and open(out, "rb").read(26) == b"TopOpt result version 1.1\n"
+
+
+def _petsc_vecs(path):
+    """all Vecs of a PETSc binary file: big-endian (classid 1211214, n, n doubles)"""
+    raw = open(path, "rb").read()
+    out, at = [], 0
+    while at < len(raw):
+        cls, n = np.frombuffer(raw, dtype=">i4", count=2, offset=at)
+        assert cls == 1211214
+        out.append(np.frombuffer(raw, dtype=">f8", count=int(n), offset=at + 8).astype(np.float64))
+        at += 8 + 8 * int(n)
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(TOPOPT_REF), reason="host/_refbuild/topopt_ref not built (build container only)")
+def test_whole_reference_program_on_slab_ranks(tmp_path):
+    """The reference's whole program, unchanged, as 2 and 4 processes (host/slabrun; the compat layer's MPI is the
+    shared-memory job of host/slab_comm.h, its DMDA a 1 x 1 x R process grid of z-slabs with PETSc's ownership and
+    ghost ranges, its Vecs the library's slab arrays): same optimisation history as one process, the same restart
+    vectors (design, MMA history, state) in natural ordering, and a result container."""
+    run = os.path.join(ROOT, "host", "slabrun")
+    nit, hist, vecs = 3, {}, {}
+    for n in (1, 2, 4):
+        wd = tmp_path / ("r%d" % n)
+        wd.mkdir()
+        r = subprocess.run([run, "-n", str(n), "--same-device", TOPOPT_REF, "-nx", "65", "-ny", "33", "-nz", "33", "-maxItr", str(nit)] + OPTS,
+                           capture_output=True, text=True, timeout=600, cwd=str(wd))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        lines = [re.sub(r"time: .*", "", ln) for ln in r.stdout.splitlines() if ln.startswith(("It.:", "State solver"))]
+        assert len(lines) == 2 * nit, r.stdout[-3000:]
+        hist[n] = [[float(v) for v in re.findall(r"-?\d+\.?\d*(?:[eE][+-]?\d+)?", ln)] for ln in lines]
+        vecs[n] = _petsc_vecs(str(wd / "Restart00.dat")) + _petsc_vecs(str(wd / "RestartSol00.dat"))
+        assert open(str(wd / "output_00000.dat"), "rb").read(26) == b"TopOpt result version 1.1\n"
+    for n in (2, 4):
+        for a, b in zip(hist[n], hist[1]):
+            assert a == pytest.approx(b, rel=2e-5, abs=2e-6), (n, a, b)
+        assert len(vecs[n]) == len(vecs[1]) and len(vecs[1]) >= 4
+        for a, b in zip(vecs[n], vecs[1]):
+            assert a.shape == b.shape
+            assert np.abs(a - b).max() <= 1e-7 * max(np.abs(b).max(), 1e-30), n
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(BIN), reason="host/_refbuild/ref_on_shim not built (build container only)")
+@pytest.mark.parametrize("filt", [1, 2])
+def test_reference_classes_on_slab_ranks(filt):
+    """The reference's LinearElasticity / Filter / PDEFilt classes on a synthetic design, 1 against 2 and 4 ranks:
+    objective, constraint, sensitivity sums and ||U|| to 1e-10."""
+    run = os.path.join(ROOT, "host", "slabrun")
+    vals = {}
+    for n in (1, 2, 4):
+        r = subprocess.run([run, "-n", str(n), "--same-device", BIN, "32", "16", "16", str(filt), "-nlvls", "3"], capture_output=True,
+                           text=True, timeout=300, env=dict(os.environ, PETSC_OPTIONS=" ".join(OPTS)))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        m = re.search(r"REF_ON_SHIM fx (\S+) gx (\S+) sum_dfdx (\S+) sum_dgdx (\S+) sum_xphys (\S+) normU (\S+)", r.stdout)
+        assert m, r.stdout[-2000:]
+        vals[n] = [float(v) for v in m.groups()]
+    for n in (2, 4):
+        assert vals[n] == pytest.approx(vals[1], rel=1e-10)

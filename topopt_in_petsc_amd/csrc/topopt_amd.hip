@@ -271,6 +271,10 @@ extern "C" long tp_grid_owned_node_offset(const tp_grid *g) {
 extern "C" long tp_grid_owned_nodes(const tp_grid *g) { return make_geom(g, 0).owned_nodes(); }
 extern "C" int tp_grid_node_z0(const tp_grid *g) { return make_geom(g, 0).gz0; }
 extern "C" int tp_grid_elem_z0(const tp_grid *g) { return g->rank * g->ez_own; }
+extern "C" int tp_grid_halo_nodes(tp_grid *g, double *v, int dof) {
+    if (!g || !v || dof < 1) return TP_ERR_ARG;
+    return halo_nodes(g, make_geom(g, 0), v, dof);
+}
 
 extern "C" int tp_set_device(int device) {
     TP_HIP(hipSetDevice(device));

@@ -67,6 +67,7 @@ SYMBOLS = {
     "tp_grid_owned_node_offset": (_l, [_vp]),
     "tp_grid_owned_nodes": (_l, [_vp]),
     "tp_grid_node_z0": (_i, [_vp]),
+    "tp_grid_halo_nodes": (_i, [_vp, _vp, C.c_int]),
     "tp_grid_elem_z0": (_i, [_vp]),
     "tp_set_device": (_i, [C.c_int]),
     "tp_malloc": (_i, [C.POINTER(_vp), C.c_size_t]),
