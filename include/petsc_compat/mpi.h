@@ -1,6 +1,8 @@
-/* mpi.h (compat) -- the single-process subset of MPI that TopOpt_in_PETSc touches outside PETSc: reductions on one
- * rank (identity), timers, and the MPI-IO calls of MPIIO.cc (file views with byte displacement and vector
- * filetypes).  One process per GPU; the multi-GPU path of the MI355X library is tp_comm / RCCL (topopt_amd.h). */
+/* mpi.h (compat) -- the subset of MPI that TopOpt_in_PETSc touches outside PETSc: rank / size, barriers, reductions and
+ * gathers over the ranks of ONE node (a shared-memory job started by host/slabrun: host/slab_comm.h; no MPI library is
+ * involved), timers, and the MPI-IO calls of MPIIO.cc (file views with byte displacement and vector filetypes; every
+ * rank writes through its own view into the same file).  One process per GPU; the slab exchange of the MI355X library
+ * itself is tp_comm / RCCL (topopt_amd.h). */
 #ifndef TOPOPT_MPI_COMPAT_H
 #define TOPOPT_MPI_COMPAT_H
 #include <stddef.h>

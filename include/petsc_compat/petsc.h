@@ -4,15 +4,17 @@
  *
  * Put  -I include/petsc_compat  where a PETSc build would put  -I $PETSC_DIR/include : ALL EIGHT sources of the
  * reference (main.cc, TopOpt.cc, MMA.cc, MPIIO.cc and the three hot-path classes) compile UNCHANGED against this
- * header and the single-process mpi.h beside it (host/build_ref_on_shim.sh and tests/test_reference_on_shim.py do
+ * header and the small mpi.h beside it (host/build_ref_on_shim.sh and tests/test_reference_on_shim.py do
  * exactly that, in the build container, storing nothing), and the resulting program runs the reference's
  * optimisation loop on the GPU.  Same names, argument order, ownership rules (XxxDestroy nulls the handle,
  * reference counted where the reference relies on it: PCMGSetInterpolation / KSPSetOperators retain) and error
  * convention (PetscErrorCode, 0 = success, CHKERRQ = return on non-zero).
  *
  * What is different behind the names:
- *  - one process per call sequence, one GPU (the z-slab multi-GPU path is the tp_comm / RCCL interface of
- *    topopt_amd.h); MPI_Allreduce on PETSC_COMM_WORLD is the identity;
+ *  - one process per GPU.  host/slabrun -n R starts R ranks of the program on one node; MPI_* is a shared-memory job
+ *    (host/slab_comm.h), a DMDA is split into R z-slabs (1 x 1 x R process grid, PETSc's ownership and ghost ranges),
+ *    nodal Vecs are the library's slab arrays (global vector = the owned window, local vector = the whole slab), the
+ *    halo exchange underneath is host-staged or, with a GPU per rank, RCCL inside the library (topopt_amd.h);
  *  - Vec data lives in HBM; VecGetArray lends a host mirror (copied down, copied back on VecRestoreArray);
  *  - Mat is never assembled.  MatSetValuesLocal is a CAPTURE: the 24x24 element matrices of
  *    AssembleStiffnessMatrix (LinearElasticity.cc:510-524) must be multiples of one matrix -- the multiplier
@@ -47,7 +49,7 @@ typedef double PetscScalar;
 typedef double PetscReal;
 typedef double PetscLogDouble;
 typedef enum { PETSC_FALSE, PETSC_TRUE } PetscBool;
-#include <mpi.h> /* the single-process MPI subset of this directory */
+#include <mpi.h> /* the MPI subset of this directory (one node, shared memory: host/slab_comm.h) */
 #define PETSC_COMM_WORLD MPI_COMM_WORLD
 #define PETSC_COMM_SELF MPI_COMM_SELF
 #define PETSC_DECIDE (-1)
