@@ -118,9 +118,10 @@ inline int hook_allgather(void *u, long n) {
 }
 }  // namespace slab_detail
 
-// Joins the job described by TP_RANK / TP_NRANKS / TP_SHM (absent: a one-rank job) and allocates the staging buffers
-// for messages of up to `cap` doubles.  Returns 0, or an error code after a message on stderr.
-inline int slab_comm_init(SlabComm *c, long cap) {
+// Joins the job described by TP_RANK / TP_NRANKS / TP_SHM (absent: a one-rank job): mailboxes of `cap` doubles per
+// half, no device memory yet (this much runs without a GPU: host/slab_selftest.cc).  Returns 0, or an error code after a
+// message on stderr.
+inline int slab_comm_join(SlabComm *c, long cap) {
     const char *er = getenv("TP_RANK"), *en = getenv("TP_NRANKS"), *es = getenv("TP_SHM"), *ed = getenv("TP_DEVICE");
     c->rank = er ? atoi(er) : 0;
     c->nranks = en ? atoi(en) : 1;
@@ -186,6 +187,13 @@ inline int slab_comm_init(SlabComm *c, long cap) {
         one.slot_doubles = cap;
         c->hdr = &one;
     }
+    c->hooks.cap = cap;
+    return 0;
+}
+// ... and allocates the device staging buffers of the tp_comm hooks on the rank's GPU
+inline int slab_comm_init(SlabComm *c, long cap) {
+    if (slab_comm_join(c, cap)) return 1;
+    cap = c->hooks.cap;
     const size_t nd = 4 * (size_t)cap + 16 + (size_t)c->nranks * (size_t)cap;
     if (tp_set_device(c->device) || tp_malloc((void **)&c->dev_buf, sizeof(double) * nd)) return 1;
     tp_comm &h = c->hooks;

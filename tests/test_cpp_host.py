@@ -38,6 +38,27 @@ def test_cpp_driver_matches_python_driver():
     assert "# final volume fraction 0.1" in out.stdout
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 5])
+def test_slab_job_shared_memory_selftest(n):
+    """N > 1 on the CPU: host/slabrun starts n processes that meet in the shared-memory segment of host/slab_comm.h and
+    push rank-tagged data through its barrier, its rank-ordered reductions and its mailboxes (200 rounds)."""
+    _build()
+    out = subprocess.run([os.path.join(ROOT, "host", "slabrun"), "-n", str(n), os.path.join(ROOT, "host", "slab_selftest")],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert sorted(out.stdout.split("\n")[:-1]) == ["rank %d of %d OK" % (r, n) for r in range(n)]
+
+
+def test_slab_job_dead_rank_does_not_hang(tmp_path):
+    """a rank that dies takes the job down: slabrun returns its failure instead of waiting for the survivors"""
+    _build()
+    sh = tmp_path / "r.sh"
+    sh.write_text("#!/bin/bash\nif [ \"$TP_RANK\" = 1 ]; then exit 7; fi\nexec %s\n" % os.path.join(ROOT, "host", "slab_selftest"))
+    sh.chmod(0o755)
+    out = subprocess.run([os.path.join(ROOT, "host", "slabrun"), "-n", "3", str(sh)], capture_output=True, text=True, timeout=200)
+    assert out.returncode == 7, (out.returncode, out.stdout, out.stderr)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("filt", [1, 2])
 def test_cpp_driver_slab_ranks_match_one_rank(filt):
