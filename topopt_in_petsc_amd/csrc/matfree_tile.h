@@ -511,8 +511,13 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
 #pragma unroll
             for (int m = 0; m < 4; m++) {
                 const double sum = f[c][m] + f[c][m + 4], dif = f[c][m] - f[c][m + 4];
-                P[c][m] = fma(Ee, sum, Cy[c][m]);
-                Cy[c][m] = Ee * dif;
+                if (MACRO) {  // the children's moduli are inside f already (all zero for an element outside the domain)
+                    P[c][m] = sum + Cy[c][m];
+                    Cy[c][m] = dif;
+                } else {
+                    P[c][m] = fma(Ee, sum, Cy[c][m]);
+                    Cy[c][m] = Ee * dif;
+                }
             }
         double s0[3], s1[3];
 #pragma unroll
