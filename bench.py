@@ -136,6 +136,11 @@ def main():
     import torch.distributed as dist
     import topopt_in_petsc_amd as tp
 
+    # stdout carries ONE line, the JSON: whatever libraries print there (gloo's connection notes, RCCL's version banner)
+    # goes to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -305,7 +310,8 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.cpu_sample, a.rtol, a.fine_eig, ndof)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         # orderly teardown: solver objects (and the library's own RCCL communicator) go before the process group,
         # on all ranks together
