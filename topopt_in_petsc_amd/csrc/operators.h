@@ -218,20 +218,22 @@ __global__ __launch_bounds__(BLK) void k_restrict(Geom gc, Geom gf, const double
     double s[DOF];
 #pragma unroll
     for (int r = 0; r < DOF; r++) s[r] = 0.0;
+    // branch-free: a neighbour outside the array is read at the centre node with weight 0 (fma(0, v, s) = s: the same
+    // bits as skipping it), so that all 27 x DOF loads are in flight at once instead of one round trip per branch
 #pragma unroll
     for (int dk = -1; dk <= 1; dk++) {
         const int k = 2 * K + dk;
-        if (k < 0 || k >= gf.nzl) continue;
+        const bool okk = k >= 0 && k < gf.nzl;
 #pragma unroll
         for (int dj = -1; dj <= 1; dj++) {
             const int j = 2 * J + dj;
-            if (j < 0 || j >= gf.ny) continue;
+            const bool okj = okk && j >= 0 && j < gf.ny;
 #pragma unroll
             for (int di = -1; di <= 1; di++) {
                 const int i = 2 * I + di;
-                if (i < 0 || i >= gf.nx) continue;
-                const double w = (di ? 0.5 : 1.0) * (dj ? 0.5 : 1.0) * (dk ? 0.5 : 1.0);
-                const long nf = (long)i + (long)gf.nx * (j + (long)gf.ny * k);
+                const bool ok = okj && i >= 0 && i < gf.nx;
+                const double w = ok ? (di ? 0.5 : 1.0) * (dj ? 0.5 : 1.0) * (dk ? 0.5 : 1.0) : 0.0;
+                const long nf = ok ? (long)i + (long)gf.nx * (j + (long)gf.ny * k) : (long)(2 * I) + (long)gf.nx * (2 * J + (long)gf.ny * (2 * K));
 #pragma unroll
                 for (int r = 0; r < DOF; r++) s[r] = fma(w, rf[nf * DOF + r], s[r]);
             }
