@@ -209,7 +209,11 @@ __global__ __launch_bounds__(BLK) void k_restrict(Geom gc, Geom gf, const double
                                                   double inv_theta = 0.0, long t0 = 0, long tn = -1) {
     // owned coarse nodes [t0, t0 + tn) counted from the first owned plane (tn < 0: all)
     const long plane = gc.plane();
-    const long t = t0 + blockIdx.x * (long)BLK + threadIdx.x;
+    // workgroups are dealt round-robin to the 8 XCDs: give every XCD a contiguous run of coarse nodes, so that the fine
+    // planes two neighbouring coarse planes share are fetched into ONE L2
+    const int nbk = gridDim.x, x8 = blockIdx.x & 7;
+    const long bid = (long)x8 * (nbk >> 3) + min(x8, nbk & 7) + (blockIdx.x >> 3);
+    const long t = t0 + bid * (long)BLK + threadIdx.x;
     if (t >= (tn < 0 ? gc.owned_nodes() : t0 + tn)) return;
     const int K = gc.own_lo + (int)(t / plane);
     const int rem = (int)(t % plane);
