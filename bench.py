@@ -31,6 +31,7 @@ WORKLOADS = {
     "cube256": (256, 256, 256, 4),         # north-star SpMV target mesh
     "c3": (256, 128, 128, 4),              # configs[2] on ONE GPU (12.8 M DOF); with --gpus 8: 256x128x(128*8)
     "c4": (192, 64, 64, 3, 2, "mbb"),      # configs[3]: MBB beam, Helmholtz (PDE) filter
+    "c5": (512, 256, 256, 4),              # configs[4] on ONE GPU (101.7 M DOF, ~35 GB of the 288 GB); with --gpus 8 --scaling strong: its slabs
     "tiny": (32, 16, 16, 3),
 }
 

@@ -97,6 +97,7 @@ CONFIGS = {
     "C4_192x64x64_mbb_pde": (192, 64, 64, 3, 2, "mbb"),
     "C3_256x128x128_one_gpu": (256, 128, 128, 4, 1, "cantilever"),
     "metric_128cubed": (128, 128, 128, 4, 1, "cantilever"),
+    "C5_512x256x256_one_gpu": (512, 256, 256, 4, 1, "cantilever"),   # 101.6 M DOF, ~35 GB of the 288 GB
 }
 
 
