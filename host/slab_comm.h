@@ -233,7 +233,16 @@ inline void slab_comm_try_rccl(SlabComm *c, tp_grid *g) {
     if (got == 0.0) return;
     memcpy(id, c->mailbox(0, 1), sizeof(id));
     c->barrier();
-    (void)tp_grid_use_rccl(g, id);  // collective; falls back to the hooks above on every rank if one rank fails
+    // every rank takes the same decision: the communicator must exist everywhere, and rank-tagged planes through the new
+    // path must arrive where they belong -- else all ranks return to the mailboxes
+    double good = tp_grid_use_rccl(g, id) == 0 ? 1.0 : 0.0;
+    slab_detail::host_reduce(c, &good, 1, 2);
+    if (good != 0.0) {
+        int ok = 0;
+        good = (tp_grid_comm_selfcheck(g, &ok) == 0 && ok == 1) ? 1.0 : 0.0;
+        slab_detail::host_reduce(c, &good, 1, 2);
+    }
+    if (good == 0.0) (void)tp_grid_drop_rccl(g);
 }
 
 inline void slab_comm_free(SlabComm *c) {

@@ -108,8 +108,10 @@ class Grid:
         rc = self.L.tp_grid_use_rccl(self.handle, idb)
         flag = torch.tensor([1 if rc == 0 else 0], device=self.device, dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-        if int(flag[0]) == 0:
-            raise TopOptError(rc or 4, "tp_grid_use_rccl (some rank could not create its communicator)")
+        if int(flag[0]) == 0:   # some rank could not create its communicator: every rank goes back to the hooks
+            self.L.tp_grid_drop_rccl(self.handle)
+            print("topopt_amd: tp_grid_use_rccl failed on a rank; using the torch.distributed hooks", flush=True)
+            return
         # trust, but verify: rank-tagged planes through the new path; any rank unhappy -> everybody back to the hooks
         ok = C.c_int(0)
         rc = self.L.tp_grid_comm_selfcheck(self.handle, C.byref(ok))
