@@ -131,6 +131,8 @@ def fine_kernel_times(tp, torch, ex, ey, ez, reps):
 
 def main():
     a = parse()
+    # multi-process GPU work on this driver stack needs dmabuf IPC (RCCL / tensor sharing fail with the legacy mode)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         respawn_under_torchrun(a.gpus)
     import torch

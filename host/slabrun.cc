@@ -46,6 +46,7 @@ int main(int argc, char **argv) {
             setenv("TP_NRANKS", std::to_string(n).c_str(), 1);
             setenv("TP_SHM", shm.c_str(), 1);
             setenv("TP_DEVICE", same ? "0" : std::to_string(r).c_str(), 1);
+            setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);  // dmabuf IPC: what RCCL across processes needs on this driver stack
             execvp(argv[a], argv + a);
             perror("execvp");
             _exit(127);
