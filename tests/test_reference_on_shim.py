@@ -185,3 +185,24 @@ def test_reference_classes_on_slab_ranks(filt):
         vals[n] = [float(v) for v in m.groups()]
     for n in (2, 4):
         assert vals[n] == pytest.approx(vals[1], rel=1e-10)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(TOPOPT_REF), reason="host/_refbuild/topopt_ref not built (build container only)")
+@pytest.mark.parametrize("filt", [0, 2])
+def test_whole_reference_program_other_filters_on_two_ranks(tmp_path, filt):
+    """-filter 0 (sensitivity filter) and -filter 2 (Helmholtz PDE filter: the reference's PDEFilt with its own KSP and
+    the MatCreateAIJ'ed element-to-node matrix) through the unchanged program on 2 slab processes = on one."""
+    run = os.path.join(ROOT, "host", "slabrun")
+    hist = {}
+    for n in (1, 2):
+        wd = tmp_path / ("r%d" % n)
+        wd.mkdir()
+        r = subprocess.run([run, "-n", str(n), "--same-device", TOPOPT_REF, "-nx", "65", "-ny", "33", "-nz", "33", "-filter", str(filt),
+                            "-maxItr", "3"] + OPTS, capture_output=True, text=True, timeout=600, cwd=str(wd))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        lines = [re.sub(r"time: .*", "", ln) for ln in r.stdout.splitlines() if ln.startswith(("It.:", "State solver"))]
+        assert len(lines) == 6, r.stdout[-3000:]
+        hist[n] = [[float(v) for v in re.findall(r"-?\d+\.?\d*(?:[eE][+-]?\d+)?", ln)] for ln in lines]
+    for a, b in zip(hist[2], hist[1]):
+        assert a == pytest.approx(b, rel=2e-5, abs=2e-6), (a, b)
