@@ -221,4 +221,5 @@ def test_graphed_coarsest_smoothing_bits(tp):
     for k in range(2):
         assert np.array_equal(res[0][k][0], res[1][k][0]) and np.array_equal(res[0][k][0], res[2][k][0])
         assert res[0][k][1] == res[1][k][1] and res[0][k][1] > 4
-        assert res[1][k][2] < res[0][k][2], (res[1][k][2], res[0][k][2])
+        if not os.environ.get("TP_DEBUG_SYNC"):   # (per-launch synchronisation switches graph replay off)
+            assert res[1][k][2] < res[0][k][2], (res[1][k][2], res[0][k][2])
