@@ -406,3 +406,40 @@ def test_mesh_shape_sweep(tp, orc, ex, ey, ez, nlv):
         f.FilterProject(dev(x), xt, xp)
         xto, xpo = of.project(1, x)
         assert rel(host(xt), xto) <= 1e-13
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,frac", [(1, 0.02), (2, 0.15), (3, 0.002)])
+def test_random_dirichlet_sets(tp, orc, seed, frac):
+    """Clamped dofs scattered at random (single components, interior nodes, whole clusters): nearly every level-1
+    element near them takes the stored-correction path and most fine tiles the masked instantiation -- every level
+    operator and the solve against the oracle with the same N."""
+    ex, ey, ez, nlv = 32, 16, 24, 3
+    nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
+    rng = np.random.default_rng(seed)
+    N = np.ones(3 * nx * ny * nz)
+    N[rng.random(N.size) < frac] = 0.0                      # single components anywhere
+    nodes = rng.integers(0, nx * ny * nz, size=max(3, int(20 * frac * 50)))
+    for n in nodes:                                         # some fully clamped nodes
+        N[3 * n: 3 * n + 3] = 0.0
+    N[: 3 * nx].reshape(-1, 3)[:, :] = 0.0                  # and one clamped edge, so that the operator is definite
+    R = rng.standard_normal(N.size) * 1e-3
+    grid = tp.Grid(nx, ny, nz, h)
+    le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=nlv, rtol=1e-9))
+    le.SetBC(dev(N), dev(R))
+    x = orc.synth_density(ex, ey, ez, h)
+    KE = orc.hex8_ke_box(h, h, h, 0.3)
+    mg = orc.MG(nx, ny, nz, 3, nlv)
+    mg.assemble(KE, orc.simp(x), N)
+    le.AssembleStiffnessMatrix(dev(x), 1e-9, 1.0, 3.0)
+    u = rng.standard_normal(mg.n)
+    for l in range(nlv):
+        ul = u[: mg.size(l)]
+        assert rel(host(le.level_apply(l, dev(ul))), mg.apply(l, ul)) <= 1e-13, l
+        assert le.level_lambda(l) == pytest.approx(mg.lam(l), rel=1e-9)
+    its = le.KSPSolve(hist_cap=400)
+    Uo, its_o, hist_o = mg.solve(R * N, rtol=1e-9, maxit=400)
+    assert its == its_o
+    assert rel(host(le.U), Uo) <= 1e-7
+    k = min(10, its)
+    assert np.abs(le.last_hist[:k] / hist_o[:k] - 1).max() <= 1e-8
