@@ -182,12 +182,52 @@ def gpu_mode(rank, world):
           (rank, its, grid.comm.n_exchanges, grid.comm.n_allreduces, grid.halo_overlap), flush=True)
 
 
+def gpu_randbc_mode(rank, world):
+    """randomly scattered Dirichlet dofs on slabs: flagged level-1 elements on both sides of every slab boundary (compact
+    ghost rows of the correction, masks on ghost planes) -- level operators and the solve against the serial oracle"""
+    import topopt_in_petsc_amd as tp
+    torch.cuda.set_device(0)
+    ex, ey, ez, nlv = [int(v) for v in sys.argv[2:6]] if len(sys.argv) >= 6 else (16, 8, 16, 3)
+    nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
+    rng = np.random.default_rng(11)
+    N = np.ones(3 * nx * ny * nz)
+    N[rng.random(N.size) < 0.03] = 0.0
+    for n in rng.integers(0, nx * ny * nz, size=40):
+        N[3 * n: 3 * n + 3] = 0.0
+    N[: 3 * nx] = 0.0
+    R = rng.standard_normal(N.size) * 1e-3
+    grid = tp.Grid(nx, ny, nz, h, rank=rank, nranks=world)
+    part = grid.part
+    gs, own = part.global_slice(3), part.owned_slice(3)
+    le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=nlv, rtol=1e-9, max_it=400))
+    le.SetBC(torch.from_numpy(N[gs].copy()).cuda(), torch.from_numpy(R[gs].copy()).cuda())
+    xo = orc.synth_density(ex, ey, ez, h)
+    le.AssembleStiffnessMatrix(torch.from_numpy(xo[part.global_elem_slice()].copy()).cuda(), 1e-9, 1.0, 3.0)
+    KE = orc.hex8_ke_box(h, h, h, 0.3)
+    mg = orc.MG(nx, ny, nz, 3, nlv)
+    mg.assemble(KE, orc.simp(xo), N)
+    rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
+    for l in range(nlv):
+        pl = part.level(l)
+        ug = rng.standard_normal(mg.size(l))
+        yg = mg.apply(l, ug)
+        yl = le.level_apply(l, torch.from_numpy(ug[pl.global_slice(3)].copy()).cuda()).cpu().numpy()
+        assert rel(yl[pl.owned_slice(3)], yg[pl.global_slice(3)][pl.owned_slice(3)]) <= 1e-12, l
+        assert abs(le.level_lambda(l) / mg.lam(l) - 1) <= 1e-9
+    its = le.KSPSolve(hist_cap=400)
+    U, its_o, hist = mg.solve(R * N, rtol=1e-9, maxit=400)
+    assert its == its_o, (its, its_o)
+    assert np.abs(le.last_hist[:10] / hist[:10] - 1).max() <= 1e-8
+    assert rel(le.U.cpu().numpy()[own], U[gs][own]) <= 1e-7
+    print("rank %d gpu_randbc OK its=%d" % (rank, its), flush=True)
+
+
 if __name__ == "__main__":
     mode = sys.argv[1]
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     try:
-        (cpu_mode if mode == "cpu" else gpu_mode)(rank, world)
+        {"cpu": cpu_mode, "gpu": gpu_mode, "gpu_randbc": gpu_randbc_mode}[mode](rank, world)
     finally:
         dist.destroy_process_group()

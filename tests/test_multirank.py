@@ -73,3 +73,11 @@ def test_eight_ranks_one_gpu_c3_c5_slab_geometry():
     interior ranks with neighbours on both sides -- on a mesh reduced in x-y (16x8x128), every rank on cuda:0,
     against the serial oracle (residual history, U, objective, sensitivities, filters, every level operator)."""
     _launch("gpu", nproc=8, timeout=900, extra=(16, 8, 128, 4))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,mesh", [(2, (16, 8, 16, 3)), (4, (24, 12, 32, 3))])
+def test_random_dirichlet_on_slabs(nproc, mesh):
+    """Dirichlet dofs scattered at random across the slab boundaries (flagged level-1 elements in the ghost layers,
+    masks on ghost planes): slabs on one GPU against the serial oracle"""
+    _launch("gpu_randbc", nproc=nproc, extra=mesh)
