@@ -81,3 +81,23 @@ def test_random_dirichlet_on_slabs(nproc, mesh):
     """Dirichlet dofs scattered at random across the slab boundaries (flagged level-1 elements in the ghost layers,
     masks on ghost planes): slabs on one GPU against the serial oracle"""
     _launch("gpu_randbc", nproc=nproc, extra=mesh)
+
+
+@pytest.mark.gpu
+def test_two_levels_on_slabs_coarsest_level_stays_distributed():
+    """two multigrid levels on 2 slabs: the coarsest level is level 1 (applied from the fine moduli, nothing to
+    replicate) and keeps its halo exchanges -- against the serial oracle"""
+    _launch("gpu", nproc=2, extra=(16, 8, 8, 2))
+
+
+@pytest.mark.gpu
+def test_too_thin_slabs_are_refused_on_every_rank():
+    """one element layer per rank on a distributed level: refused at creation with TP_ERR_ARG on all ranks alike (a
+    rank-dependent failure later would leave the others waiting in a collective)"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "mp_gloo_worker.py"), "gpu", "16", "8", "8", "2"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=180)
+    assert r.returncode != 0
+    assert (r.stdout + r.stderr).count("too few for 2 multigrid levels on slabs") == 4
+    assert "tp_elasticity_create failed: TP_ERR_ARG" in r.stdout + r.stderr

@@ -439,12 +439,25 @@ extern "C" int tp_elasticity_create_ke(tp_elasticity **out, tp_grid *g, const tp
     // TopOpt.cc:183-201: every direction divisible by 2^(nlvls-1); here also per slab
     const int f = 1 << (o->nlvls - 1);
     if (g->ex % f || g->ey % f || g->ez_own % f) return TP_ERR_ARG;
+    // slabs: every level that stays distributed keeps at least two element layers per rank (the boundary-first halo
+    // overlap and the level-1 ghost rows assume a rank's two boundary planes are distinct); the replicated coarsest
+    // level (three or more levels) may come down to one.  Decided from global sizes: the same answer on every rank.
+    if (g->has_comm) {
+        const int last_distributed = o->nlvls >= 3 ? o->nlvls - 2 : o->nlvls - 1;
+        if ((g->ez_own >> last_distributed) < 2) {
+            fprintf(stderr, "topopt_amd: %d element layers per rank are too few for %d multigrid levels on slabs (need >= %d)\n",
+                    g->ez_own, o->nlvls, 2 << last_distributed);
+            return TP_ERR_ARG;
+        }
+    }
     tp_elasticity *e = new tp_elasticity();
     e->grid = g;
     e->mg.grid = g;
     e->mg.nlv = o->nlvls;
     e->mg.opt = *o;
-    e->mg.allow_replicate = true;
+    // the replicated copy of the coarsest level is a stored stencil: levels >= 2 are; with two levels the coarsest one is
+    // level 1, applied from the fine moduli (no stencil to gather) -- it stays distributed
+    e->mg.allow_replicate = o->nlvls >= 3;
     e->have_bc = e->assembled = false;
     e->d_flagged = nullptr;
     e->nflagged = 0;
