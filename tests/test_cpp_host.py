@@ -49,6 +49,39 @@ def test_slab_job_shared_memory_selftest(n):
     assert sorted(out.stdout.split("\n")[:-1]) == ["rank %d of %d OK" % (r, n) for r in range(n)]
 
 
+@pytest.mark.parametrize("nz,R,sw", [(13, 3, 3), (17, 4, 1), (33, 8, 2), (9, 1, 2), (65, 2, 5)])
+def test_compat_dmda_partition_matches_petsc_rules(nz, R, sw):
+    """N > 1 on the CPU: what the compat layer's DMDA reports on every rank of a slab job (host/dmda_probe under
+    host/slabrun) against PETSc's rules for a DM_BOUNDARY_NONE DMDA on a 1 x 1 x R process grid: the first
+    (M mod R) ranks own one point more, ghost ranges are the owned range widened by the stencil width and clipped;
+    the element mesh is built on the node mesh's ownership ranges minus one (TopOpt.cc:254-290)."""
+    _build()
+    nx, ny = 9, 5
+    out = subprocess.run([os.path.join(ROOT, "host", "slabrun"), "-n", str(R), os.path.join(ROOT, "host", "dmda_probe"),
+                          str(nx), str(ny), str(nz), str(sw)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    got = {}
+    for ln in out.stdout.splitlines():
+        m = re.match(r"rank (\d+) of (\d+) (\w+) grid (\d+) (\d+) (\d+) own 0 0 (\d+) \+ (\d+) (\d+) (\d+) ghost 0 0 (\d+) \+ (\d+) (\d+) (\d+) "
+                     r"info (\d+) (\d+) (\d+) (\d+) sw (\d+)", ln)
+        assert m, ln
+        v = [int(x) for x in m.groups() if x.isdigit()]
+        got[(int(m.group(1)), m.group(3))] = [int(g) for i, g in enumerate(m.groups()) if i != 2]
+    assert len(got) == 2 * R
+    for kind, P, w, mx, my in (("nodes", nz, 1, nx, ny), ("elems", nz - 1, sw, nx - 1, ny - 1)):
+        node_own = [nz // R + (1 if q < nz % R else 0) for q in range(R)]           # PETSc: remainder to the first ranks
+        own = node_own if kind == "nodes" else [node_own[q] - (1 if q == 0 else 0) for q in range(R)]
+        assert sum(own) == P
+        for r in range(R):
+            zs = sum(own[:r])
+            gzs, gze = max(zs - w, 0), min(zs + own[r] + w, P)
+            rk, size, md, nd, pd, ozs, oxm, oym, ozm, ggzs, gxm, gym, gzm, izs, izm, igzs, igzm, isw = got[(r, kind)]
+            assert (rk, size, md, nd, pd) == (r, R, 1, 1, R)
+            assert (ozs, oxm, oym, ozm) == (zs, mx, my, own[r])
+            assert (ggzs, gxm, gym, gzm) == (gzs, mx, my, gze - gzs)
+            assert (izs, izm, igzs, igzm, isw) == (zs, own[r], gzs, gze - gzs, w)
+
+
 def test_slab_job_dead_rank_does_not_hang(tmp_path):
     """a rank that dies takes the job down: slabrun returns its failure instead of waiting for the survivors"""
     _build()
