@@ -103,7 +103,7 @@ int comm_ready() {
     }
     long cap = std::max(12L * nx * ny, 1L << 16);
     if (getenv("TP_SLAB_CAP")) cap = std::max(cap, atol(getenv("TP_SLAB_CAP")));
-    if (slab_comm_init(&sc, cap)) return PETSC_ERR_LIB;
+    if (slab_comm_join(&sc, cap)) return PETSC_ERR_LIB;  // (device buffers: ensure_grid -- MPI_* alone needs no GPU)
     sc_ready = true;
     return 0;
 }
@@ -234,6 +234,7 @@ int ensure_grid() {
         fprintf(stderr, "[petsc-compat] the mailboxes of the job were sized before the mesh was known (%ld doubles): pass -nx/-ny or set TP_SLAB_CAP\n", sc.hooks.cap);
         return PETSC_ERR_LIB;
     }
+    if (slab_comm_alloc(&sc)) return PETSC_ERR_LIB;
     o.rank = sc.rank;
     o.nranks = sc.nranks;
     o.device = sc.device;

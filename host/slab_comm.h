@@ -190,10 +190,10 @@ inline int slab_comm_join(SlabComm *c, long cap) {
     c->hooks.cap = cap;
     return 0;
 }
-// ... and allocates the device staging buffers of the tp_comm hooks on the rank's GPU
-inline int slab_comm_init(SlabComm *c, long cap) {
-    if (slab_comm_join(c, cap)) return 1;
-    cap = c->hooks.cap;
+// the device staging buffers of the tp_comm hooks on the rank's GPU (after slab_comm_join)
+inline int slab_comm_alloc(SlabComm *c) {
+    if (c->dev_buf) return 0;
+    const long cap = c->hooks.cap;
     const size_t nd = 4 * (size_t)cap + 16 + (size_t)c->nranks * (size_t)cap;
     if (tp_set_device(c->device) || tp_malloc((void **)&c->dev_buf, sizeof(double) * nd)) return 1;
     tp_comm &h = c->hooks;
@@ -213,6 +213,7 @@ inline int slab_comm_init(SlabComm *c, long cap) {
     h.set_stream = nullptr;
     return 0;
 }
+inline int slab_comm_init(SlabComm *c, long cap) { return slab_comm_join(c, cap) || slab_comm_alloc(c); }
 
 // Optional upgrade to the library's own RCCL path (one process per GPU on real hardware).  Harmless when it cannot be
 // used (ranks sharing a GPU, no librccl): every rank keeps the host-staged hooks.  TP_RCCL_LIB names the library.

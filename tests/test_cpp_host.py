@@ -82,6 +82,30 @@ def test_compat_dmda_partition_matches_petsc_rules(nz, R, sw):
             assert (izs, izm, igzs, igzm, isw) == (zs, own[r], gzs, gze - gzs, w)
 
 
+@pytest.mark.parametrize("R", [1, 2, 3, 6])
+def test_compat_mpi_subset_across_ranks(tmp_path, R):
+    """N > 1 on the CPU: the MPI subset of include/petsc_compat/mpi.h over the shared-memory job (host/mpi_probe under
+    host/slabrun): reductions of every element type the reference reduces, Allgather, and the MPI-IO pattern of
+    MPIIO.cc -- rank 0's header, every rank's block through its own view (contiguous, and a strided vector filetype
+    interleaving three fields) -- checked byte for byte."""
+    import numpy as np
+    _build()
+    fn = str(tmp_path / "probe.bin")
+    out = subprocess.run([os.path.join(ROOT, "host", "slabrun"), "-n", str(R), os.path.join(ROOT, "host", "mpi_probe"), fn],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert sorted(out.stdout.split("\n")[:-1]) == ["rank %d of %d OK" % (r, R) for r in range(R)]
+    raw = open(fn, "rb").read()
+    assert raw[:9] == b"probe v1\n"
+    nloc = [5 + r for r in range(R)]
+    total = sum(nloc)
+    data = np.frombuffer(raw[9:], dtype="<f4")
+    assert data.size == 4 * total
+    want = np.concatenate([100 * r + np.arange(nloc[r]) for r in range(R)] +
+                          [1000 * (f + 1) + 100 * r + np.arange(nloc[r]) for f in range(3) for r in range(R)]).astype(np.float32)
+    assert np.array_equal(data, want)
+
+
 def test_slab_job_dead_rank_does_not_hang(tmp_path):
     """a rank that dies takes the job down: slabrun returns its failure instead of waiting for the survivors"""
     _build()
