@@ -42,7 +42,6 @@ struct SlabComm {
     std::string shm_name;
     tp_comm hooks{};
     double *dev_buf = nullptr;  // send_lo | send_hi | recv_lo | recv_hi | red(16) | gather(nranks * cap)
-    double *host_tmp = nullptr;
     tp_grid *grid = nullptr;    // set by the host once the grid exists (stream synchronisation)
     long n_exchanges = 0;
 

@@ -5,6 +5,7 @@
 // returned if all ranks succeed, otherwise the first failure; a rank that dies takes the others down (they time out
 // in their next barrier, or are killed here).
 #include <signal.h>
+#include <sys/mman.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -64,5 +65,6 @@ int main(int argc, char **argv) {
                 if (k != p) kill(k, SIGTERM);  // the others would only wait for the dead rank
         }
     }
+    shm_unlink(shm.c_str());  // (rank 0 removes the name once everybody is attached; this is for jobs that never got there)
     return rc;
 }
