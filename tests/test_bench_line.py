@@ -1,0 +1,34 @@
+"""The bench contract: `python bench.py` prints exactly ONE line on stdout, a JSON object with the driver's keys plus the
+`roofline` and `cpu_baseline` objects."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_json_line_with_the_contract_keys():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-cube256",
+                        "--cpu-sample", "16x8x8"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.split("\n") if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                 ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                 ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(d[k], t), (k, d.get(k))
+    assert d["vs_baseline"] is None and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["scaling"] in ("weak", "strong") and d["higher_is_better"] is True
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] == pytest.approx(d["config"]["n_dof"] / (d["ms_per_step"] * 1e-3), rel=1e-6)
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"]) and 0 < rf["frac"] < 1
+    assert "traffic" in rf and "traffic_source" in rf
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and isinstance(cb["sample"], str)
