@@ -101,3 +101,10 @@ def test_too_thin_slabs_are_refused_on_every_rank():
     assert r.returncode != 0
     assert (r.stdout + r.stderr).count("too few for 2 multigrid levels on slabs") == 4
     assert "tp_elasticity_create failed: TP_ERR_ARG" in r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_three_ranks_one_gpu_odd_rank_count():
+    """an odd number of slabs (the middle rank has neighbours on both sides, the replicated coarsest level is gathered
+    from three unequal parts: rank 0 owns one node plane more)"""
+    _launch("gpu", nproc=3, extra=(16, 8, 24, 3))
