@@ -154,7 +154,10 @@ struct _p_Mat {
     std::vector<double> ref0;    // K_ELAST: rank 0's first block = the element matrix of the operator
     std::vector<double> E;       // K_ELAST: per element multiplier of `ref`
     long ncalls;
+    long nverified = 0;          // TP_SHIM_VERIFY=1: element blocks checked entry by entry
     double coneR;                // K_CONE
+    std::vector<int> hrow, hcol; // K_CONE, TP_SHIM_VERIFY=1: every entry the caller inserted
+    std::vector<double> hval;
     bool assembled_since_setup;  // new values since the operator was last built
     Vec Nvec;                    // K_ELAST: copy of the Dirichlet vector
     bool have_bc;
@@ -428,6 +431,10 @@ int ensure_elasticity(Mat A) {
     if (A->assembled_since_setup) {
         if (!A->have_bc || !A->Nvec) return sup("stiffness matrix without MatDiagonalScale(K, N, N): Dirichlet vector unknown");
         if ((long)A->E.size() != nel || A->ncalls != nel) return sup("MatSetValuesLocal: not every element was added exactly once");
+        if (A->nverified) {
+            printf("[petsc-compat] verified %ld element blocks (576 entries, 24 indices each) of the assembled stiffness matrix\n", A->nverified);
+            A->nverified = 0;
+        }
         // N arrived through window copies: its ghost planes are refreshed before the library reads the whole slab
         int rc = job_size() > 1 ? tp_grid_halo_nodes(mesh.g, binout(A->Nvec), 3) : 0;
         if (!rc) rc = tp_elasticity_set_bc(A->e, bin(A->Nvec));
@@ -1350,6 +1357,18 @@ PetscErrorCode MatSetValuesLocal(Mat A, PetscInt nrow, const PetscInt irow[], Pe
         for (int q : {0, 1, 25, 300, 575})
             if (fabs(y[q] - s * A->ref[q]) > 1e-12 * fabs(s) * (fabs(A->ref[0]) + fabs(A->ref[q])))
                 return sup("dof-3 matrix: element blocks are not multiples of one element matrix");
+        if (getenv("TP_SHIM_VERIFY")) {  // the whole block and all 24 indices, not samples
+            for (int q = 0; q < 576; q++)
+                if (fabs(y[q] - s * A->ref[q]) > 1e-12 * fabs(s) * (fabs(A->ref[0]) + fabs(A->ref[q])))
+                    return sup("dof-3 matrix (verify): an element block is not a multiple of the first one");
+            const PetscInt dz = d->M * d->N;
+            const PetscInt cell[8] = {n0, n0 + 1, n0 + 1 + d->M, n0 + d->M, n0 + dz, n0 + 1 + dz, n0 + 1 + d->M + dz, n0 + d->M + dz};
+            for (int a = 0; a < 8; a++)
+                for (int c = 0; c < 3; c++)
+                    if (irow[3 * a + c] != 3 * cell[a] + c || icol[3 * a + c] != irow[3 * a + c])
+                        return sup("dof-3 matrix (verify): rows/columns are not the hexahedron's dofs in the reference's corner order");
+            A->nverified++;
+        }
         A->E[(size_t)el] += s;
         A->ncalls++;
         A->assembled_since_setup = true;
@@ -1375,6 +1394,11 @@ PetscErrorCode MatSetValuesLocal(Mat A, PetscInt nrow, const PetscInt irow[], Pe
         } else if (A->coneR != 0.0 && !(y[0] > 0.0 && y[0] < A->coneR)) {
             return sup("element matrix: off-diagonal weight outside (0, R)");
         }
+        if (getenv("TP_SHIM_VERIFY") && job_size() == 1) {  // keep the caller's matrix to check the device filter against it
+            A->hrow.push_back((int)irow[0]);
+            A->hcol.push_back((int)icol[0]);
+            A->hval.push_back(y[0]);
+        }
         A->ncalls++;
         return 0;
     default:
@@ -1387,6 +1411,42 @@ PetscErrorCode MatAssemblyEnd(Mat A, MatAssemblyType) {
         if (A->coneR <= 0.0) return sup("element matrix without diagonal entries");
         int rc = ensure_grid();
         if (!rc) rc = tp_filter_create(&A->f, mesh.g, 1, A->coneR, nullptr);
+        if (!rc && !A->hval.empty()) {
+            // TP_SHIM_VERIFY=1: only the radius was taken from the caller's entries -- check that the device filter IS the
+            // matrix the caller assembled (Filter.cc:417-433: the reference's own distances and weights): H x for a
+            // pseudo-random x, entry by entry on the host, against tp_filter_mult_h
+            const long n = A->n_rows;
+            std::vector<double> x((size_t)n), yh((size_t)n, 0.0), yd((size_t)n);
+            uint64_t st = 0x9E3779B97F4A7C15ULL;
+            for (long i = 0; i < n; i++) {
+                st = st * 6364136223846793005ULL + 1442695040888963407ULL;
+                x[(size_t)i] = (double)(st >> 11) / 9007199254740992.0;
+            }
+            for (size_t e = 0; e < A->hval.size(); e++) yh[(size_t)A->hrow[e]] += A->hval[e] * x[(size_t)A->hcol[e]];
+            double *dx = nullptr, *dy = nullptr;
+            rc = tp_malloc((void **)&dx, sizeof(double) * (size_t)n) || tp_malloc((void **)&dy, sizeof(double) * (size_t)n);
+            if (!rc) rc = tp_memcpy_h2d(dx, x.data(), sizeof(double) * (size_t)n);
+            if (!rc) rc = tp_filter_mult_h(A->f, dx, dy);
+            if (!rc) rc = tp_sync(mesh.g);
+            if (!rc) rc = tp_memcpy_d2h(yd.data(), dy, sizeof(double) * (size_t)n);
+            if (dx) tp_free(dx);
+            if (dy) tp_free(dy);
+            if (rc) return rc;
+            double dev = 0.0, scale = 0.0;
+            for (long i = 0; i < n; i++) {
+                dev = fmax(dev, fabs(yh[(size_t)i] - yd[(size_t)i]));
+                scale = fmax(scale, fabs(yh[(size_t)i]));
+            }
+            printf("[petsc-compat] verified the cone filter against the %zu inserted entries: max |H x - device| / max |H x| = %.3e\n",
+                   A->hval.size(), dev / scale);
+            if (!(dev <= 1e-12 * scale)) return sup("element matrix: the inserted entries are not the cone filter of their diagonal's radius on this mesh");
+            A->hrow.clear();
+            A->hcol.clear();
+            A->hval.clear();
+            A->hrow.shrink_to_fit();
+            A->hcol.shrink_to_fit();
+            A->hval.shrink_to_fit();
+        }
         return rc;
     }
     return 0;

@@ -215,3 +215,20 @@ def test_whole_reference_program_other_filters_on_two_ranks(tmp_path, filt):
         hist[n] = [[float(v) for v in re.findall(r"-?\d+\.?\d*(?:[eE][+-]?\d+)?", ln)] for ln in lines]
     for a, b in zip(hist[2], hist[1]):
         assert a == pytest.approx(b, rel=2e-5, abs=2e-6), (a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(BIN), reason="host/_refbuild/ref_on_shim not built (build container only)")
+def test_capture_is_verified_against_what_the_reference_assembled():
+    """TP_SHIM_VERIFY=1: MatSetValuesLocal normally keeps one number per element (the modulus) and one per filter (the
+    radius).  In verify mode every 24x24 block of AssembleStiffnessMatrix is compared entry by entry (and index by
+    index) with modulus x the first block, and ALL entries of the filter matrix that Filter::SetUp inserted
+    (Filter.cc:417-433, the reference's own distances and weights) are kept and H x is compared with the device
+    filter: the operators behind the names ARE the matrices the reference assembled."""
+    r = subprocess.run([BIN, "32", "16", "16", "1", "-nlvls", "3"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, PETSC_OPTIONS=" ".join(OPTS), TP_SHIM_VERIFY="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    m = re.search(r"verified the cone filter against the (\d+) inserted entries: max \|H x - device\| / max \|H x\| = (\S+)", r.stdout)
+    assert m and int(m.group(1)) > 500000 and float(m.group(2)) < 1e-14, r.stdout[-1500:]
+    assert "verified 8192 element blocks (576 entries, 24 indices each)" in r.stdout
+    assert "REF_ON_SHIM fx" in r.stdout
