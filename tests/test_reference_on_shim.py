@@ -232,3 +232,37 @@ def test_capture_is_verified_against_what_the_reference_assembled():
     assert m and int(m.group(1)) > 500000 and float(m.group(2)) < 1e-14, r.stdout[-1500:]
     assert "verified 8192 element blocks (576 entries, 24 indices each)" in r.stdout
     assert "REF_ON_SHIM fx" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(TOPOPT_REF), reason="host/_refbuild/topopt_ref not built (build container only)")
+@pytest.mark.parametrize("n", [1, 2])
+def test_restart_through_the_reference_code(tmp_path, n):
+    """The reference's own restart path (TopOpt.cc:386-512: VecLoad of x, xPhys, xo1, xo2, U, L through the compat
+    binary viewer; LinearElasticity's -restartFileVecSol) on one and on two slab processes: 3 iterations, restart, 2
+    more = 5 iterations straight (objective and constraint of iterations 4 and 5; the reference does not restore xold,
+    so the printed design change of the first restarted iteration differs -- with real PETSc too)."""
+    run = os.path.join(ROOT, "host", "slabrun")
+    base = [run, "-n", str(n), "--same-device", TOPOPT_REF, "-nx", "33", "-ny", "17", "-nz", "17", "-nlvls", "3"]
+
+    def hist(out):
+        return {int(m[0]): (float(m[1]), float(m[2])) for m in re.findall(r"It\.: (\d+), True fx: (\S+), Scaled fx: \S+ gx\[0\]: (\S+),", out)}
+
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir()
+    b.mkdir()
+    r = subprocess.run(base + ["-maxItr", "5"] + OPTS, capture_output=True, text=True, timeout=300, cwd=str(a))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    straight = hist(r.stdout)
+    r = subprocess.run(base + ["-maxItr", "3"] + OPTS, capture_output=True, text=True, timeout=300, cwd=str(b))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    files = sorted((f for f in os.listdir(str(b)) if re.fullmatch(r"Restart0\d\.dat", f)), key=lambda f: os.path.getmtime(str(b / f)))
+    vec = files[-1]
+    r = subprocess.run(base + ["-maxItr", "5", "-restart", "1", "-restartFileVec", vec, "-restartFileItr", vec[:-4] + "_itr_f0.dat",
+                               "-restartFileVecSol", "RestartSol" + vec[len("Restart"):]] + OPTS,
+                       capture_output=True, text=True, timeout=300, cwd=str(b))
+    assert r.returncode == 0 and "Successful restart" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    again = hist(r.stdout)
+    assert sorted(again) == [4, 5] and sorted(straight) == [1, 2, 3, 4, 5]
+    for it in (4, 5):
+        assert again[it] == pytest.approx(straight[it], rel=2e-6, abs=2e-6)
