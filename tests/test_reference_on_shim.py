@@ -266,3 +266,51 @@ def test_restart_through_the_reference_code(tmp_path, n):
     assert sorted(again) == [4, 5] and sorted(straight) == [1, 2, 3, 4, 5]
     for it in (4, 5):
         assert again[it] == pytest.approx(straight[it], rel=2e-6, abs=2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(TOPOPT_REF), reason="host/_refbuild/topopt_ref not built (build container only)")
+def test_restart_files_cross_the_boundary_both_ways(tmp_path):
+    """Restart files written by the REFERENCE's code (TopOpt::WriteRestartFiles + the compat binary viewer; the iteration
+    file by the reference's own ofstream) are read by the product's Python driver, and the driver's files are read by
+    the reference's code (TopOpt.cc:386-512): iterations 4 and 5 equal the uninterrupted run either way."""
+    import topopt_in_petsc_amd as tp
+    ex, ey, ez, nlv = 32, 16, 16, 3
+    h = 1.0 / ey
+    kw = dict(nxyz=(ex + 1, ey + 1, ez + 1), xc=(0, ex * h, 0, 1, 0, ez * h), nlvls=nlv, rmin=2.56 * h, filter=1,
+              solver=tp.SolverOptions(nlvls=nlv))
+    straight = tp.TopOpt(**kw)
+    want = [straight.step() for _ in range(5)][3:]
+    base = [TOPOPT_REF, "-nx", str(ex + 1), "-ny", str(ey + 1), "-nz", str(ez + 1), "-nlvls", str(nlv), "-rmin", repr(2.56 * h)]
+
+    def latest(d):
+        fs = sorted((f for f in os.listdir(d) if re.fullmatch(r"Restart0\d\.dat", f)), key=lambda f: os.path.getmtime(os.path.join(d, f)))
+        v = fs[-1]
+        return os.path.join(d, v), os.path.join(d, v[:-4] + "_itr_f0.dat"), os.path.join(d, "RestartSol" + v[len("Restart"):])
+
+    # ---- reference writes, product reads
+    a = str(tmp_path / "a")
+    os.makedirs(a)
+    r = subprocess.run(base + ["-maxItr", "3"] + OPTS, capture_output=True, text=True, timeout=300, cwd=a)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    vec, itr, sol = latest(a)
+    cont = tp.TopOpt(restartFileVec=vec, restartFileItr=itr, restartFileVecSol=sol, **kw)
+    assert cont.itr == 3
+    for w in want:
+        g = cont.step()
+        assert g["ksp_its"] == w["ksp_its"]
+        assert g["fx"] == pytest.approx(w["fx"], rel=1e-7) and g["gx"] == pytest.approx(w["gx"], abs=1e-9)
+    # ---- product writes, reference reads
+    b = str(tmp_path / "b")
+    first = tp.TopOpt(workdir=b, output=False, **kw)
+    for _ in range(3):
+        first.step()
+    first.WriteRestartFiles()
+    vec, itr, sol = latest(b)
+    r = subprocess.run(base + ["-maxItr", "5", "-restart", "1", "-restartFileVec", vec, "-restartFileItr", itr, "-restartFileVecSol", sol] + OPTS,
+                       capture_output=True, text=True, timeout=300, cwd=b)
+    assert r.returncode == 0 and "Successful restart" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    got = {int(m[0]): (float(m[1]), float(m[2])) for m in re.findall(r"It\.: (\d+), True fx: (\S+), Scaled fx: \S+ gx\[0\]: (\S+),", r.stdout)}
+    assert sorted(got) == [4, 5]
+    for it, w in zip((4, 5), want):
+        assert got[it][0] == pytest.approx(w["fx"], rel=2e-6, abs=2e-6) and got[it][1] == pytest.approx(w["gx"], abs=2e-6)
