@@ -83,6 +83,16 @@ int main(int argc, char **argv) {
     VecSum(dgdx, &sdg);
     VecSum(xPhys, &sxp);
     VecNorm(physics->GetStateField(), NORM_2, &un);
+    if (const char *dump = getenv("REF_ON_SHIM_DUMP")) {  // xPhys, dfdx, dgdx (filtered, as main.cc:76 leaves them), U
+        PetscViewer view;
+        ierr = PetscViewerBinaryOpen(PETSC_COMM_WORLD, dump, FILE_MODE_WRITE, &view);
+        CHKERRQ(ierr);
+        VecView(xPhys, view);
+        VecView(dfdx, view);
+        VecView(dgdx, view);
+        VecView(physics->GetStateField(), view);
+        PetscViewerDestroy(&view);
+    }
     PetscInt its = 0;
     PetscPrintf(PETSC_COMM_WORLD, "REF_ON_SHIM fx %.16e gx %.16e sum_dfdx %.16e sum_dgdx %.16e sum_xphys %.16e normU %.16e\n", fx, gx, sdf, sdg, sxp, un);
     delete filter;
