@@ -346,8 +346,8 @@ def test_result_container_of_the_reference_writer_equals_the_products(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(BIN), reason="host/_refbuild/ref_on_shim not built (build container only)")
-@pytest.mark.parametrize("n", [1, 2])
-def test_reference_loops_elementwise_against_the_device_kernels(tmp_path, n):
+@pytest.mark.parametrize("n,filt", [(1, 1), (2, 1), (1, 2), (2, 2)])
+def test_reference_loops_elementwise_against_the_device_kernels(tmp_path, n, filt):
     """What the REFERENCE's own host loops produce for a synthetic design -- the filtered density, the compliance
     sensitivities of LinearElasticity.cc:299-437 after the chain rule of Filter.cc:120-204, the volume sensitivities and
     the state -- ELEMENT BY ELEMENT against the product's device kernels (k_objective, the filter kernels) on the same
@@ -356,21 +356,22 @@ def test_reference_loops_elementwise_against_the_device_kernels(tmp_path, n):
     ex, ey, ez, nlv = 32, 16, 16, 3
     h = 1.0 / ey
     dump = str(tmp_path / "ref.bin")
-    r = subprocess.run([os.path.join(ROOT, "host", "slabrun"), "-n", str(n), "--same-device", BIN, str(ex), str(ey), str(ez), "1", "-nlvls", str(nlv)],
+    r = subprocess.run([os.path.join(ROOT, "host", "slabrun"), "-n", str(n), "--same-device", BIN, str(ex), str(ey), str(ez), str(filt), "-nlvls", str(nlv)],
                        capture_output=True, text=True, timeout=300, env=dict(os.environ, PETSC_OPTIONS=" ".join(OPTS), REF_ON_SHIM_DUMP=dump))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     xp_r, df_r, dg_r, U_r = _petsc_vecs(dump)
     grid = tp.Grid(ex + 1, ey + 1, ez + 1, h)
     le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=nlv))
     le.SetUpLoadAndBC()
-    flt = tp.Filter(grid, 1, 2.56 * h)
+    flt = tp.Filter(grid, filt, 2.56 * h)   # (type 2: the reference's PDEFilt defaults = the library's)
     x = grid.synth_density()
     xt, xp, df, dg = grid.elem_vec(), grid.elem_vec(), grid.elem_vec(), grid.elem_vec()
     flt.FilterProject(x, xt, xp)
     le.ComputeObjectiveConstraintsSensitivities(df, dg, xp, 1e-9, 1.0, 3.0, 0.12)
     flt.Gradients(x, xt, df, [dg])
     rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
-    assert rel(xp.cpu().numpy(), xp_r) <= 1e-13
-    assert rel(le.U.cpu().numpy(), U_r) <= 1e-8
-    assert rel(df.cpu().numpy(), df_r) <= 1e-8
-    assert rel(dg.cpu().numpy(), dg_r) <= 1e-12
+    tight = filt == 1   # the Helmholtz filter has an iterative solve (rtol 1e-8) inside
+    assert rel(xp.cpu().numpy(), xp_r) <= (1e-13 if tight else 1e-7)
+    assert rel(le.U.cpu().numpy(), U_r) <= (1e-8 if tight else 1e-6)
+    assert rel(df.cpu().numpy(), df_r) <= (1e-8 if tight else 1e-6)
+    assert rel(dg.cpu().numpy(), dg_r) <= (1e-12 if tight else 1e-6)
