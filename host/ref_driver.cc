@@ -3,7 +3,10 @@
 // this repository) linked against libtopopt_petsc_shim.so, driven like main.cc:48-111 drives them for one design
 // iteration.  This file is ours: it only calls the reference's public methods.
 //   ref_on_shim ex ey ez filterType [petsc options...]
+// (this acceptance program also looks at the class's load and Dirichlet vectors, which the reference keeps private)
+#define private public
 #include <LinearElasticity.h>
+#undef private
 #include <Filter.h>
 
 #include <cstdint>
@@ -91,6 +94,8 @@ int main(int argc, char **argv) {
         VecView(dfdx, view);
         VecView(dgdx, view);
         VecView(physics->GetStateField(), view);
+        VecView(physics->N, view);    // what the reference's SetUpLoadAndBC (LinearElasticity.cc:46-180) set
+        VecView(physics->RHS, view);  // (after AssembleStiffnessMatrix zeroed the loads on clamped dofs, :541)
         PetscViewerDestroy(&view);
     }
     PetscInt its = 0;

@@ -359,7 +359,7 @@ def test_reference_loops_elementwise_against_the_device_kernels(tmp_path, n, fil
     r = subprocess.run([os.path.join(ROOT, "host", "slabrun"), "-n", str(n), "--same-device", BIN, str(ex), str(ey), str(ez), str(filt), "-nlvls", str(nlv)],
                        capture_output=True, text=True, timeout=300, env=dict(os.environ, PETSC_OPTIONS=" ".join(OPTS), REF_ON_SHIM_DUMP=dump))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    xp_r, df_r, dg_r, U_r = _petsc_vecs(dump)
+    xp_r, df_r, dg_r, U_r, N_r, RHS_r = _petsc_vecs(dump)
     grid = tp.Grid(ex + 1, ey + 1, ez + 1, h)
     le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=nlv))
     le.SetUpLoadAndBC()
@@ -369,6 +369,10 @@ def test_reference_loops_elementwise_against_the_device_kernels(tmp_path, n, fil
     flt.FilterProject(x, xt, xp)
     le.ComputeObjectiveConstraintsSensitivities(df, dg, xp, 1e-9, 1.0, 3.0, 0.12)
     flt.Gradients(x, xt, df, [dg])
+    # the Dirichlet and load vectors the reference's SetUpLoadAndBC wrote (the latter after :541 masked it) against
+    # k_cantilever's: the same bits
+    assert np.array_equal(le.N.cpu().numpy(), N_r)
+    assert np.array_equal((le.RHS * le.N).cpu().numpy(), RHS_r)
     rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
     tight = filt == 1   # the Helmholtz filter has an iterative solve (rtol 1e-8) inside
     assert rel(xp.cpu().numpy(), xp_r) <= (1e-13 if tight else 1e-7)
