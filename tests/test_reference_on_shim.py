@@ -379,3 +379,29 @@ def test_reference_loops_elementwise_against_the_device_kernels(tmp_path, n, fil
     assert rel(le.U.cpu().numpy(), U_r) <= (1e-8 if tight else 1e-6)
     assert rel(df.cpu().numpy(), df_r) <= (1e-8 if tight else 1e-6)
     assert rel(dg.cpu().numpy(), dg_r) <= (1e-12 if tight else 1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(TOPOPT_REF), reason="host/_refbuild/topopt_ref not built (build container only)")
+def test_whole_reference_program_with_heaviside_projection(tmp_path):
+    """-projectionFilter 1: the reference's Heaviside projection, its chain rule, the measure of non-discreteness and
+    the beta continuation (Filter.cc:206-288) through the unchanged program against the product's driver with the
+    device kernels, 12 iterations (the continuation raises beta at iteration 10)."""
+    import topopt_in_petsc_amd as tp
+    nit = 12
+    r = subprocess.run([TOPOPT_REF, "-nx", "33", "-ny", "17", "-nz", "17", "-nlvls", "3", "-maxItr", str(nit), "-projectionFilter", "1"] + OPTS,
+                       capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    ref = [[float(v) for v in m] for m in re.findall(
+        r"It\.: \d+, True fx: (\S+), Scaled fx: (\S+), gx\[0\]: (\S+), ch\.: (\S+), mnd\.: (\S+),", r.stdout)]
+    assert len(ref) == nit
+    ex, ey, ez, nlv = 32, 16, 16, 3
+    h = 1.0 / ey
+    opt = tp.TopOpt(nxyz=(ex + 1, ey + 1, ez + 1), xc=(0, ex * h, 0, 1, 0, ez * h), nlvls=nlv, rmin=0.08, filter=1,
+                    projectionFilter=True, solver=tp.SolverOptions(nlvls=nlv))
+    for it in range(nit):
+        rec = opt.step()
+        fx, sfx, gx, ch, mnd = ref[it]
+        assert fx == pytest.approx(rec["fx"], rel=5e-6, abs=5e-6), it
+        assert gx == pytest.approx(rec["gx"], abs=5e-6) and ch == pytest.approx(rec["ch"], abs=5e-6)
+        assert mnd == pytest.approx(rec["mnd"], abs=5e-6)
