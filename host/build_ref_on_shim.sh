@@ -25,5 +25,10 @@ done
 g++ -o "$OUT/topopt_ref" "$TMP"/main.o "$TMP"/TopOpt.o "$TMP"/MMA.o "$TMP"/MPIIO.o "$TMP"/LinearElasticity.o "$TMP"/Filter.o "$TMP"/PDEFilter.o \
     -L"$HERE/../topopt_in_petsc_amd" -ltopopt_petsc_shim -ltopopt_amd \
     -Wl,-rpath,'$ORIGIN/../../topopt_in_petsc_amd' -L/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib
+# the reference's MMA class alone, around host/ref_mma_driver.cc (m > 1 constraints)
+g++ -std=c++11 -O2 -w -I"$HERE/../include/petsc_compat" -I"$REF" -c "$HERE/ref_mma_driver.cc" -o "$TMP/mma_driver.o"
+g++ -o "$OUT/ref_mma" "$TMP"/mma_driver.o "$TMP"/MMA.o \
+    -L"$HERE/../topopt_in_petsc_amd" -ltopopt_petsc_shim -ltopopt_amd \
+    -Wl,-rpath,'$ORIGIN/../../topopt_in_petsc_amd' -L/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib
 rm -rf "$TMP"
-echo "built $OUT/ref_on_shim $OUT/topopt_ref"
+echo "built $OUT/ref_on_shim $OUT/topopt_ref $OUT/ref_mma"

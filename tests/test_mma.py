@@ -188,3 +188,43 @@ def test_device_mma_several_constraints(orc, m):
         lam_d, lam_o = np.asarray(m_d.state()[0])[:m], np.asarray(m_o.state()[0])[:m]
         assert np.abs(lam_d - lam_o).max() <= 1e-9 * max(np.abs(lam_o).max(), 1.0)
         xd.copy_(dev(x))
+
+
+REF_MMA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "host", "_refbuild", "ref_mma")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_MMA), reason="host/_refbuild/ref_mma not built (build container only)")
+@pytest.mark.parametrize("m,nproc", [(1, 1), (2, 1), (3, 2), (6, 1)])
+def test_device_mma_against_the_references_own_mma_class(tmp_path, m, nproc):
+    """The REFERENCE's MMA.cc (compiled unchanged against the compat layer, host/ref_mma_driver.cc; on one or two slab
+    processes) and the device MMA on the same synthetic problem with m constraints: the design vector of every
+    iteration."""
+    import subprocess
+    import torch
+    import topopt_in_petsc_amd as tp
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ex, ey, ez, iters = 16, 8, 8, 8
+    out = str(tmp_path / "x.bin")
+    r = subprocess.run([os.path.join(root, "host", "slabrun"), "-n", str(nproc), "--same-device", REF_MMA, str(ex), str(ey), str(ez), str(m),
+                        str(iters), out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    raw = open(out, "rb").read()
+    n = ex * ey * ez
+    xs_ref = [np.frombuffer(raw, dtype=">f8", count=n, offset=k * (8 + 8 * n) + 8).astype(np.float64) for k in range(iters)]
+    grid = tp.Grid(ex + 1, ey + 1, ez + 1, 1.0 / ey)
+    i = torch.arange(n, dtype=torch.float64, device="cuda")
+    x = torch.full((n,), 0.3, dtype=torch.float64, device="cuda")
+    xmin, xmax = torch.zeros_like(x), torch.zeros_like(x)
+    mma = tp.MMA(grid, x, m)
+    a = 1.0 + 0.3 * torch.sin(0.37 * i)
+    w = [1.0 + 0.5 * torch.cos(0.11 * i * (j + 1)) for j in range(m)]
+    worst = 0.0
+    for k in range(iters):
+        dfdx = -a / ((x + 0.1) * (x + 0.1))
+        dgdx = [(wj / n).contiguous() for wj in w]
+        gx = [float((wj * x).sum() / n) - (0.25 + 0.05 * j) for j, wj in enumerate(w)]
+        mma.SetOuterMovelimit(0.0, 1.0, 0.2, x, xmin, xmax)
+        mma.Update(x, dfdx.contiguous(), gx, dgdx, xmin, xmax)
+        worst = max(worst, float(np.abs(x.cpu().numpy() - xs_ref[k]).max()))
+    assert worst <= 1e-9, worst
