@@ -158,3 +158,40 @@ def test_sensitivity_matches_finite_difference(orc):
 def test_mesh_must_be_coarsenable(orc):
     with pytest.raises(ValueError):  # TopOpt.cc:183-201
         orc.MG(11, 5, 5, 3, 3)
+
+
+@pytest.mark.parametrize("k,zero_guess", [(4, True), (4, False), (1, True), (1, False), (30, True), (7, False)])
+def test_chebyshev_equals_petsc_three_term_recurrence(orc, k, zero_guess):
+    """The oracle (and the kernels) run the Chebyshev iteration in the direction-vector form; KSPSolve_Chebyshev of
+    PETSc 3.11 is written as a three-term recurrence (scale = 2/(emax+emin), alpha = 1 - scale*emin, mu = 1/alpha,
+    c_{k+1} = 2 mu c_k - c_{k-1}, omega = 2 c_k/(alpha c_{k+1}); first update without an operator application when the
+    guess is zero; `-ksp_max_it k` = the first update plus k-1 recurrence steps).  Restated here in numpy from the
+    published algorithm, with the Jacobi preconditioner and the window [0.1, 1.1] x lambda_max estimate: the same
+    iterates to rounding -- the two forms are one method."""
+    nx, ny, nz, h, KE, N, b, x, E = _problem(orc, 8, 4, 4, "synth")
+    mg = orc.MG(nx, ny, nz, 3, 1)
+    mg.assemble(KE, E, N)
+    lam = mg.lam(0)
+    emin, emax = 0.1 * lam, 1.1 * lam
+    dinv = 1.0 / mg.diag(0)
+    rng = np.random.default_rng(3)
+    x0 = np.zeros_like(b) if zero_guess else rng.standard_normal(b.size) * 1e-3
+    A = lambda v: mg.apply(0, v)
+    # ---- PETSc's form
+    scale = 2.0 / (emax + emin)
+    alpha = 1.0 - scale * emin
+    mu = 1.0 / alpha
+    omegaprod = 2.0 / alpha
+    c_km1, c_k = 1.0, mu
+    p_km1 = x0.copy()
+    r = b.copy() if zero_guess else b - A(p_km1)
+    p_k = p_km1 + scale * (dinv * r)
+    for _ in range(1, k):
+        c_kp1 = 2.0 * mu * c_k - c_km1
+        omega = omegaprod * c_k / c_kp1
+        r = b - A(p_k)
+        p_kp1 = (1.0 - omega) * p_km1 + omega * p_k + omega * scale * (dinv * r)
+        p_km1, p_k = p_k, p_kp1
+        c_km1, c_k = c_k, c_kp1
+    xo = mg.smooth(0, b, x0.copy(), k, zero_guess)
+    assert np.abs(xo - p_k).max() <= 1e-12 * np.abs(p_k).max()
