@@ -195,3 +195,46 @@ def test_chebyshev_equals_petsc_three_term_recurrence(orc, k, zero_guess):
         c_km1, c_k = c_k, c_kp1
     xo = mg.smooth(0, b, x0.copy(), k, zero_guess)
     assert np.abs(xo - p_k).max() <= 1e-12 * np.abs(p_k).max()
+
+
+@pytest.mark.parametrize("warm", [False, True])
+def test_cg_equals_petsc_ksp_cg_restated(orc, warm):
+    """KSPSolve_CG with -ksp_norm_type unpreconditioned and KSPConvergedDefault (reference norm ||b||, also for a non-zero
+    initial guess) restated in numpy around the oracle's V-cycle as the preconditioner: the oracle's own CG gives the
+    same iteration count and residual history."""
+    nx, ny, nz, h, KE, N, b, x, E = _problem(orc, 16, 8, 8, "synth")
+    mg = orc.MG(nx, ny, nz, 3, 3)
+    mg.assemble(KE, E, N)
+    rtol, atol, dtol, maxit = 1e-7, 1e-50, 1e5, 200
+    x0 = np.zeros_like(b)
+    if warm:
+        x0, _, _ = mg.solve(b, rtol=1e-2)
+    # ---- the restatement
+    X = x0.copy()
+    R = b - mg.apply(0, X) if warm else b.copy()
+    bnorm = np.linalg.norm(b)
+    ttol = max(rtol * bnorm, atol)
+    hist = [np.linalg.norm(R)]
+    its = 0
+    if hist[0] > ttol:
+        Z = mg.precond(R)
+        beta = float(Z @ R)
+        P = None
+        for i in range(maxit):
+            its = i + 1
+            P = Z.copy() if i == 0 else Z + (beta / betaold) * P
+            W = mg.apply(0, P)
+            a = beta / float(P @ W)
+            X += a * P
+            R -= a * W
+            betaold = beta
+            dp = np.linalg.norm(R)
+            hist.append(dp)
+            if dp <= ttol or dp >= dtol * bnorm:
+                break
+            Z = mg.precond(R)
+            beta = float(Z @ R)
+    U, its_o, hist_o = mg.solve(b, x0=x0 if warm else None, rtol=rtol, atol=atol, dtol=dtol, maxit=maxit)
+    assert its_o == its
+    assert np.abs(np.asarray(hist_o[: its + 1]) / np.asarray(hist) - 1).max() <= 1e-8
+    assert np.abs(U - X).max() <= 1e-9 * np.abs(X).max()
