@@ -353,13 +353,16 @@ void ksp_apply_options(KSP k, const std::vector<std::string> &prefixes) {
         if (const std::string *v = opt_find(p.c_str(), "ksp_atol")) k->atol = atof(v->c_str());
         if (const std::string *v = opt_find(p.c_str(), "ksp_divtol")) k->dtol = atof(v->c_str());
         if (const std::string *v = opt_find(p.c_str(), "ksp_max_it")) k->maxits = atoi(v->c_str());
+        if (const std::string *v = opt_find(p.c_str(), "ksp_gmres_restart")) k->restart = atoi(v->c_str());
         if (const std::string *v = opt_find(p.c_str(), "pc_type")) k->pc->type = *v;
     }
 }
 const char *NEED =
-    "the MI355X path solves CG + PCMG(V-cycle, Galerkin) with Chebyshev/Jacobi smoothers; select it like with real "
-    "PETSc: -ksp_type cg -mg_levels_ksp_type chebyshev -mg_levels_pc_type jacobi -mg_coarse_ksp_type chebyshev "
-    "-mg_coarse_pc_type jacobi (argv of PetscInitialize, $PETSC_OPTIONS or PetscOptionsSetValue)";
+    "the MI355X path solves CG + PCMG(V-cycle, Galerkin) with Chebyshev/Jacobi smoothers (fast; any number of slabs) or "
+    "FGMRES + PCMG with GMRES smoothers / coarse solve and SOR or Jacobi (the reference's hard-coded configuration, run as "
+    "written on ONE device: a correctness mode); select the fast one like with real PETSc: -ksp_type cg "
+    "-mg_levels_ksp_type chebyshev -mg_levels_pc_type jacobi -mg_coarse_ksp_type chebyshev -mg_coarse_pc_type jacobi "
+    "(argv of PetscInitialize, $PETSC_OPTIONS or PetscOptionsSetValue)";
 
 int resolve(KSP k, tp_solver_opts *o) {
     tp_solver_default_opts(o);
@@ -376,8 +379,12 @@ int resolve(KSP k, tp_solver_opts *o) {
         }
         ksp_apply_options(pc->lev[l], pre);
     }
-    if (k->type != KSPCG) return sup((std::string("outer KSP type '") + k->type + "': " + NEED).c_str());
+    const bool flexible = k->type == KSPFGMRES;  // LinearElasticity.cc:638, PDEFilter.cc:276
+    if (k->type != KSPCG && !flexible) return sup((std::string("outer KSP type '") + k->type + "': " + NEED).c_str());
     if (pc->type != PCMG) return sup((std::string("PC type '") + pc->type + "': " + NEED).c_str());
+    if (flexible && job_size() > 1)
+        return sup((std::string("FGMRES + GMRES/SOR on more than one rank (its SOR is rank-local in PETSc: results depend on the "
+                                "partition): ") + NEED).c_str());
     o->nlvls = nl;
     o->rtol = k->rtol;
     o->atol = k->atol;
@@ -385,6 +392,31 @@ int resolve(KSP k, tp_solver_opts *o) {
     o->max_it = k->maxits;
     if (pc->cycle != PC_MG_CYCLE_V || pc->mgtype != PC_MG_MULTIPLICATIVE) return sup("PCMG: only the multiplicative V-cycle");
     if (nl > 1 && pc->galerkin != PC_MG_GALERKIN_BOTH) return sup("PCMG: only -pc_mg_galerkin both");
+    if (flexible) {
+        // the configuration SetUpSolver hard-codes, as written (csrc/refksp.h)
+        o->ksp_mode = 1;
+        o->restart = k->restart;
+        for (int l = 0; l < (int)pc->lev.size(); l++) {
+            KSP s = pc->lev[l];
+            const bool sor = s->pc->type == PCSOR;
+            if (s->type != KSPGMRES || (!sor && s->pc->type != PCJACOBI))
+                return sup((std::string("level ") + std::to_string(l) + " solver '" + s->type + "/" + s->pc->type +
+                            "' under FGMRES (GMRES with SOR or Jacobi is what the reference sets): " + NEED).c_str());
+            if ((l == 0 && nl > 1) || nl == 1) {
+                o->ncoarse = s->maxits;
+                o->coarse_restart = s->restart;
+                o->coarse_rtol = s->rtol;
+                o->coarse_pc = sor ? 1 : 0;
+            } else {
+                if (s->restart < s->maxits) return sup("level smoother: GMRES restart shorter than its iteration count");
+                if (l > 1 && (o->nsmooth != s->maxits || o->smooth_pc != (sor ? 1 : 0)))
+                    return sup("level smoothers that differ from level to level");
+                o->nsmooth = s->maxits;
+                o->smooth_pc = sor ? 1 : 0;
+            }
+        }
+        return 0;
+    }
     for (int l = 0; l < (int)pc->lev.size(); l++) {
         KSP s = pc->lev[l];
         if (s->type != KSPCHEBYSHEV || s->pc->type != PCJACOBI)

@@ -154,6 +154,17 @@ typedef struct tp_solver_opts {
     double cheb_lo, cheb_hi; /* Chebyshev window as fractions of the eigenvalue estimate */
     int nlanczos;       /* Lanczos steps for the eigenvalue estimates */
     int fine_eig;       /* fine-level estimate: 0 = rigorous element bound (free), 1 = Lanczos like the coarse levels */
+    /* 0: CG + V-cycle with Chebyshev/Jacobi smoothers -- the fast path (the option string of SURVEY 8(d));
+     * 1: the configuration the reference hard-codes, run as written (a correctness mode, ONE device, ~1000 launches per
+     *    Gauss-Seidel sweep): FGMRES(restart) + V-cycle whose smoothers are GMRES(nsmooth) for nsmooth iterations and whose
+     *    coarse solve is GMRES(coarse_restart), at most ncoarse iterations to coarse_rtol on the preconditioned residual
+     *    (LinearElasticity.cc:620-746, PDEFilter.cc:276-378; csrc/refksp.h) */
+    int ksp_mode;
+    int restart;         /* KSPGMRESSetRestart of the outer FGMRES, :624 (100) */
+    int smooth_pc;       /* PC of the level smoothers: 0 PCJACOBI, 1 PCSOR (one local symmetric sweep, omega 1), :745 */
+    int coarse_pc;       /* PC of the coarse solve, :731 */
+    int coarse_restart;  /* :632 (30) */
+    double coarse_rtol;  /* :628 (1e-8) */
 } tp_solver_opts;
 void tp_solver_default_opts(tp_solver_opts *o);
 
@@ -203,6 +214,11 @@ double tp_elasticity_level_lambda(const tp_elasticity *e, int level);
 int tp_elasticity_level_apply(tp_elasticity *e, int level, const double *u, double *y); /* [dev, level local dofs] */
 int tp_elasticity_level_diag(tp_elasticity *e, int level, double *d);
 int tp_elasticity_precond(tp_elasticity *e, const double *r, double *z); /* one V-cycle */
+/* ksp_mode 1 level by level (tests): z = M^-1 r with PCJACOBI (pc 0) or PCSOR (pc 1) on a level; the level's left-
+ * preconditioned GMRES(m) for at most `its` iterations on x (rtol < 0: no convergence test, as PCMG runs its smoothers) */
+int tp_elasticity_level_pc(tp_elasticity *e, int level, int pc, const double *r, double *z);
+int tp_elasticity_level_gmres(tp_elasticity *e, int level, int pc, int m, int its, double rtol, const double *b, double *x,
+                              int zero_guess, int *its_done);
 /* k Chebyshev-Jacobi steps on a level (the fused operator+update kernel): x <- smooth(b, x) */
 int tp_elasticity_smooth(tp_elasticity *e, int level, const double *b, double *x, int k, int zero_guess);
 int tp_elasticity_restrict(tp_elasticity *e, int level, const double *rf, double *rc);

@@ -4,7 +4,8 @@ CPU part (build container, where /root/reference exists): the reference's Linear
 PDEFilter.cc compile UNCHANGED against the compat headers and link against libtopopt_petsc_shim.so
 (host/build_ref_on_shim.sh; nothing of the reference is stored in the repository, the binaries are git-ignored
 build artefacts) -- and so do main.cc, TopOpt.cc, MMA.cc and MPIIO.cc: the reference's WHOLE program.  GPU part: that binary -- the reference's own classes on the MI355X path -- against the product's
-Python API on the same mesh, and its refusal to run the reference's hard-coded FGMRES/GMRES/SOR configuration."""
+Python API on the same mesh; with no solver options at all the reference's hard-coded FGMRES/GMRES/SOR configuration
+runs as written (a one-device correctness mode), anything else is refused."""
 import os
 import re
 import subprocess
@@ -80,15 +81,52 @@ def test_reference_classes_on_the_mi355x_path(ftype):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(BIN), reason="host/_refbuild/ref_on_shim not built (build container only)")
-def test_reference_default_solver_is_refused_not_substituted():
-    """FGMRES + GMRES/SOR (LinearElasticity.cc:638, :720-746) is not implemented: the shim says so (PETSC_ERR_SUP = 56)
-    instead of silently solving with something else; $PETSC_OPTIONS selects the implemented configuration."""
-    r = _run([16, 8, 8, 1, "-nlvls", "3"])
-    assert r.returncode != 0 and "PETSC_ERR_SUP" in r.stderr and "fgmres" in r.stderr
-    assert "REF_ON_SHIM failed: 56" in r.stdout
-    r = _run([16, 8, 8, 1, "-nlvls", "3"], env={"PETSC_OPTIONS": " ".join(OPTS)})
+@pytest.mark.parametrize("ftype", [1, 2])
+def test_reference_hard_coded_solver_runs_as_written(ftype):
+    """No solver options at all: the reference's SetUpSolver bodies configure FGMRES(100) + PCMG with GMRES(4)/SOR
+    smoothers and a GMRES(30)/SOR coarse solve (LinearElasticity.cc:638, :720-746), PDEFilt's FGMRES(20) with
+    GMRES(1)/Jacobi (PDEFilter.cc:276-378).  The shim runs exactly that (csrc/refksp.h, a one-device correctness mode);
+    the numbers agree with the option-selected fast configuration to the solver tolerances, and the iteration count of the
+    state solve equals the CPU restatement's (oracle/refksp.py)."""
+    from oracle import oracle as orc, refksp
+    ex, ey, ez = 16, 8, 8
+    r = _run([ex, ey, ez, ftype, "-nlvls", "3"])
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
-    assert np.isfinite(_numbers(r.stdout)).all()
+    assert "fgmres" in r.stdout                      # the reference's own settings print (:758-780)
+    a = _numbers(r.stdout)
+    its = int(re.search(r"State solver:\s+iter: (\d+)", r.stdout).group(1))
+    r2 = _run([ex, ey, ez, ftype, "-nlvls", "3"] + OPTS)
+    assert r2.returncode == 0, r2.stdout[-1500:] + r2.stderr[-1500:]
+    b = _numbers(r2.stdout)
+    its_cg = int(re.search(r"State solver:\s+iter: (\d+)", r2.stdout).group(1))
+    assert its < its_cg
+    # fx, gx, sum dfdx, sum dgdx, sum xPhys, |U|: both state solves stop at rtol 1e-5 -> agreement ~1e-4, not more
+    assert a == pytest.approx(b, rel=2e-4, abs=1e-9)
+    if ftype == 1:                                   # the state solve of the restatement on the same filtered density
+        import torch
+        import topopt_in_petsc_amd as tp
+        h = 1.0 / ey
+        grid = tp.Grid(ex + 1, ey + 1, ez + 1, h)
+        flt = tp.Filter(grid, 1, 2.56 * h)
+        x = grid.synth_density(12345)
+        xt, xp = grid.elem_vec(), grid.elem_vec()
+        flt.FilterProject(x, xt, xp)
+        KE = orc.hex8_ke_box(h, h, h, 0.3)
+        N, R = orc.cantilever_bc(ex + 1, ey + 1, ez + 1, h)
+        mg = orc.MG(ex + 1, ey + 1, ez + 1, 3, 3)
+        mg.assemble(KE, orc.simp(xp.cpu().numpy()), N)
+        assert refksp.RefSolver(mg).solve(R * N)[1] == its
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(BIN), reason="host/_refbuild/ref_on_shim not built (build container only)")
+def test_unsupported_solver_configurations_are_refused_not_substituted():
+    """anything but the two implemented configurations: PETSC_ERR_SUP = 56 with a message, never a silent substitute"""
+    for extra, word in (["-ksp_type", "gmres"], "gmres"), (["-mg_levels_ksp_type", "richardson"], "richardson"), \
+            (["-ksp_type", "cg"], "gmres/sor"):      # CG outside, the hard-coded GMRES/SOR inside: not one of the two
+        r = _run([16, 8, 8, 1, "-nlvls", "3"] + extra)
+        assert r.returncode != 0 and "PETSC_ERR_SUP" in r.stderr and word in r.stderr, r.stderr[-800:]
+        assert "REF_ON_SHIM failed: 56" in r.stdout
 
 
 TOPOPT_REF = os.path.join(ROOT, "host", "_refbuild", "topopt_ref")

@@ -52,10 +52,32 @@ class SolverOptions:
     cheb_hi: float = 1.1
     nlanczos: int = 10
     fine_eig: int = 0   # 0: element bound on the fine level, 1: Lanczos estimate
+    # ksp_mode 1: the configuration the reference hard-codes (FGMRES(restart) + V-cycle with GMRES(nsmooth) smoothers and
+    # a GMRES(coarse_restart) coarse solve, PCSOR / PCJACOBI; LinearElasticity.cc:620-746, PDEFilter.cc:276-378) run as
+    # written -- a correctness mode on one device; 0: CG + Chebyshev/Jacobi, the fast path
+    ksp_mode: int = 0
+    restart: int = 100
+    smooth_pc: int = 1      # 0 PCJACOBI, 1 PCSOR
+    coarse_pc: int = 1
+    coarse_restart: int = 30
+    coarse_rtol: float = 1.0e-8
+
+    @classmethod
+    def reference_elasticity(cls, **kw):
+        """LinearElasticity::SetUpSolver as hard-coded (LinearElasticity.cc:620-746)"""
+        return cls(**{**dict(ksp_mode=1, restart=100, nsmooth=4, ncoarse=30, smooth_pc=1, coarse_pc=1, coarse_restart=30,
+                             coarse_rtol=1e-8, rtol=1e-5, atol=1e-50, dtol=1e5, max_it=200), **kw})
+
+    @classmethod
+    def reference_pdefilter(cls, **kw):
+        """PDEFilt::SetUpSolver as hard-coded (PDEFilter.cc:276-378)"""
+        return cls(**{**dict(ksp_mode=1, nlvls=3, restart=20, nsmooth=1, ncoarse=10, smooth_pc=0, coarse_pc=0, coarse_restart=10,
+                             coarse_rtol=1e-8, rtol=1e-8, atol=1e-50, dtol=1e3, max_it=60), **kw})
 
     def c_struct(self):
         return _lib.SolverOpts(self.nlvls, self.nu, self.rtol, self.atol, self.dtol, self.max_it, self.nsmooth,
-                               self.ncoarse, self.cheb_lo, self.cheb_hi, self.nlanczos, self.fine_eig)
+                               self.ncoarse, self.cheb_lo, self.cheb_hi, self.nlanczos, self.fine_eig, self.ksp_mode,
+                               self.restart, self.smooth_pc, self.coarse_pc, self.coarse_restart, self.coarse_rtol)
 
 
 class Grid:
@@ -276,6 +298,20 @@ class LinearElasticity:
         d = self.level_vec(l)
         _chk(self.L.tp_elasticity_level_diag(self.handle, l, _ptr(d)), "tp_elasticity_level_diag")
         return d
+
+    def level_pc(self, l, pc, r):
+        """ksp_mode 1: z = M^-1 r on level l, pc 0 = PCJACOBI, 1 = PCSOR (one symmetric Gauss-Seidel sweep)"""
+        z = torch.zeros_like(r)
+        _chk(self.L.tp_elasticity_level_pc(self.handle, l, pc, _ptr(r), _ptr(z)), "tp_elasticity_level_pc")
+        return z
+
+    def level_gmres(self, l, pc, m, its, b, x, zero_guess=False, rtol=-1.0):
+        """ksp_mode 1: the level's left-preconditioned GMRES(m), at most `its` iterations (rtol < 0: no test)"""
+        import ctypes
+        done = ctypes.c_int(0)
+        _chk(self.L.tp_elasticity_level_gmres(self.handle, l, pc, m, its, rtol, _ptr(b), _ptr(x), int(zero_guess),
+                                              ctypes.byref(done)), "tp_elasticity_level_gmres")
+        return x, done.value
 
     def precond(self, r):
         z = torch.zeros_like(r)

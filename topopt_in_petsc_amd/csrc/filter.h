@@ -347,7 +347,12 @@ extern "C" int tp_filter_create(tp_filter **out, tp_grid *g, int filterType, dou
             TP_TRY(mg.setup_matfree_level(l, f->KF.data()));
         }
         mg.ready = true;
-        TP_TRY(mg.estimate_spectra(1));
+        if (o.ksp_mode != 0 && o.ksp_mode != 1) return TP_ERR_ARG;
+        if (o.ksp_mode == 1 && g->has_comm) {
+            fprintf(stderr, "topopt_amd: ksp_mode 1 (the reference's FGMRES / GMRES configuration) runs on one device only\n");
+            return TP_ERR_ARG;
+        }
+        if (o.ksp_mode == 0) TP_TRY(mg.estimate_spectra(1));
         Geom q = mg.lv[0].g;
         TP_HIP(hipMalloc((void **)&f->xe, sizeof(double) * (size_t)q.elems_stored()));
         TP_HIP(hipMalloc((void **)&f->rhs, sizeof(double) * (size_t)q.nodes()));

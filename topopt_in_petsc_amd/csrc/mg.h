@@ -284,8 +284,19 @@ inline int fine_kz(int planes, int tiles, int fine_v) {
 }
 
 template <int DOF>
+struct MGSolver;
+// the reference's hard-coded FGMRES / GMRES / SOR configuration (refksp.h), tp_solver_opts::ksp_mode = 1
+template <int DOF>
+int refksp_solve(MGSolver<DOF> &mg, const double *b, double *x, int *its, double *rnorm, double *bnorm, double *hist, int hist_cap);
+template <int DOF>
+int refksp_precond(MGSolver<DOF> &mg, const double *r, double **z);
+template <int DOF>
+void refksp_free(MGSolver<DOF> &mg);
+
+template <int DOF>
 struct MGSolver {
     tp_grid *grid = nullptr;
+    void *refksp = nullptr;  // RefKsp<DOF>: work space of the ksp_mode 1 solver
     int nlv = 0;
     Level<DOF> lv[TP_MAX_LEVELS + 1];  // [nlv] = replicated global copy of the coarsest level (nranks > 1)
     bool replicate = false;
@@ -388,6 +399,7 @@ struct MGSolver {
     }
     void free_levels() {
         smooth_graphs_free();
+        refksp_free(*this);
         for (int l = 0; l <= nlv; l++) {
             Level<DOF> &L = lv[l];
             for (double *p : {L.b, L.x, L.x2, L.r, L.d, L.dinv, L.S, L.Kel}) (void)hipFree(p);
@@ -1097,6 +1109,7 @@ struct MGSolver {
 
     // z = M r : one V-cycle.  Returns the pointer holding z (lv[0].x).
     int precond(const double *r, double **z, int dot_slot = -1) {
+        if (opt.ksp_mode == 1) return refksp_precond(*this, r, z);
         TP_TRY(vcycle(0, r, dot_slot));
         TP_TRY(drain_halos());
         *z = lv[0].x;
@@ -1108,6 +1121,7 @@ struct MGSolver {
     int solve(const double *b, double *x, int *its_out, double *rnorm_out, double *bnorm_out, double *hist,
               int hist_cap) {
         if (!ready) return TP_ERR_STATE;
+        if (opt.ksp_mode == 1) return refksp_solve(*this, b, x, its_out, rnorm_out, bnorm_out, hist, hist_cap);
         Level<DOF> &L = lv[0];
         hipStream_t s = grid->stream;
         const long off = L.own_off(), n = L.own_n();

@@ -61,6 +61,32 @@ struct MatfreeOp {
                 if ((m >> r) & 1u) y[r] = u[n * DOF + r];
         }
     }
+    // the node's own DOF x DOF block of N K N + (I - N), row major (Gauss-Seidel sweeps, refksp.h)
+    __device__ inline void diag_block(long n, int i, int j, int k, double D[DOF * DOF]) const {
+        constexpr int ED = 8 * DOF;
+#pragma unroll
+        for (int q = 0; q < DOF * DOF; q++) D[q] = 0.0;
+#pragma unroll
+        for (int a = 0; a < 8; a++) {
+            const int ei = i - LXc(a), ej = j - LYc(a), ek = k - LZc(a);
+            if (ei < 0 || ei >= g.ex || ej < 0 || ej >= g.ey || ek < 0 || ek >= g.ezl) continue;
+            const double Ee = E ? E[(long)ei + (long)g.ex * (ej + (long)g.ey * ek)] : 1.0;
+#pragma unroll
+            for (int r = 0; r < DOF; r++)
+#pragma unroll
+                for (int c = 0; c < DOF; c++) D[r * DOF + c] = fma(Ee, KE[(a * DOF + r) * ED + a * DOF + c], D[r * DOF + c]);
+        }
+        if (mask) {
+            const unsigned m = mask[n];
+#pragma unroll
+            for (int r = 0; r < DOF; r++)
+#pragma unroll
+                for (int c = 0; c < DOF; c++) {
+                    const bool fr = (m >> r) & 1u, fc = (m >> c) & 1u;
+                    if (fr || fc) D[r * DOF + c] = (r == c) ? 1.0 : 0.0;
+                }
+        }
+    }
 };
 
 // ---------------------------------------------------------------------------
@@ -96,6 +122,12 @@ struct DiaOp {
                 }
             }
         }
+    }
+    __device__ inline void diag_block(long n, int, int, int, double D[DOF * DOF]) const {
+#pragma unroll
+        for (int c = 0; c < DOF; c++)
+#pragma unroll
+            for (int r = 0; r < DOF; r++) D[r * DOF + c] = S[(long)(13 * DOF + c) * nrows + n * DOF + r];
     }
 };
 

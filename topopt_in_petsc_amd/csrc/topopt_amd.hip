@@ -4,6 +4,7 @@
 
 #include "elements.h"
 #include "mg.h"
+#include "refksp.h"
 #include "rccl_comm.h"
 
 // ===========================================================================
@@ -368,6 +369,12 @@ extern "C" void tp_solver_default_opts(tp_solver_opts *o) {
     o->cheb_hi = 1.1;
     o->nlanczos = 10;
     o->fine_eig = 0;
+    o->ksp_mode = 0;
+    o->restart = 100;        // :624
+    o->smooth_pc = 1;        // :745 PCSOR
+    o->coarse_pc = 1;        // :731 PCSOR
+    o->coarse_restart = 30;  // :632
+    o->coarse_rtol = 1.0e-8; // :628
 }
 
 struct tp_elasticity {
@@ -439,6 +446,11 @@ extern "C" int tp_elasticity_create_ke(tp_elasticity **out, tp_grid *g, const tp
     // TopOpt.cc:183-201: every direction divisible by 2^(nlvls-1); here also per slab
     const int f = 1 << (o->nlvls - 1);
     if (g->ex % f || g->ey % f || g->ez_own % f) return TP_ERR_ARG;
+    if (o->ksp_mode != 0 && o->ksp_mode != 1) return TP_ERR_ARG;
+    if (o->ksp_mode == 1 && g->has_comm) {
+        fprintf(stderr, "topopt_amd: ksp_mode 1 (the reference's FGMRES / GMRES / SOR configuration) runs on one device only\n");
+        return TP_ERR_ARG;
+    }
     // slabs: every level that stays distributed keeps at least two element layers per rank (the boundary-first halo
     // overlap and the level-1 ghost rows assume a rank's two boundary planes are distinct); the replicated coarsest
     // level (three or more levels) may come down to one.  Decided from global sizes: the same answer on every rank.
@@ -511,7 +523,7 @@ extern "C" int tp_elasticity_create_ke(tp_elasticity **out, tp_grid *g, const tp
             L.colmask = e->d_colmask;
             L.use_tile = L.sym_slot >= 0;
         }
-        if (l == 1 && e->mg.lv[0].use_tile && !getenv("TP_NO_MACRO")) {
+        if (l == 1 && e->mg.lv[0].use_tile && !getenv("TP_NO_MACRO") && o->ksp_mode == 0) {  // Gauss-Seidel needs rows
             // level 1 is applied from the fine densities (k_matfree_tile<.,1>): no stencil storage
             L.kind = LV_MACRO;
             L.use_tile = true;
@@ -813,7 +825,7 @@ extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, dou
     }
     mg.ready = true;
     TP_TRY(mg.setup_replicated());
-    TP_TRY(mg.estimate_spectra(mg.opt.fine_eig ? 0 : 1));
+    if (mg.opt.ksp_mode == 0) TP_TRY(mg.estimate_spectra(mg.opt.fine_eig ? 0 : 1));  // Chebyshev windows
     e->assembled = true;
     return TP_OK;
 }
@@ -915,6 +927,24 @@ extern "C" int tp_elasticity_petsc_options(const tp_elasticity *e, char *buf, si
     const MGSolver<3> &mg = e->mg;
     std::string o;
     char t[512];
+    if (mg.opt.ksp_mode == 1) {  // what the reference's SetUpSolver hard-codes (LinearElasticity.cc:620-746)
+        const char *pcn[2] = {"jacobi", "sor"};
+        snprintf(t, sizeof t,
+                 "-ksp_type fgmres -ksp_gmres_restart %d -ksp_rtol %.17g -ksp_atol %.17g -ksp_divtol %.17g -ksp_max_it %d "
+                 "-ksp_initial_guess_nonzero true -pc_type mg -pc_mg_levels %d -pc_mg_type multiplicative -pc_mg_cycle_type v "
+                 "-pc_mg_galerkin both -mg_levels_ksp_type gmres -mg_levels_ksp_gmres_restart %d -mg_levels_ksp_max_it %d "
+                 "-mg_levels_pc_type %s -mg_coarse_ksp_type gmres -mg_coarse_ksp_gmres_restart %d -mg_coarse_ksp_rtol %.17g "
+                 "-mg_coarse_ksp_max_it %d -mg_coarse_pc_type %s",
+                 mg.opt.restart, mg.opt.rtol, mg.opt.atol, mg.opt.dtol, mg.opt.max_it, mg.nlv, mg.opt.nsmooth, mg.opt.nsmooth,
+                 pcn[mg.opt.smooth_pc ? 1 : 0], mg.opt.coarse_restart, mg.opt.coarse_rtol, mg.opt.ncoarse, pcn[mg.opt.coarse_pc ? 1 : 0]);
+        o = t;
+        if (buf && cap > 0) {
+            const size_t n = o.size() < cap - 1 ? o.size() : cap - 1;
+            memcpy(buf, o.data(), n);
+            buf[n] = 0;
+        }
+        return (int)o.size();
+    }
     snprintf(t, sizeof t,
              "-ksp_type cg -ksp_norm_type unpreconditioned -ksp_rtol %.17g -ksp_atol %.17g -ksp_divtol %.17g -ksp_max_it %d "
              "-ksp_initial_guess_nonzero true -pc_type mg -pc_mg_levels %d -pc_mg_type multiplicative -pc_mg_cycle_type v "
@@ -954,6 +984,21 @@ extern "C" int tp_elasticity_level_diag(tp_elasticity *e, int l, double *d) {
     Level<3> &L = e->mg.lv[l];
     TP_HIP(hipMemcpyAsync(d, L.dinv, sizeof(double) * (size_t)L.ndof(), hipMemcpyDeviceToDevice, e->grid->stream));
     return TP_OK;
+}
+// ksp_mode 1 building blocks, level by level (tests): z = M^-1 r with PCJACOBI (pc 0) / PCSOR (pc 1), and the level's
+// GMRES(m) run for its iterations on x (zero_guess: x is zeroed first; rtol < 0: no convergence test)
+extern "C" int tp_elasticity_level_pc(tp_elasticity *e, int l, int pc, const double *r, double *z) {
+    if (!e->assembled || l < 0 || l >= e->mg.nlv || e->mg.opt.ksp_mode != 1) return TP_ERR_STATE;
+    RefKsp<3> *R;
+    TP_TRY(refksp_get(e->mg, &R));
+    return R->pc_apply(l, pc, r, z);
+}
+extern "C" int tp_elasticity_level_gmres(tp_elasticity *e, int l, int pc, int m, int its, double rtol, const double *b, double *x,
+                                         int zero_guess, int *its_done) {
+    if (!e->assembled || l < 0 || l >= e->mg.nlv || e->mg.opt.ksp_mode != 1) return TP_ERR_STATE;
+    RefKsp<3> *R;
+    TP_TRY(refksp_get(e->mg, &R));
+    return R->gmres(l, b, x, zero_guess != 0, m, its, rtol < 0 ? 0.0 : rtol, e->mg.opt.atol, e->mg.opt.dtol, rtol >= 0, pc, its_done);
 }
 extern "C" int tp_elasticity_precond(tp_elasticity *e, const double *r, double *z) {
     if (!e->assembled) return TP_ERR_STATE;

@@ -32,7 +32,9 @@ class GridOpts(C.Structure):
 class SolverOpts(C.Structure):
     _fields_ = [("nlvls", C.c_int), ("nu", C.c_double), ("rtol", C.c_double), ("atol", C.c_double),
                 ("dtol", C.c_double), ("max_it", C.c_int), ("nsmooth", C.c_int), ("ncoarse", C.c_int),
-                ("cheb_lo", C.c_double), ("cheb_hi", C.c_double), ("nlanczos", C.c_int), ("fine_eig", C.c_int)]
+                ("cheb_lo", C.c_double), ("cheb_hi", C.c_double), ("nlanczos", C.c_int), ("fine_eig", C.c_int),
+                ("ksp_mode", C.c_int), ("restart", C.c_int), ("smooth_pc", C.c_int), ("coarse_pc", C.c_int),
+                ("coarse_restart", C.c_int), ("coarse_rtol", C.c_double)]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_long)
@@ -93,6 +95,8 @@ SYMBOLS = {
     "tp_elasticity_level_apply": (_i, [_vp, _i, _vp, _vp]),
     "tp_elasticity_level_diag": (_i, [_vp, _i, _vp]),
     "tp_elasticity_precond": (_i, [_vp, _vp, _vp]),
+    "tp_elasticity_level_pc": (_i, [_vp, _i, _i, _vp, _vp]),
+    "tp_elasticity_level_gmres": (_i, [_vp, _i, _i, _i, _i, _d, _vp, _vp, _i, C.POINTER(_i)]),
     "tp_elasticity_smooth": (_i, [_vp, _i, _vp, _vp, _i, _i]),
     "tp_elasticity_restrict": (_i, [_vp, _i, _vp, _vp]),
     "tp_elasticity_prolong_add": (_i, [_vp, _i, _vp, _vp]),
