@@ -23,16 +23,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# name: elements (ex, ey, ez per GPU; domain edge h = 1/ey), multigrid depth and the two iteration counts of the V-cycle.
+# nlvls: what BASELINE.json states where it states one (configs[1]: 3, configs[4]: 4), otherwise coarsened until the
+# coarsest grid is a few hundred nodes.  nsmooth = 2 is PETSc's own default for Chebyshev smoothers
+# (-mg_levels_ksp_max_it 2); the reference's "4" (LinearElasticity.cc:635) and "30" (:631) are the counts of its GMRES/SOR
+# level solvers, a far stronger -- and sequential -- smoother.  Scans: tools/sweep_solver_params.sh, DESIGN.md 4.5.
 WORKLOADS = {
-    # name: (ex, ey, ez_per_gpu, nlvls)   domain edge h = 1/ey
-    "cantilever128": (128, 128, 128, 4),   # BASELINE.json metric mesh: 128^3 elements, 6.44 M DOF
-    "c2": (128, 64, 64, 3),                # configs[1]
-    "c1": (48, 24, 24, 4),                 # configs[0]
-    "cube256": (256, 256, 256, 4),         # north-star SpMV target mesh
-    "c3": (256, 128, 128, 4),              # configs[2] on ONE GPU (12.8 M DOF); with --gpus 8: 256x128x(128*8)
-    "c4": (192, 64, 64, 3, 2, "mbb"),      # configs[3]: MBB beam, Helmholtz (PDE) filter
-    "c5": (512, 256, 256, 4),              # configs[4] on ONE GPU (101.7 M DOF, ~35 GB of the 288 GB); with --gpus 8 --scaling strong: its slabs
-    "tiny": (32, 16, 16, 3),
+    "cantilever128": dict(el=(128, 128, 128), nlvls=5, nsmooth=2, ncoarse=45),  # BASELINE.json metric mesh, 6.44 M DOF
+    "c2": dict(el=(128, 64, 64), nlvls=3, nsmooth=2, ncoarse=45),               # configs[1] ("3-level GMG")
+    "c1": dict(el=(48, 24, 24), nlvls=4, nsmooth=2, ncoarse=22),                # configs[0]
+    "cube256": dict(el=(256, 256, 256), nlvls=6, nsmooth=2, ncoarse=45),        # north-star SpMV target mesh
+    "c3": dict(el=(256, 128, 128), nlvls=5, nsmooth=2, ncoarse=45),             # configs[2] on ONE GPU (12.8 M DOF); with --gpus 8: 256x128x(128*8)
+    "c4": dict(el=(192, 64, 64), nlvls=4, nsmooth=2, ncoarse=45, ftype=2, bc="mbb"),  # configs[3]: MBB beam, Helmholtz (PDE) filter
+    "c5": dict(el=(512, 256, 256), nlvls=4, nsmooth=2, ncoarse=60),             # configs[4] ("4-level GMG") on ONE GPU (101.7 M DOF, ~35 GB of the 288 GB); with --gpus 8 --scaling strong: its slabs
+    "tiny": dict(el=(32, 16, 16), nlvls=3, nsmooth=2, ncoarse=30),
 }
 
 
@@ -45,8 +49,8 @@ def parse():
     p.add_argument("--rtol", type=float, default=1e-5)
     p.add_argument("--fine-eig", type=int, default=0, help="1: Lanczos estimate for the fine-level Chebyshev window")
     p.add_argument("--nlvls", type=int, default=0, help="override the multigrid depth of the workload")
-    p.add_argument("--ncoarse", type=int, default=30)
-    p.add_argument("--nsmooth", type=int, default=4)
+    p.add_argument("--ncoarse", type=int, default=0, help="coarse-solve Chebyshev steps (0: the workload's)")
+    p.add_argument("--nsmooth", type=int, default=0, help="Chebyshev steps per smoothing sweep (0: the workload's)")
     p.add_argument("--spmv-reps", type=int, default=50)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", default="96x48x48")
@@ -70,19 +74,20 @@ def respawn_under_torchrun(n):
     os.execv(sys.executable, cmd)
 
 
-def cpu_baseline(sample, rtol, fine_eig, gpu_ndof):
+def cpu_baseline(sample, rtol, fine_eig, gpu_ndof, nlv=4, nsmooth=4, ncoarse=30):
     """The oracle (a port of the reference's assembled-CSR path, OpenMP) timed on
     the host cores for one step of the same algorithm on a bounded sample mesh."""
     from oracle import oracle as orc
     ex, ey, ez = [int(v) for v in sample.split("x")]
-    nlv = 4
+    while nlv > 1 and (ex % (1 << (nlv - 1)) or ey % (1 << (nlv - 1)) or ez % (1 << (nlv - 1))):
+        nlv -= 1
     nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
     cores = int(os.environ.get("OMP_NUM_THREADS", min(os.cpu_count() or 1, 16)))
     x = orc.synth_density(ex, ey, ez, h)
     KE = orc.hex8_ke_box(h, h, h, 0.3)
     N, R = orc.cantilever_bc(nx, ny, nz, h)
     flt = orc.Filter(nx, ny, nz, h, 2.56 * h)
-    mg = orc.MG(nx, ny, nz, 3, nlv, fine_eig=fine_eig)
+    mg = orc.MG(nx, ny, nz, 3, nlv, nsmooth, ncoarse, fine_eig=fine_eig)
     t0 = time.perf_counter()
     xt, xp = flt.project(1, x)
     mg.assemble(KE, orc.simp(xp), N)
@@ -95,8 +100,9 @@ def cpu_baseline(sample, rtol, fine_eig, gpu_ndof):
     return {"value": ndof / t, "unit": "DOF-updates/s", "cores": cores, "kind": "port",
             "sample_n_dof": ndof, "gpu_line_n_dof": gpu_ndof,
             "sample": "1 step on %s elements (%d DOF -- NOT the GPU line's %d-DOF mesh: bounded to ~15 s of host time), "
-                      "%d levels, CG its %d, %.2f s; assembled CSR + Galerkin SpGEMM (the reference's data path), "
-                      "OpenMP on %d threads" % (sample, ndof, gpu_ndof, nlv, its, t, cores)}
+                      "%d levels, Chebyshev(%d) / coarse Chebyshev(%d) as on the GPU line, CG its %d, %.2f s; assembled CSR + "
+                      "Galerkin SpGEMM (the reference's data path), OpenMP on %d threads" % (sample, ndof, gpu_ndof, nlv, nsmooth,
+                                                                                             ncoarse, its, t, cores)}
 
 
 def fine_kernel_times(tp, torch, ex, ey, ez, reps):
@@ -158,9 +164,12 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    ex, ey, ezg, nlv = WORKLOADS[a.workload][:4]
-    ftype, bc = (WORKLOADS[a.workload] + (1, "cantilever"))[4:6]
-    nlv = a.nlvls or nlv
+    W = WORKLOADS[a.workload]
+    ex, ey, ezg = W["el"]
+    ftype, bc = W.get("ftype", 1), W.get("bc", "cantilever")
+    nlv = a.nlvls or W["nlvls"]
+    a.nsmooth = a.nsmooth or W["nsmooth"]
+    a.ncoarse = a.ncoarse or W["ncoarse"]
     if a.scaling == "strong" and (ezg % world or (ezg // world) % (1 << (nlv - 1))):
         raise SystemExit("strong scaling: %d element layers do not split into %d slabs of whole coarse layers" % (ezg, world))
     ez = ezg * world if a.scaling == "weak" else ezg  # weak: fixed slab per GPU; strong: fixed mesh
@@ -311,7 +320,7 @@ def main():
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.cpu_sample, a.rtol, a.fine_eig, ndof)
+        out["cpu_baseline"] = cpu_baseline(a.cpu_sample, a.rtol, a.fine_eig, ndof, nlv, a.nsmooth, a.ncoarse)
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -99,6 +99,22 @@ def test_vcycle(tp, orc):
     assert rel(host(le.precond(dev(r))), mg.precond(r)) <= 1e-11
 
 
+@pytest.mark.parametrize("mesh,nlv,ns,nc", [((32, 16, 16), 5, 2, 45), ((32, 32, 32), 6, 2, 45), ((48, 24, 24), 4, 2, 22),
+                                            ((32, 16, 16), 3, 1, 60)])
+def test_bench_cycle_parameters(tp, orc, mesh, nlv, ns, nc):
+    """the multigrid depths and iteration counts bench.py runs its workloads with (down to a coarsest grid of 3 x 2 x 2 /
+    2 x 2 x 2 nodes): same iteration count, residual history and solution as the oracle with the same parameters"""
+    grid, le, mg, x, KE, N, R = make(tp, orc, *mesh, nlv, "synth", rtol=1e-9, max_it=400, nsmooth=ns, ncoarse=nc)
+    its = le.KSPSolve(hist_cap=400)
+    Uo, its_o, hist_o = mg.solve(R * N, rtol=1e-9, maxit=400)
+    assert its == its_o
+    assert np.abs(le.last_hist[:10] / hist_o[:10] - 1).max() <= 1e-10
+    assert np.abs(le.last_hist / hist_o - 1).max() <= 1e-6
+    assert rel(host(le.U), Uo) <= 1e-9
+    for l in range(nlv):
+        assert le.level_lambda(l) == pytest.approx(mg.lam(l), rel=1e-9)
+
+
 @pytest.mark.parametrize("kind,nlv", [("uniform", 3), ("synth", 3), ("synth", 2)])
 def test_solve_residual_history(tp, orc, kind, nlv):
     """KSP residual history and solution against the oracle running the same

@@ -67,6 +67,13 @@ def test_four_ranks_one_gpu_interior_slabs():
 
 
 @pytest.mark.gpu
+def test_bench_cycle_on_slabs():
+    """the V-cycle bench.py runs on the metric mesh (5 levels, Chebyshev(2) smoothing, Chebyshev(45) coarse solve) on two
+    slabs: four levels stay distributed, the fifth is the replicated copy"""
+    _launch("gpu", nproc=2, extra=(32, 16, 64, 5, 2, 45))
+
+
+@pytest.mark.gpu
 def test_eight_ranks_one_gpu_c3_c5_slab_geometry():
     """The 8-GPU slab geometry of BASELINE configs C3 (256x128x128) and C5 (512x256x256) before hardware sees it:
     8 ranks, 4 multigrid levels, 16 fine = 2 coarsest-level element layers per rank, replicated coarsest level,
