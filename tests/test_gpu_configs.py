@@ -223,3 +223,29 @@ def test_graphed_coarsest_smoothing_bits(tp):
         assert res[0][k][1] == res[1][k][1] and res[0][k][1] > 4
         if not os.environ.get("TP_DEBUG_SYNC"):   # (per-launch synchronisation switches graph replay off)
             assert res[1][k][2] < res[0][k][2], (res[1][k][2], res[0][k][2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mesh,nl", [((64, 32, 32), 4), ((32, 32, 32), 5), ((48, 24, 24), 3)])
+def test_coarsest_run_in_one_launch_bits(tp, mesh, nl):
+    """TP_COARSE_RUN=1 (csrc/coarse_run.h): the Chebyshev steps of the coarsest level as iterations inside ONE kernel --
+    stencil parts in registers, the iterate exchanged between the workgroups past the L2, a barrier per step -- give the
+    same bits as the launches (9 x 5 x 5, 3 x 3 x 3 and 13 x 7 x 7 nodes: 1, 1 and 4 rows per thread), with fewer launches."""
+    ex, ey, ez = mesh
+    g = tp.Grid(ex + 1, ey + 1, ez + 1, 1.0 / ey)
+    le = tp.LinearElasticity(g, tp.SolverOptions(nlvls=nl, nsmooth=2, ncoarse=45))
+    le.SetUpLoadAndBC()
+    res = []
+    for run in (False, True):
+        if run:
+            os.environ["TP_COARSE_RUN"] = "1"
+        try:
+            le.AssembleStiffnessMatrix(g.synth_density(3), 1e-9, 1.0, 3.0)
+            le.pop_stats()
+            le.U.zero_()
+            le.KSPSolve()
+            res.append((host(le.U), le.last_its, le.pop_stats()[2]))
+        finally:
+            os.environ.pop("TP_COARSE_RUN", None)
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1] > 4
+    assert res[1][2] < 0.6 * res[0][2], (res[1][2], res[0][2])

@@ -1,0 +1,166 @@
+// coarse_run.h -- the Chebyshev run of the coarsest level (30-60 steps on a few hundred to a few thousand nodes) in ONE
+// launch.  As separate launches every step costs the dependent-dispatch latency of the device (~6.5 us for a ~2 us
+// kernel; measured, also under hipGraph replay), 58 % of all launches of a design iteration at 128^3.  Here the steps
+// are iterations of a loop inside one kernel of at most 64 resident workgroups:
+//   * every thread keeps ITS part of the stencil in registers for the whole run (a row is split over 9 threads by the
+//     (z, y) offset of the neighbour, exactly as in k_dia_row_split<.,.,9>; R rows per thread), the part-0 thread of a
+//     row also keeps the row's iterate, direction, right-hand side and Jacobi factor;
+//   * per step only the iterate travels: written with agent-scope stores into one of two buffers; after a barrier over
+//     the workgroups (one arrival counter, release / relaxed polling: 1.4 us for 8, 2.3-3.3 us for 64 workgroups --
+//     tools/probe/barrier_probe.hip) every workgroup copies the contiguous stretch of the iterate its rows couple to
+//     (own nodes +- one plane, one row, one node) into LDS with ONE round of coalesced cache-bypassing loads (sc1: the
+//     L2 slices of the XCDs are not coherent with each other).  First version: agent-scope ATOMIC loads straight from
+//     the stencil loop -- the compiler waits for each of them (s_waitcnt vmcnt(0) after every load), 36 serial round
+//     trips per step: 11 us per step, slower than the launches;
+//   * the arithmetic of a row is the one of k_dia_row_split<DOF, EPI_CHEB, 9>: same products, same order, same bits.
+// A workgroup that waits longer than ~1 s (its peers not resident: cannot happen with <= 64 workgroups on an otherwise
+// idle queue, but a hang would take the device down) gives up everywhere and poisons the result with NaN, which the
+// Krylov loop reports as divergence.
+#pragma once
+#include "operators.h"
+
+constexpr int RUN_WG = 512, RUN_RPB = RUN_WG / 9;  // 56 rows x 9 parts per round of a workgroup
+constexpr int RUN_MAXK = 96, RUN_MAX_WGS = 64;
+constexpr int RUN_XS = 6144;  // doubles of the iterate a workgroup stages per step (48 KB)
+
+struct ChebRunCoef {
+    double c1[RUN_MAXK], c2[RUN_MAXK];
+    int nsteps;
+};
+
+// doubles of the iterate that a workgroup of R x RUN_RPB rows couples to (upper bound; host-side eligibility check)
+inline long run_stage_doubles(const Geom &g, int dof, int R) {
+    const long own = ((long)RUN_RPB * R + dof - 1) / dof + 1;
+    return dof * (own + 2 * (g.plane() + g.nx + 1));
+}
+
+template <int DOF, int R>
+__global__ __launch_bounds__(RUN_WG) void k_dia_cheb_run(DiaOp<DOF> op, const double *__restrict__ b,
+                                                         const double *__restrict__ dinv, const double *__restrict__ d0,
+                                                         double *xa, double *xb, ChebRunCoef cr, unsigned long long *cnt,
+                                                         unsigned long long base) {
+    __shared__ double s_part[9][RUN_RPB * R];
+    __shared__ double xs[RUN_XS];
+    __shared__ int s_dead;
+    typedef unsigned u2_r __attribute__((ext_vector_type(2)));
+    const Geom &g = op.g;
+    const long plane = g.plane();
+    const long nown = g.owned_nodes() * DOF;
+    const int part = threadIdx.x / RUN_RPB, r = threadIdx.x % RUN_RPB;
+    const bool lane_ok = part < 9;
+    // the stretch of nodes this workgroup reads: its rows' nodes +- (plane + nx + 1), clamped to the array
+    const long t_lo = (long)blockIdx.x * R * RUN_RPB, t_hi = min(t_lo + (long)R * RUN_RPB, nown) - 1;
+    const long reach = plane + g.nx + 1;
+    const long n_first = max((t_lo + plane * g.own_lo * DOF) / DOF - reach, 0L);
+    const long n_last = min((t_hi + plane * g.own_lo * DOF) / DOF + reach, g.nodes() - 1);
+    const int stage_n = (int)((n_last - n_first + 1) * DOF);  // <= RUN_XS (checked by the host)
+    double coef[R][3 * DOF];
+    int nbi[R][3];
+    long row[R];
+    bool valid[R];
+    double e_b[R], e_di[R], dcur[R], xo[R];
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+        const long t = t_lo + (long)m * RUN_RPB + r;
+        valid[m] = lane_ok && t < nown;
+        const long q = (valid[m] ? t : 0) + plane * g.own_lo * DOF;
+        row[m] = q;
+        const long n = q / DOF;
+        const int k = (int)(n / plane);
+        const int rem = (int)(n % plane);
+        const int j = rem / g.nx, i = rem % g.nx;
+        const int dk = part / 3 - 1, dj = part % 3 - 1;
+        const bool okj = k + dk >= 0 && k + dk < g.nzl && j + dj >= 0 && j + dj < g.ny;
+#pragma unroll
+        for (int di = -1; di <= 1; di++) {
+            const bool ok = okj && i + di >= 0 && i + di < g.nx;
+            const int blk = ((lane_ok ? dk : 0) + 1) * 9 + ((lane_ok ? dj : 0) + 1) * 3 + (di + 1);
+            // coefficients of non-existent neighbours are stored as zeros: only the address is made safe
+            const long nb = ok ? n + di + (long)g.nx * (dj + (long)g.ny * dk) : n;
+            nbi[m][di + 1] = valid[m] ? (int)((nb - n_first) * DOF) : 0;  // index into the staged stretch
+#pragma unroll
+            for (int c = 0; c < DOF; c++) coef[m][(di + 1) * DOF + c] = valid[m] ? op.S[(long)(blk * DOF + c) * op.nrows + q] : 0.0;
+        }
+        const bool own = valid[m] && part == 0;
+        e_b[m] = own ? b[q] : 0.0;
+        e_di[m] = own ? dinv[q] : 0.0;
+        dcur[m] = own ? d0[q] : 0.0;
+        xo[m] = own ? xa[q] : 0.0;
+    }
+    const double *xin = xa;
+    double *xout = xb;
+    bool dead = false;
+    for (int s = 0; s < cr.nsteps; s++) {
+        // ---- this step's input: one round of coalesced loads past the (non-coherent) L2
+        {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(xin) + n_first * DOF, 0, stage_n * 8, 0x00020000);
+            // all loads first (offsets past the stretch are dropped by the buffer bounds check), then the LDS writes
+            constexpr int NST = RUN_XS / RUN_WG;
+            double tmp[NST];
+#pragma unroll
+            for (int q = 0; q < NST; q++)
+                tmp[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, (threadIdx.x + q * RUN_WG) * 8, 0, 16 /* sc1 */));
+#pragma unroll
+            for (int q = 0; q < NST; q++)
+                if (threadIdx.x + q * RUN_WG < stage_n) xs[threadIdx.x + q * RUN_WG] = tmp[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+            double y = 0.0;
+            if (valid[m]) {
+#pragma unroll
+                for (int d3 = 0; d3 < 3; d3++)
+#pragma unroll
+                    for (int c = 0; c < DOF; c++) y = fma(coef[m][d3 * DOF + c], xs[nbi[m][d3] + c], y);
+            }
+            if (lane_ok) s_part[part][m * RUN_RPB + r] = y;
+        }
+        __syncthreads();
+        if (part == 0) {
+#pragma unroll
+            for (int m = 0; m < R; m++)
+                if (valid[m]) {
+                    double y = s_part[0][m * RUN_RPB + r];
+#pragma unroll
+                    for (int p = 1; p < 9; p++) y += s_part[p][m * RUN_RPB + r];
+                    const double dn = cheb_dn(cr.c1[s], dcur[m], cr.c2[s], e_di[m], e_b[m], y);
+                    dcur[m] = dn;
+                    xo[m] = xo[m] + dn;
+                    __hip_atomic_store(&xout[row[m]], xo[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+        }
+        if (s + 1 == cr.nsteps) break;  // nobody reads this kernel's last output before the kernel ends
+        // ---- barrier over the workgroups of the run
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long target = base + (unsigned long long)(s + 1) * gridDim.x;
+            long spins = 0;
+            int gave_up = 0;
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                // (the give-up flag is looked at every 4096 polls only: a second load per poll doubles the wake-up latency)
+                if ((++spins & 4095) == 0 &&
+                    (spins > 2000000L || __hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    __hip_atomic_store(cnt + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    gave_up = 1;
+                    break;
+                }
+            }
+            s_dead = gave_up;
+        }
+        __syncthreads();
+        if (s_dead) {
+            dead = true;
+            break;
+        }
+        const double *tmp = xout;
+        xout = const_cast<double *>(xin);
+        xin = tmp;
+    }
+    if (dead && part == 0) {
+#pragma unroll
+        for (int m = 0; m < R; m++)
+            if (valid[m]) xa[row[m]] = xb[row[m]] = __builtin_nan("");
+    }
+}

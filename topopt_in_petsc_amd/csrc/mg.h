@@ -7,6 +7,7 @@
 #include "galerkin.h"
 #include "grid.h"
 #include "operators.h"
+#include "coarse_run.h"
 #include "matfree_tile.h"
 #include "fine_tile.h"
 
@@ -405,6 +406,8 @@ struct MGSolver {
             for (double *p : {L.b, L.x, L.x2, L.r, L.d, L.dinv, L.S, L.Kel}) (void)hipFree(p);
         }
         for (double *p : {cg_r, cg_p, cg_w}) (void)hipFree(p);
+        (void)hipFree(run_cnt);
+        run_cnt = nullptr;
         for (LanBuf &b : lan) {
             (void)hipFree(b.V);
             (void)hipFree(b.coef);
@@ -766,6 +769,64 @@ struct MGSolver {
         *victim = ng;
         return TP_OK;
     }
+    // ---- the coarsest level's run in one launch (coarse_run.h)
+    unsigned long long *run_cnt = nullptr;  // [dev] arrival counter (monotone over the runs) + give-up flag
+    unsigned long long run_base = 0;        // arrivals of all runs so far
+    long coarse_runs = 0;
+    // rows per thread: the fewest that bring the run down to `want` workgroups (barrier cost grows with their number)
+    static int run_rows_per_thread(long rows, int *wgs) {
+        static const int want = getenv("TP_RUN_WGS") ? atoi(getenv("TP_RUN_WGS")) : 16;
+        int R = 1;
+        while (R < 8 && (rows + (long)RUN_RPB * R - 1) / ((long)RUN_RPB * R) > want) R *= 2;
+        *wgs = (int)((rows + (long)RUN_RPB * R - 1) / ((long)RUN_RPB * R));
+        return R;
+    }
+    bool coarse_run_ok(int l, int nsteps) const {
+        // opt-in (TP_COARSE_RUN=1): measured at 128^3 / C1 / C3 the run costs what its launches cost (19.7 against 19.6 ms,
+        // 654 against 1471 launches per design iteration) -- a step inside the kernel is 2.6-3.2 us (stores past the L2,
+        // release arrival, polling, staging loads past the L2: tools/probe/step_probe.hip), a dependent launch of a ~1 us
+        // kernel 3.1 us; the XCDs' L2 slices are not coherent, so either way the iterate makes a round trip through the
+        // memory side.  Kept as the evidence; off by default because a spinning kernel is a liability on a shared device.
+        const char *sw = getenv("TP_COARSE_RUN");  // read per call: the tests switch it within a process
+        const bool off = !(sw && atoi(sw) == 1);
+        const Level<DOF> &L = lv[l];
+        if (off || sg_capturing || DOF != 3 || L.kind != LV_DIA || !(l == nlv - 1 || l == nlv)) return false;
+        if (!(L.no_comm || !grid->has_comm) || nsteps < 4 || nsteps > RUN_MAXK) return false;
+        int wgs;
+        const int R = run_rows_per_thread(L.own_n(), &wgs);
+        return wgs <= RUN_MAX_WGS && run_stage_doubles(L.g, DOF, R) <= RUN_XS;
+    }
+    // steps it0 .. k-1 of smooth() (it0 >= 1: the direction vector L.d is valid)
+    int coarse_run(int l, const double *b, int it0, int k, double sigma, double delta) {
+        Level<DOF> &L = lv[l];
+        if (!run_cnt) {
+            TP_HIP(hipMalloc((void **)&run_cnt, 2 * sizeof(unsigned long long)));
+            TP_HIP(hipMemset(run_cnt, 0, 2 * sizeof(unsigned long long)));
+        }
+        ChebRunCoef cr;
+        cr.nsteps = k - it0;
+        double rho = 1.0 / sigma;
+        for (int s = 0; s < cr.nsteps; s++) {
+            const double rn = 1.0 / (2.0 * sigma - rho);
+            cr.c1[s] = rn * rho;
+            cr.c2[s] = 2.0 * rn / delta;
+            rho = rn;
+        }
+        int wgs;
+        const int R = run_rows_per_thread(L.own_n(), &wgs);
+        DiaOp<DOF> o{L.S, L.ndof(), L.g};
+        if (R == 1) TP_LAUNCH((k_dia_cheb_run<DOF, 1>), dim3(wgs), dim3(RUN_WG), 0, grid->stream, o, b, L.dinv, L.d, L.x, L.x2, cr, run_cnt, run_base);
+        else if (R == 2) TP_LAUNCH((k_dia_cheb_run<DOF, 2>), dim3(wgs), dim3(RUN_WG), 0, grid->stream, o, b, L.dinv, L.d, L.x, L.x2, cr, run_cnt, run_base);
+        else if (R == 4) TP_LAUNCH((k_dia_cheb_run<DOF, 4>), dim3(wgs), dim3(RUN_WG), 0, grid->stream, o, b, L.dinv, L.d, L.x, L.x2, cr, run_cnt, run_base);
+        else TP_LAUNCH((k_dia_cheb_run<DOF, 8>), dim3(wgs), dim3(RUN_WG), 0, grid->stream, o, b, L.dinv, L.d, L.x, L.x2, cr, run_cnt, run_base);
+        run_base += (unsigned long long)(cr.nsteps - 1) * wgs;  // no barrier after the last step
+        coarse_runs++;
+        const long nown = L.g.owned_nodes();
+        count_launch(grid, cr.nsteps * (27.0 * DOF * DOF + 6.0 * DOF) * 8.0 * nown, cr.nsteps * 2.0 * 27 * DOF * DOF * (double)nown);
+        if (cr.nsteps & 1) std::swap(L.x, L.x2);
+        return TP_OK;
+    }
+
     // Chebyshev(k)-Jacobi; the iterate ping-pongs between L.x and L.x2, on exit L.x holds it
     // dot_slot >= 0: the LAST step also leaves b . x in scal[dot_slot] (this rank's part; fine tile kernel only)
     int smooth(int l, const double *b, int k, bool zero_guess, int dot_slot = -1, bool first_done = false) {
@@ -800,6 +861,7 @@ struct MGSolver {
             count_launch(grid, 32.0 * L.own_n(), 2.0 * L.own_n());
             it = 1;
         }
+        if (it >= 1 && dot_slot < 0 && coarse_run_ok(l, k - it)) return coarse_run(l, b, it, k, sigma, delta);
         for (; it < k; it++) {
             NodeArgs a{};
             a.x = L.x;
