@@ -1,7 +1,9 @@
 // main.cc -- the reference's driver loop (main.cc:22-141) written against the C++ host mirror:
 // construct -> initial filter -> { solve + sensitivities, scale, filter gradients, move limits, MMA,
 // change, filter, MND, print }.  Command line: -nx -ny -nz (node counts, TopOpt.cc:154-160), -nlvls,
-// -maxItr, -filter, -rmin, -volfrac, -penal.  Output/restart files are out of scope.
+// -maxItr, -filter, -rmin, -volfrac, -penal, -mg_levels_ksp_max_it, -mg_coarse_ksp_max_it (Chebyshev steps of the
+// V-cycle; e.g. -nlvls 5 -mg_levels_ksp_max_it 2 -mg_coarse_ksp_max_it 45).  Output/restart files are out
+// of scope.
 // One process per GPU: `host/slabrun -n N ./host/topopt ...` starts the z-slab ranks (slab_comm.h: shared-memory
 // hooks, upgraded to the library's RCCL path where every rank has a GPU of its own).
 #include <algorithm>
@@ -44,7 +46,8 @@ int main(int argc, char **argv) {
         printf("# nodes %d x %d x %d, %ld elements and %ld DOF on rank 0 of %d, nlvls %d, filter %d, rmin %g\n", nx, ny, nz, nel,
                3 * tp_grid_owned_nodes(grid), sc.nranks, nlvls, filterType, rmin);
 
-    LinearElasticity *physics = new LinearElasticity(grid, nlvls, nu);
+    LinearElasticity *physics = new LinearElasticity(grid, nlvls, nu, (int)opt_d(argc, argv, "-mg_levels_ksp_max_it", 0),
+                                                     (int)opt_d(argc, argv, "-mg_coarse_ksp_max_it", 0));
     CHKERRQ(physics->err);
     Filter *filter = new Filter(grid, filterType, rmin);
     CHKERRQ(filter->err);
