@@ -25,7 +25,7 @@ if ROOT not in sys.path:
 
 # name: elements (ex, ey, ez per GPU; domain edge h = 1/ey), multigrid depth and the two iteration counts of the V-cycle.
 # nlvls: what BASELINE.json states where it states one (configs[1]: 3, configs[4]: 4), otherwise coarsened until the
-# coarsest grid is a few hundred nodes.  nsmooth = 2 is PETSc's own default for Chebyshev smoothers
+# coarsest grid is a few hundred nodes (128^3, C1) or until its Chebyshev run fits ONE workgroup (C3, C4: csrc/coarse_run.h).  nsmooth = 2 is PETSc's own default for Chebyshev smoothers
 # (-mg_levels_ksp_max_it 2); the reference's "4" (LinearElasticity.cc:635) and "30" (:631) are the counts of its GMRES/SOR
 # level solvers, a far stronger -- and sequential -- smoother.  Scans: tools/sweep_solver_params.sh, DESIGN.md 4.5.
 WORKLOADS = {
@@ -33,8 +33,8 @@ WORKLOADS = {
     "c2": dict(el=(128, 64, 64), nlvls=3, nsmooth=2, ncoarse=45),               # configs[1] ("3-level GMG")
     "c1": dict(el=(48, 24, 24), nlvls=4, nsmooth=2, ncoarse=22),                # configs[0]
     "cube256": dict(el=(256, 256, 256), nlvls=6, nsmooth=2, ncoarse=45),        # north-star SpMV target mesh
-    "c3": dict(el=(256, 128, 128), nlvls=5, nsmooth=2, ncoarse=45),             # configs[2] on ONE GPU (12.8 M DOF); with --gpus 8: 256x128x(128*8)
-    "c4": dict(el=(192, 64, 64), nlvls=4, nsmooth=2, ncoarse=45, ftype=2, bc="mbb"),  # configs[3]: MBB beam, Helmholtz (PDE) filter
+    "c3": dict(el=(256, 128, 128), nlvls=7, nsmooth=2, ncoarse=45),             # configs[2] on ONE GPU (12.8 M DOF); with --gpus 8: 256x128x(128*8)
+    "c4": dict(el=(192, 64, 64), nlvls=6, nsmooth=2, ncoarse=45, ftype=2, bc="mbb"),  # configs[3]: MBB beam, Helmholtz (PDE) filter
     "c5": dict(el=(512, 256, 256), nlvls=4, nsmooth=2, ncoarse=60),             # configs[4] ("4-level GMG") on ONE GPU (101.7 M DOF, ~35 GB of the 288 GB); with --gpus 8 --scaling strong: its slabs
     "tiny": dict(el=(32, 16, 16), nlvls=3, nsmooth=2, ncoarse=30),
 }

@@ -226,26 +226,30 @@ def test_graphed_coarsest_smoothing_bits(tp):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mesh,nl", [((64, 32, 32), 4), ((32, 32, 32), 5), ((48, 24, 24), 3)])
-def test_coarsest_run_in_one_launch_bits(tp, mesh, nl):
-    """TP_COARSE_RUN=1 (csrc/coarse_run.h): the Chebyshev steps of the coarsest level as iterations inside ONE kernel --
-    stencil parts in registers, the iterate exchanged between the workgroups past the L2, a barrier per step -- give the
-    same bits as the launches (9 x 5 x 5, 3 x 3 x 3 and 13 x 7 x 7 nodes: 1, 1 and 4 rows per thread), with fewer launches."""
+@pytest.mark.parametrize("mesh,nl,single", [((64, 32, 32), 4, False), ((32, 32, 32), 5, True), ((48, 24, 24), 3, False),
+                                            ((48, 24, 24), 4, True), ((64, 64, 64), 5, True)])
+def test_coarsest_run_in_one_launch_bits(tp, mesh, nl, single):
+    """csrc/coarse_run.h: the Chebyshev steps of the coarsest level as iterations inside ONE kernel.  Coarsest grids of
+    <= 448 rows (7 x 4 x 4, 5^3, 3^3 nodes here) run in ONE workgroup with the iterate in LDS -- the default; larger ones
+    (9 x 5 x 5, 13 x 7 x 7 nodes: 1 and 4 rows per thread) across workgroups with a barrier per step, opt-in
+    (TP_COARSE_RUN=1).  Either way: the same bits as the separate launches (TP_NO_COARSE_RUN=1), fewer launches."""
     ex, ey, ez = mesh
     g = tp.Grid(ex + 1, ey + 1, ez + 1, 1.0 / ey)
     le = tp.LinearElasticity(g, tp.SolverOptions(nlvls=nl, nsmooth=2, ncoarse=45))
     le.SetUpLoadAndBC()
-    res = []
-    for run in (False, True):
-        if run:
-            os.environ["TP_COARSE_RUN"] = "1"
+    res = {}
+    for mode, env in (("launches", {"TP_NO_COARSE_RUN": "1"}), ("default", {}), ("run", {"TP_COARSE_RUN": "1"})):
+        os.environ.update(env)
         try:
             le.AssembleStiffnessMatrix(g.synth_density(3), 1e-9, 1.0, 3.0)
             le.pop_stats()
             le.U.zero_()
             le.KSPSolve()
-            res.append((host(le.U), le.last_its, le.pop_stats()[2]))
+            res[mode] = (host(le.U), le.last_its, le.pop_stats()[2])
         finally:
-            os.environ.pop("TP_COARSE_RUN", None)
-    assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1] > 4
-    assert res[1][2] < 0.6 * res[0][2], (res[1][2], res[0][2])
+            for k in env:
+                os.environ.pop(k, None)
+    for mode in ("default", "run"):
+        assert np.array_equal(res["launches"][0], res[mode][0]) and res["launches"][1] == res[mode][1] > 4, mode
+    assert res["run"][2] < 0.6 * res["launches"][2], (res["run"][2], res["launches"][2])
+    assert (res["default"][2] < 0.6 * res["launches"][2]) == single, (res["default"][2], res["launches"][2])

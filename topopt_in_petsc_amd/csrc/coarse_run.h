@@ -13,6 +13,8 @@
 //     the stencil loop -- the compiler waits for each of them (s_waitcnt vmcnt(0) after every load), 36 serial round
 //     trips per step: 11 us per step, slower than the launches;
 //   * the arithmetic of a row is the one of k_dia_row_split<DOF, EPI_CHEB, 9>: same products, same order, same bits.
+//   * a level of at most 448 rows (coarsest grids of <= ~150 nodes) is ONE workgroup's work: the iterate then lives in
+//     LDS for the whole run, nothing travels and nobody waits -- 0.4-0.5 us per step instead of ~3 (SINGLE).
 // A workgroup that waits longer than ~1 s (its peers not resident: cannot happen with <= 64 workgroups on an otherwise
 // idle queue, but a hang would take the device down) gives up everywhere and poisons the result with NaN, which the
 // Krylov loop reports as divergence.
@@ -34,7 +36,7 @@ inline long run_stage_doubles(const Geom &g, int dof, int R) {
     return dof * (own + 2 * (g.plane() + g.nx + 1));
 }
 
-template <int DOF, int R>
+template <int DOF, int R, bool SINGLE>
 __global__ __launch_bounds__(RUN_WG) void k_dia_cheb_run(DiaOp<DOF> op, const double *__restrict__ b,
                                                          const double *__restrict__ dinv, const double *__restrict__ d0,
                                                          double *xa, double *xb, ChebRunCoef cr, unsigned long long *cnt,
@@ -42,29 +44,28 @@ __global__ __launch_bounds__(RUN_WG) void k_dia_cheb_run(DiaOp<DOF> op, const do
     __shared__ double s_part[9][RUN_RPB * R];
     __shared__ double xs[RUN_XS];
     __shared__ int s_dead;
-    typedef unsigned u2_r __attribute__((ext_vector_type(2)));
     const Geom &g = op.g;
     const long plane = g.plane();
     const long nown = g.owned_nodes() * DOF;
+    const long off = plane * g.own_lo * DOF;  // first owned row
     const int part = threadIdx.x / RUN_RPB, r = threadIdx.x % RUN_RPB;
     const bool lane_ok = part < 9;
     // the stretch of nodes this workgroup reads: its rows' nodes +- (plane + nx + 1), clamped to the array
     const long t_lo = (long)blockIdx.x * R * RUN_RPB, t_hi = min(t_lo + (long)R * RUN_RPB, nown) - 1;
     const long reach = plane + g.nx + 1;
-    const long n_first = max((t_lo + plane * g.own_lo * DOF) / DOF - reach, 0L);
-    const long n_last = min((t_hi + plane * g.own_lo * DOF) / DOF + reach, g.nodes() - 1);
+    const long n_first = max((t_lo + off) / DOF - reach, 0L);
+    const long n_last = min((t_hi + off) / DOF + reach, g.nodes() - 1);
     const int stage_n = (int)((n_last - n_first + 1) * DOF);  // <= RUN_XS (checked by the host)
+    // ---- stencil parts: thread (part, r) serves rows t_lo + m * RUN_RPB + r, m < R, with the 3 x DOF values of its
+    // (z, y) neighbour offset
     double coef[R][3 * DOF];
     int nbi[R][3];
-    long row[R];
     bool valid[R];
-    double e_b[R], e_di[R], dcur[R], xo[R];
 #pragma unroll
     for (int m = 0; m < R; m++) {
         const long t = t_lo + (long)m * RUN_RPB + r;
         valid[m] = lane_ok && t < nown;
-        const long q = (valid[m] ? t : 0) + plane * g.own_lo * DOF;
-        row[m] = q;
+        const long q = (valid[m] ? t : 0) + off;
         const long n = q / DOF;
         const int k = (int)(n / plane);
         const int rem = (int)(n % plane);
@@ -81,20 +82,26 @@ __global__ __launch_bounds__(RUN_WG) void k_dia_cheb_run(DiaOp<DOF> op, const do
 #pragma unroll
             for (int c = 0; c < DOF; c++) coef[m][(di + 1) * DOF + c] = valid[m] ? op.S[(long)(blk * DOF + c) * op.nrows + q] : 0.0;
         }
-        const bool own = valid[m] && part == 0;
-        e_b[m] = own ? b[q] : 0.0;
-        e_di[m] = own ? dinv[q] : 0.0;
-        dcur[m] = own ? d0[q] : 0.0;
-        xo[m] = own ? xa[q] : 0.0;
     }
+    // ---- the rows are FINISHED (partial sums added, Chebyshev update) one per thread: thread f takes row t_lo + f
+    const int f = threadIdx.x;
+    const bool fin = f < R * RUN_RPB && t_lo + f < nown;
+    const long qf = (fin ? t_lo + f : 0) + off;
+    const int xsf = (int)(qf - n_first * DOF);  // the row's own place in the staged stretch
+    const double e_b = fin ? b[qf] : 0.0, e_di = fin ? dinv[qf] : 0.0;
+    double dcur = fin ? d0[qf] : 0.0, xo = fin ? xa[qf] : 0.0;
     const double *xin = xa;
     double *xout = xb;
     bool dead = false;
+    if (SINGLE) {  // the whole level, once
+        for (int idx = threadIdx.x; idx < stage_n; idx += RUN_WG) xs[idx] = xa[n_first * DOF + idx];
+        __syncthreads();
+    }
     for (int s = 0; s < cr.nsteps; s++) {
-        // ---- this step's input: one round of coalesced loads past the (non-coherent) L2
-        {
+        if (!SINGLE) {
+            // ---- this step's input: one round of coalesced loads past the (non-coherent) L2; all loads first (offsets
+            // past the stretch are dropped by the buffer bounds check), then the LDS writes
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(xin) + n_first * DOF, 0, stage_n * 8, 0x00020000);
-            // all loads first (offsets past the stretch are dropped by the buffer bounds check), then the LDS writes
             constexpr int NST = RUN_XS / RUN_WG;
             double tmp[NST];
 #pragma unroll
@@ -103,8 +110,8 @@ __global__ __launch_bounds__(RUN_WG) void k_dia_cheb_run(DiaOp<DOF> op, const do
 #pragma unroll
             for (int q = 0; q < NST; q++)
                 if (threadIdx.x + q * RUN_WG < stage_n) xs[threadIdx.x + q * RUN_WG] = tmp[q];
+            __syncthreads();
         }
-        __syncthreads();
 #pragma unroll
         for (int m = 0; m < R; m++) {
             double y = 0.0;
@@ -116,19 +123,20 @@ __global__ __launch_bounds__(RUN_WG) void k_dia_cheb_run(DiaOp<DOF> op, const do
             }
             if (lane_ok) s_part[part][m * RUN_RPB + r] = y;
         }
-        __syncthreads();
-        if (part == 0) {
+        __syncthreads();  // partial sums complete; every read of this step's iterate done
+        if (fin) {
+            double y = s_part[0][f];
 #pragma unroll
-            for (int m = 0; m < R; m++)
-                if (valid[m]) {
-                    double y = s_part[0][m * RUN_RPB + r];
-#pragma unroll
-                    for (int p = 1; p < 9; p++) y += s_part[p][m * RUN_RPB + r];
-                    const double dn = cheb_dn(cr.c1[s], dcur[m], cr.c2[s], e_di[m], e_b[m], y);
-                    dcur[m] = dn;
-                    xo[m] = xo[m] + dn;
-                    __hip_atomic_store(&xout[row[m]], xo[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+            for (int p = 1; p < 9; p++) y += s_part[p][f];
+            const double dn = cheb_dn(cr.c1[s], dcur, cr.c2[s], e_di, e_b, y);
+            dcur = dn;
+            xo = xo + dn;
+            if (SINGLE) xs[xsf] = xo;
+            else __hip_atomic_store(&xout[qf], xo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (SINGLE) {
+            __syncthreads();
+            continue;
         }
         if (s + 1 == cr.nsteps) break;  // nobody reads this kernel's last output before the kernel ends
         // ---- barrier over the workgroups of the run
@@ -158,9 +166,6 @@ __global__ __launch_bounds__(RUN_WG) void k_dia_cheb_run(DiaOp<DOF> op, const do
         xout = const_cast<double *>(xin);
         xin = tmp;
     }
-    if (dead && part == 0) {
-#pragma unroll
-        for (int m = 0; m < R; m++)
-            if (valid[m]) xa[row[m]] = xb[row[m]] = __builtin_nan("");
-    }
+    if (SINGLE && fin) xa[qf] = xo;  // the result goes back to where the start came from
+    if (dead && fin) xa[qf] = xb[qf] = __builtin_nan("");
 }

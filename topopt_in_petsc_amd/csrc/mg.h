@@ -781,23 +781,25 @@ struct MGSolver {
         *wgs = (int)((rows + (long)RUN_RPB * R - 1) / ((long)RUN_RPB * R));
         return R;
     }
-    bool coarse_run_ok(int l, int nsteps) const {
-        // opt-in (TP_COARSE_RUN=1): measured at 128^3 / C1 / C3 the run costs what its launches cost (19.7 against 19.6 ms,
-        // 654 against 1471 launches per design iteration) -- a step inside the kernel is 2.6-3.2 us (stores past the L2,
-        // release arrival, polling, staging loads past the L2: tools/probe/step_probe.hip), a dependent launch of a ~1 us
-        // kernel 3.1 us; the XCDs' L2 slices are not coherent, so either way the iterate makes a round trip through the
-        // memory side.  Kept as the evidence; off by default because a spinning kernel is a liability on a shared device.
-        const char *sw = getenv("TP_COARSE_RUN");  // read per call: the tests switch it within a process
-        const bool off = !(sw && atoi(sw) == 1);
+    // 0: separate launches; 1: one launch of ONE workgroup (iterate in LDS; on unless TP_NO_COARSE_RUN);
+    // 2: one launch of several workgroups with a barrier per step (opt-in TP_COARSE_RUN=1: measured at 128^3 / C1 / C3 it
+    // costs what its launches cost, 19.7 against 19.6 ms at 654 against 1471 launches per design iteration -- a step inside
+    // the kernel is 2.6-3.2 us (tools/probe/step_probe.hip), a dependent launch 3.1 us: the XCDs' L2 slices are not coherent,
+    // either way the iterate makes a round trip through the memory side; and a spinning kernel is a liability on a shared
+    // device)
+    int coarse_run_mode(int l, int nsteps) const {
         const Level<DOF> &L = lv[l];
-        if (off || sg_capturing || DOF != 3 || L.kind != LV_DIA || !(l == nlv - 1 || l == nlv)) return false;
-        if (!(L.no_comm || !grid->has_comm) || nsteps < 4 || nsteps > RUN_MAXK) return false;
+        if (sg_capturing || DOF != 3 || L.kind != LV_DIA || !(l == nlv - 1 || l == nlv)) return 0;
+        if (!(L.no_comm || !grid->has_comm) || nsteps < 4 || nsteps > RUN_MAXK) return 0;
         int wgs;
         const int R = run_rows_per_thread(L.own_n(), &wgs);
-        return wgs <= RUN_MAX_WGS && run_stage_doubles(L.g, DOF, R) <= RUN_XS;
+        if (L.own_n() <= (long)RUN_RPB * 8 && L.ndof() <= RUN_XS && L.own_n() == L.ndof()) return getenv("TP_NO_COARSE_RUN") ? 0 : 1;
+        const char *sw = getenv("TP_COARSE_RUN");  // read per call: the tests switch it within a process
+        if (!(sw && atoi(sw) == 1)) return 0;
+        return wgs <= RUN_MAX_WGS && run_stage_doubles(L.g, DOF, R) <= RUN_XS ? 2 : 0;
     }
     // steps it0 .. k-1 of smooth() (it0 >= 1: the direction vector L.d is valid)
-    int coarse_run(int l, const double *b, int it0, int k, double sigma, double delta) {
+    int coarse_run(int l, const double *b, int it0, int k, double sigma, double delta, int mode) {
         Level<DOF> &L = lv[l];
         if (!run_cnt) {
             TP_HIP(hipMalloc((void **)&run_cnt, 2 * sizeof(unsigned long long)));
@@ -812,18 +814,22 @@ struct MGSolver {
             cr.c2[s] = 2.0 * rn / delta;
             rho = rn;
         }
-        int wgs;
-        const int R = run_rows_per_thread(L.own_n(), &wgs);
         DiaOp<DOF> o{L.S, L.ndof(), L.g};
-        if (R == 1) TP_LAUNCH((k_dia_cheb_run<DOF, 1>), dim3(wgs), dim3(RUN_WG), 0, grid->stream, o, b, L.dinv, L.d, L.x, L.x2, cr, run_cnt, run_base);
-        else if (R == 2) TP_LAUNCH((k_dia_cheb_run<DOF, 2>), dim3(wgs), dim3(RUN_WG), 0, grid->stream, o, b, L.dinv, L.d, L.x, L.x2, cr, run_cnt, run_base);
-        else if (R == 4) TP_LAUNCH((k_dia_cheb_run<DOF, 4>), dim3(wgs), dim3(RUN_WG), 0, grid->stream, o, b, L.dinv, L.d, L.x, L.x2, cr, run_cnt, run_base);
-        else TP_LAUNCH((k_dia_cheb_run<DOF, 8>), dim3(wgs), dim3(RUN_WG), 0, grid->stream, o, b, L.dinv, L.d, L.x, L.x2, cr, run_cnt, run_base);
-        run_base += (unsigned long long)(cr.nsteps - 1) * wgs;  // no barrier after the last step
+        if (mode == 1) {
+            TP_LAUNCH((k_dia_cheb_run<DOF, 8, true>), dim3(1), dim3(RUN_WG), 0, grid->stream, o, b, L.dinv, L.d, L.x, L.x2, cr, run_cnt, run_base);
+        } else {
+            int wgs;
+            const int R = run_rows_per_thread(L.own_n(), &wgs);
+            if (R == 1) TP_LAUNCH((k_dia_cheb_run<DOF, 1, false>), dim3(wgs), dim3(RUN_WG), 0, grid->stream, o, b, L.dinv, L.d, L.x, L.x2, cr, run_cnt, run_base);
+            else if (R == 2) TP_LAUNCH((k_dia_cheb_run<DOF, 2, false>), dim3(wgs), dim3(RUN_WG), 0, grid->stream, o, b, L.dinv, L.d, L.x, L.x2, cr, run_cnt, run_base);
+            else if (R == 4) TP_LAUNCH((k_dia_cheb_run<DOF, 4, false>), dim3(wgs), dim3(RUN_WG), 0, grid->stream, o, b, L.dinv, L.d, L.x, L.x2, cr, run_cnt, run_base);
+            else TP_LAUNCH((k_dia_cheb_run<DOF, 8, false>), dim3(wgs), dim3(RUN_WG), 0, grid->stream, o, b, L.dinv, L.d, L.x, L.x2, cr, run_cnt, run_base);
+            run_base += (unsigned long long)(cr.nsteps - 1) * wgs;  // no barrier after the last step
+            if (cr.nsteps & 1) std::swap(L.x, L.x2);
+        }
         coarse_runs++;
         const long nown = L.g.owned_nodes();
         count_launch(grid, cr.nsteps * (27.0 * DOF * DOF + 6.0 * DOF) * 8.0 * nown, cr.nsteps * 2.0 * 27 * DOF * DOF * (double)nown);
-        if (cr.nsteps & 1) std::swap(L.x, L.x2);
         return TP_OK;
     }
 
@@ -861,7 +867,10 @@ struct MGSolver {
             count_launch(grid, 32.0 * L.own_n(), 2.0 * L.own_n());
             it = 1;
         }
-        if (it >= 1 && dot_slot < 0 && coarse_run_ok(l, k - it)) return coarse_run(l, b, it, k, sigma, delta);
+        if (it >= 1 && dot_slot < 0) {
+            const int mode = coarse_run_mode(l, k - it);
+            if (mode) return coarse_run(l, b, it, k, sigma, delta, mode);
+        }
         for (; it < k; it++) {
             NodeArgs a{};
             a.x = L.x;
