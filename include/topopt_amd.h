@@ -123,6 +123,11 @@ int tp_rccl_load(const char *librccl_path);
 int tp_rccl_unique_id(void *id128);
 int tp_grid_use_rccl(tp_grid *g, const void *id128);
 int tp_grid_comm_stats(const tp_grid *g, long *exchanges, long *reductions);   /* RCCL path only, else zeros */
+/* The roofline kernel timed where it runs (bench.py): with on = 1 every launch of the fine level's fused operator +
+ * Chebyshev step is bracketed by a pair of HIP events on the grid's stream; the read waits for the stream, returns
+ * the summed elapsed time and the number of launches, and clears the list. */
+int tp_grid_kernel_timer(tp_grid *g, int on);
+int tp_grid_kernel_timer_read(tp_grid *g, double *total_ms, long *launches);
 /* halos that travelled on the second stream, overlapped with the interior planes of their producer (0 if the hooks
  * lack set_stream / exchange_direct, or with TP_OVERLAP=0) */
 long tp_grid_overlapped_halos(const tp_grid *g);

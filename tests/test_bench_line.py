@@ -30,5 +30,9 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"]) and 0 < rf["frac"] < 1
     assert "traffic" in rf and "traffic_source" in rf
+    # the roofline kernel is timed where it runs (an event pair per launch inside design iterations); the back-to-back
+    # figure (warm Infinity Cache) stands beside it
+    assert "inside two design iterations" in rf["avg_launch_how"] and rf["avg_launch_ms"] > 0
+    assert 0 < rf["back_to_back"]["frac"] < 1 and rf["back_to_back"]["avg_launch_ms"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and isinstance(cb["sample"], str)

@@ -110,6 +110,16 @@ class Grid:
         """number of halos that travelled on the second stream, overlapped with interior planes (0 = none)"""
         return int(self.L.tp_grid_overlapped_halos(self.handle))
 
+    def kernel_timer(self, on):
+        """bracket every launch of the fine level's fused Chebyshev step with a HIP event pair (bench.py's roofline)"""
+        _chk(self.L.tp_grid_kernel_timer(self.handle, int(on)), "tp_grid_kernel_timer")
+
+    def kernel_timer_read(self):
+        """-> (average ms per launch, launches) since the timer was switched on / last read"""
+        t, n = C.c_double(0.0), C.c_long(0)
+        _chk(self.L.tp_grid_kernel_timer_read(self.handle, C.byref(t), C.byref(n)), "tp_grid_kernel_timer_read")
+        return (t.value / n.value if n.value else 0.0), n.value
+
     def _use_rccl(self, group):
         """Hand the slab exchange to RCCL inside the library (tp_grid_use_rccl): same RCCL instance as
         torch.distributed's nccl backend, no Python round trip per halo.  Every rank takes the same decision."""

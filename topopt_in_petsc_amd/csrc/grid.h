@@ -1,6 +1,7 @@
 // grid.h -- z-slab partition, halo exchange through the host framework's
 // collectives, deterministic reductions with device-resident results.
 #pragma once
+#include <vector>
 #include "common.h"
 
 struct tp_grid {
@@ -26,7 +27,18 @@ struct tp_grid {
     // accounting (algorithmic model)
     double alg_bytes, flops;
     long launches;
+    // opt-in timer of the roofline kernel IN PLACE (tp_grid_kernel_timer): a HIP event pair around every launch of the
+    // fine level's fused Chebyshev step, on the stream it is launched on
+    bool kt_on = false;
+    std::vector<hipEvent_t> kt_ev;  // pairs (start, stop)
 };
+inline void kernel_timer_mark(tp_grid *g) {
+    if (!g->kt_on) return;
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, g->stream);
+    g->kt_ev.push_back(e);
+}
 
 // geometry of multigrid level `l` of this rank's slab
 inline Geom make_geom(const tp_grid *g, int l) {

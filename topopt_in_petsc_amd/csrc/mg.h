@@ -493,6 +493,8 @@ struct MGSolver {
             static const int fine_v = getenv("TP_FINE_V") ? atoi(getenv("TP_FINE_V")) : 2;
             int kz = kz_env > 0 ? kz_env : fine_kz(planes, tx * ty, fine_v);
             if (kz > planes) kz = planes;
+            const bool timed = grid->kt_on && (EPI == EPI_CHEB || EPI == EPI_CHEB_DOT) && !split && !sg_capturing;
+            if (timed) kernel_timer_mark(grid);
             for (int pass = 0; pass < (split ? 2 : 1); pass++) {
                 int lo, hi, r1lo, r1hi;
                 tile_ranges(pass, lo, hi, r1lo, r1hi);
@@ -509,6 +511,7 @@ struct MGSolver {
                 }
                 if (split && pass == 0) TP_TRY(after_boundary());
             }
+            if (timed) kernel_timer_mark(grid);
             bytes = 16.0 * DOF * nown + 8.0 * L.g.own_elems();
             flops = 2.0 * 576 * (double)L.g.own_elems();
         } else if constexpr (EPI == EPI_CHEB_DOT) {

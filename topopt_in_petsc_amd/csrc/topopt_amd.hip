@@ -151,6 +151,32 @@ extern "C" int tp_grid_comm_selfcheck(tp_grid *g, int *ok) {
     return hook_failed ? TP_ERR_COMM : TP_OK;
 }
 extern "C" long tp_grid_overlapped_halos(const tp_grid *g) { return g ? g->n_overlapped : 0; }
+// HIP-event timing of the roofline kernel where it runs: on = 1 starts collecting a pair of events around every launch
+// of the fine level's fused Chebyshev step (one rank, unsplit launches); the read synchronises the stream, returns the
+// sum of the pairs' elapsed times and their number, and clears them
+extern "C" int tp_grid_kernel_timer(tp_grid *g, int on) {
+    if (!g) return TP_ERR_ARG;
+    g->kt_on = on != 0;
+    return TP_OK;
+}
+extern "C" int tp_grid_kernel_timer_read(tp_grid *g, double *total_ms, long *launches) {
+    if (!g || !total_ms || !launches) return TP_ERR_ARG;
+    TP_HIP(hipStreamSynchronize(g->stream));
+    double t = 0.0;
+    long n = 0;
+    for (size_t i = 0; i + 1 < g->kt_ev.size(); i += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g->kt_ev[i], g->kt_ev[i + 1]) == hipSuccess) {
+            t += ms;
+            n++;
+        }
+    }
+    for (hipEvent_t e : g->kt_ev) (void)hipEventDestroy(e);
+    g->kt_ev.clear();
+    *total_ms = t;
+    *launches = n;
+    return TP_OK;
+}
 extern "C" int tp_grid_comm_stats(const tp_grid *g, long *ex, long *red) {
     if (!g) return TP_ERR_ARG;
     if (ex) *ex = g->rccl ? g->rccl->n_exchanges : 0;
