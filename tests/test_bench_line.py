@@ -36,3 +36,22 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert 0 < rf["back_to_back"]["frac"] < 1 and rf["back_to_back"]["avg_launch_ms"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and isinstance(cb["sample"], str)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_spawns_its_own_ranks(scaling):
+    """`python bench.py --gpus 2` without a launcher re-executes itself under torch.distributed.run (what the driver's
+    scaling run does); here both slabs share the one GPU of the box (--same-device, host-staged gloo hooks)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-device", "--backend", "gloo",
+                        "--workload", "tiny", "--steps", "2", "--warmup", "1", "--scaling", scaling],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.split("\n") if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["value"] > 0
+    assert d["config"]["parallelism"] == "zslab2" and d["config"]["halo_overlap"] > 0
+    ez = 32 if scaling == "weak" else 16
+    assert "32x16x%d elements" % ez in d["config"]["workload"]
+    assert "cpu_baseline" not in d          # rank 0 of a 1-GPU job only
