@@ -282,6 +282,7 @@ extern "C" int tp_grid_destroy(tp_grid *g) {
     }
     if (g->ev_ready) (void)hipEventDestroy(g->ev_ready);
     if (g->ev_scal) (void)hipEventDestroy(g->ev_scal);
+    for (hipEvent_t e : g->kt_ev) (void)hipEventDestroy(e);  // a kernel timer that was never read
     (void)hipFree(g->partials);
     (void)hipFree(g->scal);
     (void)hipFree(g->ticket);
