@@ -238,3 +238,96 @@ def test_cg_equals_petsc_ksp_cg_restated(orc, warm):
     assert its_o == its
     assert np.abs(np.asarray(hist_o[: its + 1]) / np.asarray(hist) - 1).max() <= 1e-8
     assert np.abs(U - X).max() <= 1e-9 * np.abs(X).max()
+
+
+def _petsc_chebyshev(A, dinv, emin, emax, b, x0, k, zero_guess):
+    """KSPSolve_Chebyshev of PETSc 3.11 (three-term form, PCJACOBI, fixed eigenvalues, k = max_it, no test), see
+    test_chebyshev_equals_petsc_three_term_recurrence"""
+    if k == 0:
+        return x0.copy()
+    scale = 2.0 / (emax + emin)
+    alpha = 1.0 - scale * emin
+    mu = 1.0 / alpha
+    omegaprod = 2.0 / alpha
+    c_km1, c_k = 1.0, mu
+    p_km1 = x0.copy()
+    r = b.copy() if zero_guess else b - A @ p_km1
+    p_k = p_km1 + scale * (dinv * r)
+    for _ in range(1, k):
+        c_kp1 = 2.0 * mu * c_k - c_km1
+        omega = omegaprod * c_k / c_kp1
+        r = b - A @ p_k
+        p_kp1 = (1.0 - omega) * p_km1 + omega * p_k + omega * scale * (dinv * r)
+        p_km1, p_k = p_k, p_kp1
+        c_km1, c_k = c_k, c_kp1
+    return p_k
+
+
+@pytest.mark.parametrize("nlv,ns,nc", [(3, 4, 30), (4, 2, 45), (2, 1, 10)])
+def test_vcycle_equals_petsc_pcmg_restated(orc, nlv, ns, nc):
+    """PCApply_MG of PETSc 3.11 -- PC_MG_MULTIPLICATIVE, one V-cycle, x zeroed at the top and on every coarser level
+    (PCMGMCycle_Private), pre-smoother from the zero guess, default residual b - A x, restriction = transpose of the
+    interpolation (only PCMGSetInterpolation is called, LinearElasticity.cc:704), coarse KSP, correction added, the SAME
+    smoother again from the iterate -- restated in numpy on the oracle's level matrices and transfer operators, with
+    PETSc's Chebyshev recurrence as smoother and coarse solver (the option string of SURVEY 8(d) with the oracle's
+    numeric windows): equal to the oracle's own V-cycle to rounding."""
+    nx, ny, nz, h, KE, N, b, x, E = _problem(orc, 32, 16, 16, "synth")
+    mg = orc.MG(nx, ny, nz, 3, nlv, ns, nc)
+    mg.assemble(KE, E, N)
+    A = [mg.csr(l) for l in range(nlv)]
+    dinv = [1.0 / mg.diag(l) for l in range(nlv)]
+
+    def window(l):
+        coarsest = l == nlv - 1 and l > 0
+        return (mg.lam_min(l) if coarsest else 0.1 * mg.lam(l)), 1.1 * mg.lam(l)
+
+    def cycle(l, rhs):
+        lo, hi = window(l)
+        if l == nlv - 1:
+            return _petsc_chebyshev(A[l], dinv[l], lo, hi, rhs, np.zeros_like(rhs), nc, True)
+        xl = _petsc_chebyshev(A[l], dinv[l], lo, hi, rhs, np.zeros_like(rhs), ns, True)
+        rc = mg.restrict(l, rhs - A[l] @ xl)
+        xl = xl + mg.prolong(l, cycle(l + 1, rc))
+        return _petsc_chebyshev(A[l], dinv[l], lo, hi, rhs, xl, ns, False)
+
+    r = np.random.default_rng(5).standard_normal(b.size) * N
+    z = mg.precond(r)
+    zr = cycle(0, r)
+    assert np.abs(z - zr).max() <= 1e-11 * np.abs(zr).max()
+
+
+def test_transfer_equals_dmda_q1_interpolation_restated(orc):
+    """DMCreateInterpolation on a DMDA with Q1 elements and refinement factor 2 (what the reference passes to
+    PCMGSetInterpolation, LinearElasticity.cc:703-705): coarse node I sits on fine node 2I, odd fine nodes average their
+    two neighbours, dof by dof -- i.e. the Kronecker product Pz x Py x Px x I_3 of 1-D linear interpolations.  The
+    oracle's prolongation is that matrix, its restriction the transpose (MatRestrict of PCMG without an own restriction)."""
+    import scipy.sparse as sp
+    nx, ny, nz, h, KE, N, b, x, E = _problem(orc, 16, 8, 12, "synth")
+    mg = orc.MG(nx, ny, nz, 3, 3)
+    mg.assemble(KE, E, N)
+
+    def p1(nf):
+        nc = (nf - 1) // 2 + 1
+        P = sp.lil_matrix((nf, nc))
+        for i in range(nf):
+            if i % 2 == 0:
+                P[i, i // 2] = 1.0
+            else:
+                P[i, (i - 1) // 2] = 0.5
+                P[i, (i + 1) // 2] = 0.5
+        return P.tocsr()
+
+    rng = np.random.default_rng(9)
+    dims = (nx, ny, nz)
+    for l in range(2):
+        fx, fy, fz = [(d - 1) // (1 << l) + 1 for d in dims]
+        P = sp.kron(sp.kron(sp.kron(p1(fz), p1(fy)), p1(fx)), sp.identity(3)).tocsr()
+        assert P.shape == (mg.size(l), mg.size(l + 1))
+        xc = rng.standard_normal(mg.size(l + 1))
+        rf = rng.standard_normal(mg.size(l))
+        assert np.abs(mg.prolong(l, xc) - P @ xc).max() <= 1e-15 * np.abs(xc).max() * 8
+        assert np.abs(mg.restrict(l, rf) - P.T @ rf).max() <= 1e-14 * np.abs(rf).max() * 27
+        # Galerkin: the oracle's coarse matrix is P^T A P of ITS fine matrix (PCMGSetGalerkin both)
+        Ac = (P.T @ mg.csr(l) @ P).tocsr()
+        d = (Ac - mg.csr(l + 1)).tocoo()
+        assert np.abs(d.data).max() <= 1e-12 * np.abs(Ac.data).max()
