@@ -1652,6 +1652,12 @@ PetscErrorCode KSPSetFromOptions(KSP k) {
     ksp_apply_options(k, {k->prefix});
     return 0;
 }
+// (extension, include/petsc_shim.h) what a configured KSP resolves to on the MI355X path, without touching the device:
+// the tp_solver_opts the library would be created with, or PETSC_ERR_SUP
+PetscErrorCode KSPCompatResolve(KSP k, tp_solver_opts *o) {
+    if (!k || !o) return PETSC_ERR_ARG_WRONG;
+    return resolve(k, o);
+}
 PetscErrorCode KSPSetUp(KSP k) {
     if (!k->A) return PETSC_ERR_ORDER;
     if (k->A->kind == K_ELAST) return ensure_elasticity(k->A);

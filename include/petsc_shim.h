@@ -4,4 +4,13 @@
 #define TOPOPT_PETSC_SHIM_H
 #include "petsc_compat/petsc.h"
 #include "topopt_amd.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* what a configured KSP (types, tolerances, PCMG levels, options database) resolves to on the MI355X path -- the
+ * tp_solver_opts the library is created with at KSPSetUp -- or PETSC_ERR_SUP with a message; no device is touched */
+PetscErrorCode KSPCompatResolve(KSP ksp, tp_solver_opts *opts);
+#ifdef __cplusplus
+}
+#endif
 #endif

@@ -244,3 +244,57 @@ def test_petsc_shim_vec_operations():
         L.VecDestroy(C.byref(v))
     L.DMDestroy.argtypes = [C.POINTER(vp)]
     L.DMDestroy(C.byref(da))
+
+
+def _ksp_probe(*args, nranks=1):
+    _build()
+    exe = os.path.join(ROOT, "host", "ksp_probe")
+    cmd = [exe] + [str(a) for a in args]
+    if nranks > 1:
+        cmd = [os.path.join(ROOT, "host", "slabrun"), "-n", str(nranks)] + cmd
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=60)
+    m = re.search(r"KSP_PROBE mode (\d+) nlvls (\d+) rtol (\S+) atol (\S+) dtol (\S+) max_it (\d+) nsmooth (\d+) ncoarse (\d+) "
+                  r"restart (\d+) smooth_pc (\d+) coarse_pc (\d+) coarse_restart (\d+) coarse_rtol (\S+)", out.stdout)
+    if not m:
+        return out, None
+    keys = ("mode nlvls rtol atol dtol max_it nsmooth ncoarse restart smooth_pc coarse_pc coarse_restart coarse_rtol").split()
+    return out, {k: float(v) for k, v in zip(keys, m.groups())}
+
+
+FAST = ("-ksp_type cg -mg_levels_ksp_type chebyshev -mg_levels_pc_type jacobi -mg_coarse_ksp_type chebyshev "
+        "-mg_coarse_pc_type jacobi").split()
+
+
+def test_solver_configuration_the_compat_layer_resolves():
+    """Host logic without a GPU (host/ksp_probe replays the call sequence of the reference's two SetUpSolver methods):
+    with no option the hard-coded FGMRES / GMRES / SOR (or Jacobi) configuration resolves to ksp_mode 1 with the
+    reference's numbers; the option string of SURVEY 8(d) selects CG + Chebyshev/Jacobi and keeps the hard-coded counts
+    unless the options override them (level-specific prefixes included); everything else is PETSC_ERR_SUP = 56."""
+    out, o = _ksp_probe("le", 4)
+    assert o == dict(mode=1, nlvls=4, rtol=1e-5, atol=1e-50, dtol=1e5, max_it=200, nsmooth=4, ncoarse=30, restart=100,
+                     smooth_pc=1, coarse_pc=1, coarse_restart=30, coarse_rtol=1e-8), out.stdout + out.stderr
+    out, o = _ksp_probe("pde", 3)
+    assert o == dict(mode=1, nlvls=3, rtol=1e-8, atol=1e-50, dtol=1e3, max_it=60, nsmooth=1, ncoarse=10, restart=20,
+                     smooth_pc=0, coarse_pc=0, coarse_restart=10, coarse_rtol=1e-8), out.stdout + out.stderr
+    out, o = _ksp_probe("le", 4, *FAST)
+    assert (o["mode"], o["nlvls"], o["nsmooth"], o["ncoarse"], o["rtol"], o["max_it"]) == (0, 4, 4, 30, 1e-5, 200)
+    out, o = _ksp_probe("le", 5, *FAST, "-mg_levels_ksp_max_it", 2, "-mg_coarse_ksp_max_it", 45, "-ksp_rtol", "1e-7", "-ksp_max_it", 77)
+    assert (o["mode"], o["nlvls"], o["nsmooth"], o["ncoarse"], o["rtol"], o["max_it"]) == (0, 5, 2, 45, 1e-7, 77)
+    out, o = _ksp_probe("pde", 3, *FAST)
+    assert (o["mode"], o["nsmooth"], o["ncoarse"], o["rtol"], o["dtol"], o["max_it"]) == (0, 1, 10, 1e-8, 1e3, 60)
+    # options of the reference's own configuration
+    out, o = _ksp_probe("le", 3, "-ksp_gmres_restart", 50, "-mg_coarse_ksp_gmres_restart", 12, "-mg_coarse_ksp_rtol", "1e-6",
+                        "-mg_levels_pc_type", "jacobi")
+    assert (o["mode"], o["restart"], o["coarse_restart"], o["coarse_rtol"], o["smooth_pc"], o["coarse_pc"]) == (1, 50, 12, 1e-6, 0, 1)
+    # refused, with a message that names what is implemented
+    for extra, word in ((["-ksp_type", "gmres"], "outer KSP type 'gmres'"), (["-ksp_type", "cg"], "'gmres/sor'"),
+                        (["-mg_levels_ksp_type", "richardson"], "'richardson/sor'"), (["-pc_type", "gamg"], "PC type 'gamg'"),
+                        (FAST + ["-mg_levels_2_ksp_type", "gmres"], "level 2 smoother 'gmres/jacobi'"),
+                        (["-mg_levels_1_ksp_max_it", "3"], "differ from level to level")):
+        out, o = _ksp_probe("le", 4, *extra)
+        assert o is None and "KSP_PROBE error 56" in out.stdout and word in out.stderr, (extra, out.stderr[-600:])
+    # the reference's configuration on two ranks: PETSc's SOR is rank-local -- refused with the reason; the fast one is not
+    out, o = _ksp_probe("le", 4, nranks=2)
+    assert "more than one rank" in out.stderr and "KSP_PROBE error 56" in out.stdout
+    out, o = _ksp_probe("le", 4, *FAST, nranks=2)
+    assert out.returncode == 0 and out.stdout.count("KSP_PROBE mode 0") == 2
