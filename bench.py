@@ -29,11 +29,12 @@ if ROOT not in sys.path:
 # (-mg_levels_ksp_max_it 2); the reference's "4" (LinearElasticity.cc:635) and "30" (:631) are the counts of its GMRES/SOR
 # level solvers, a far stronger -- and sequential -- smoother.  Scans: tools/sweep_solver_params.sh, DESIGN.md 4.5.
 WORKLOADS = {
-    "cantilever128": dict(el=(128, 128, 128), nlvls=5, nsmooth=2, ncoarse=45),  # BASELINE.json metric mesh, 6.44 M DOF
+    # BASELINE.json metric mesh, 6.44 M DOF; levels 2 and 3 cycled twice (PCMGSetCycleTypeOnLevel W): 19.7 -> 17.8 ms, 19 -> 13 its
+    "cantilever128": dict(el=(128, 128, 128), nlvls=5, nsmooth=2, ncoarse=20, cycles="1,2,2,1"),
     "c2": dict(el=(128, 64, 64), nlvls=3, nsmooth=2, ncoarse=45),               # configs[1] ("3-level GMG")
     "c1": dict(el=(48, 24, 24), nlvls=4, nsmooth=2, ncoarse=22),                # configs[0]
     "cube256": dict(el=(256, 256, 256), nlvls=6, nsmooth=2, ncoarse=45),        # north-star SpMV target mesh
-    "c3": dict(el=(256, 128, 128), nlvls=7, nsmooth=2, ncoarse=45),             # configs[2] on ONE GPU (12.8 M DOF); with --gpus 8: 256x128x(128*8)
+    "c3": dict(el=(256, 128, 128), nlvls=7, nsmooth=2, ncoarse=20, cycles="1,2,2,2,2,1"),  # configs[2] on ONE GPU (12.8 M DOF); with --gpus 8: 256x128x(128*8)
     "c4": dict(el=(192, 64, 64), nlvls=6, nsmooth=2, ncoarse=45, ftype=2, bc="mbb"),  # configs[3]: MBB beam, Helmholtz (PDE) filter
     "c5": dict(el=(512, 256, 256), nlvls=4, nsmooth=2, ncoarse=60),             # configs[4] ("4-level GMG") on ONE GPU (101.7 M DOF, ~35 GB of the 288 GB); with --gpus 8 --scaling strong: its slabs
     "tiny": dict(el=(32, 16, 16), nlvls=3, nsmooth=2, ncoarse=30),
@@ -51,6 +52,7 @@ def parse():
     p.add_argument("--nlvls", type=int, default=0, help="override the multigrid depth of the workload")
     p.add_argument("--ncoarse", type=int, default=0, help="coarse-solve Chebyshev steps (0: the workload's)")
     p.add_argument("--nsmooth", type=int, default=0, help="Chebyshev steps per smoothing sweep (0: the workload's)")
+    p.add_argument("--cycles", default="", help="cycles of the next coarser level per level, finest first, e.g. 1,2,2 (1 = V, 2 = W)")
     p.add_argument("--spmv-reps", type=int, default=50)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", default="96x48x48")
@@ -74,7 +76,7 @@ def respawn_under_torchrun(n):
     os.execv(sys.executable, cmd)
 
 
-def cpu_baseline(sample, rtol, fine_eig, gpu_ndof, nlv=4, nsmooth=4, ncoarse=30):
+def cpu_baseline(sample, rtol, fine_eig, gpu_ndof, nlv=4, nsmooth=4, ncoarse=30, cycles=""):
     """The oracle (a port of the reference's assembled-CSR path, OpenMP) timed on
     the host cores for one step of the same algorithm on a bounded sample mesh."""
     from oracle import oracle as orc
@@ -88,6 +90,8 @@ def cpu_baseline(sample, rtol, fine_eig, gpu_ndof, nlv=4, nsmooth=4, ncoarse=30)
     N, R = orc.cantilever_bc(nx, ny, nz, h)
     flt = orc.Filter(nx, ny, nz, h, 2.56 * h)
     mg = orc.MG(nx, ny, nz, 3, nlv, nsmooth, ncoarse, fine_eig=fine_eig)
+    if cycles:
+        mg.set_cycles([int(v) for v in cycles.split(",")][: max(nlv - 1, 0)])
     t0 = time.perf_counter()
     xt, xp = flt.project(1, x)
     mg.assemble(KE, orc.simp(xp), N)
@@ -100,9 +104,10 @@ def cpu_baseline(sample, rtol, fine_eig, gpu_ndof, nlv=4, nsmooth=4, ncoarse=30)
     return {"value": ndof / t, "unit": "DOF-updates/s", "cores": cores, "kind": "port",
             "sample_n_dof": ndof, "gpu_line_n_dof": gpu_ndof,
             "sample": "1 step on %s elements (%d DOF -- NOT the GPU line's %d-DOF mesh: bounded to ~15 s of host time), "
-                      "%d levels, Chebyshev(%d) / coarse Chebyshev(%d) as on the GPU line, CG its %d, %.2f s; assembled CSR + "
+                      "%d levels, Chebyshev(%d) / coarse Chebyshev(%d)%s as on the GPU line, CG its %d, %.2f s; assembled CSR + "
                       "Galerkin SpGEMM (the reference's data path), OpenMP on %d threads" % (sample, ndof, gpu_ndof, nlv, nsmooth,
-                                                                                             ncoarse, its, t, cores)}
+                                                                                             ncoarse, " / cycles per level " + cycles if cycles else "",
+                                                                                             its, t, cores)}
 
 
 def fine_kernel_times(tp, torch, ex, ey, ez, reps):
@@ -170,6 +175,8 @@ def main():
     nlv = a.nlvls or W["nlvls"]
     a.nsmooth = a.nsmooth or W["nsmooth"]
     a.ncoarse = a.ncoarse or W["ncoarse"]
+    if not a.cycles and not a.nlvls:
+        a.cycles = W.get("cycles", "")     # (--cycles 1 forces plain V-cycles; an overridden depth takes no pattern along)
     if a.scaling == "strong" and (ezg % world or (ezg // world) % (1 << (nlv - 1))):
         raise SystemExit("strong scaling: %d element layers do not split into %d slabs of whole coarse layers" % (ezg, world))
     ez = ezg * world if a.scaling == "weak" else ezg  # weak: fixed slab per GPU; strong: fixed mesh
@@ -177,6 +184,8 @@ def main():
     ndof = 3 * nx * ny * nz
     grid = tp.Grid(nx, ny, nz, h, rank=rank, nranks=world)
     le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=nlv, rtol=a.rtol, fine_eig=a.fine_eig, ncoarse=a.ncoarse, nsmooth=a.nsmooth))
+    if a.cycles:
+        le.set_cycles([int(v) for v in a.cycles.split(",")])
     flt = tp.Filter(grid, ftype, 2.56 * h)
     le.SetUpLoadAndBC_MBB() if bc == "mbb" else le.SetUpLoadAndBC()
     x = grid.synth_density(12345)
@@ -321,9 +330,10 @@ def main():
         "ms_per_step": t_step * 1e3, "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s: %s %dx%dx%d elements (%d DOF), z-slabs over %d GPU(s), rmin=2.56h %s "
-                               "filter, CG + %d-level GMG (Chebyshev(%d)-Jacobi, coarse Chebyshev(%d), Galerkin), rtol %g, fine-level eig %s, cold start, "
+                               "filter, CG + %d-level GMG (Chebyshev(%d)-Jacobi, coarse Chebyshev(%d), Galerkin%s), rtol %g, fine-level eig %s, cold start, "
                                "filtered synthetic density seed 12345" % (a.workload, "MBB beam" if bc == "mbb" else "cantilever", ex, ey, ez, ndof, world,
-                                                                         "Helmholtz (PDE)" if ftype == 2 else "density", nlv, a.nsmooth, a.ncoarse, a.rtol,
+                                                                         "Helmholtz (PDE)" if ftype == 2 else "density", nlv, a.nsmooth, a.ncoarse,
+                                                                         ", cycles per level %s" % a.cycles if a.cycles else "", a.rtol,
                                                                          "Lanczos(10)" if a.fine_eig else "element bound"),
                    "n_dof": ndof, "cg_its": info.get("its"), "rel_residual": info.get("rel_res"), "fx": info.get("fx"),
                    # SURVEY 8(d) secondary metrics: Krylov work rate (KSPSolve only, assembly/setup excluded) and the
@@ -338,7 +348,7 @@ def main():
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.cpu_sample, a.rtol, a.fine_eig, ndof, nlv, a.nsmooth, a.ncoarse)
+        out["cpu_baseline"] = cpu_baseline(a.cpu_sample, a.rtol, a.fine_eig, ndof, nlv, a.nsmooth, a.ncoarse, a.cycles)
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

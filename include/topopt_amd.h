@@ -213,6 +213,10 @@ int tp_elasticity_set_tolerances(tp_elasticity *le, double rtol, double atol, do
  * someone with a PETSc build can paste it on the reference's command line and compare the residual history.
  * Returns the length of the full string (buf receives at most cap-1 characters), or -1 before the first assembly. */
 int tp_elasticity_petsc_options(const tp_elasticity *e, char *buf, size_t cap);
+/* PCMGSetCycleType / PCMGSetCycleTypeOnLevel: cycles[l] cycles of level l + 1 per visit of level l (l = 0 finest, 1 = V,
+ * 2 = W; PETSc's form: same right-hand side, the next cycle starts from the previous one's iterate); one cycle into the
+ * coarsest level whatever is set */
+int tp_elasticity_set_cycles(tp_elasticity *e, const int *cycles, int n);
 int tp_elasticity_level_count(const tp_elasticity *e);
 long tp_elasticity_level_nodes(const tp_elasticity *e, int level);
 double tp_elasticity_level_lambda(const tp_elasticity *e, int level);

@@ -39,6 +39,7 @@ def lib():
         L.orc_mg_create.argtypes = [C.c_int] * 7 + [C.c_double] * 2
         L.orc_mg_destroy.argtypes = [C.c_void_p]
         L.orc_mg_set_fine_eig.argtypes = [C.c_void_p, C.c_int]
+        L.orc_mg_set_cycles.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_mg_assemble.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_mg_precond.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_mg_solve.restype = C.c_int
@@ -187,6 +188,11 @@ class MG:
         if getattr(self, "h", None):
             self.L.orc_mg_destroy(self.h)
             self.h = None
+
+    def set_cycles(self, cycles):
+        """cycles[l] cycles of level l + 1 per visit of level l (l = 0 finest): 1 = V, 2 = W (PCMGSetCycleTypeOnLevel)"""
+        c = (C.c_int * 16)(*([int(v) for v in cycles] + [1] * 16)[:16])
+        self.L.orc_mg_set_cycles(self.h, C.addressof(c))
 
     def assemble(self, KE, E=None, N=None):
         self._keep = (f64(KE), None if E is None else f64(E), None if N is None else f64(N))

@@ -594,6 +594,7 @@ typedef struct {
     double *b[MAXLV], *x[MAXLV], *r[MAXLV], *d[MAXLV];
     int nsmooth, ncoarse, nlanczos, nlanczos_coarse, fine_eig;
     double cheb_lo, cheb_hi;
+    int cycles[MAXLV]; /* cycles[l]: how often level l + 1 is cycled from level l (1 = V, 2 = W; PCMGSetCycleTypeOnLevel) */
 } orc_mg_t;
 
 /* largest eigenvalue of the symmetric tridiagonal (a[0..m-1], b[0..m-2]) by
@@ -752,6 +753,7 @@ ORC_API orc_mg_t *orc_mg_create(int nx, int ny, int nz, int dof, int nlv, int ns
     s->nlanczos_coarse = 40;
     s->cheb_lo = cheb_lo;
     s->cheb_hi = cheb_hi;
+    for (int l = 0; l < MAXLV; l++) s->cycles[l] = 1;
     for (int l = 0; l < nlv; l++) {
         s->nx[l] = ((nx - 1) >> l) + 1;
         s->ny[l] = ((ny - 1) >> l) + 1;
@@ -772,6 +774,10 @@ ORC_API orc_mg_t *orc_mg_create(int nx, int ny, int nz, int dof, int nlv, int ns
 }
 
 ORC_API void orc_mg_set_fine_eig(orc_mg_t *s, int mode) { s->fine_eig = mode; }
+/* PCMGSetCycleType / PCMGSetCycleTypeOnLevel: c[l] cycles of level l + 1 per visit of level l (l = 0 finest) */
+ORC_API void orc_mg_set_cycles(orc_mg_t *s, const int *c) {
+    for (int l = 0; l + 1 < s->nlv; l++) s->cycles[l] = c[l] < 1 ? 1 : c[l];
+}
 
 ORC_API void orc_mg_destroy(orc_mg_t *s) {
     if (!s) return;
@@ -857,25 +863,30 @@ static void cheb_smooth(const csr_t *A, const double *dinv, const double *b, dou
     }
 }
 
-/* PCMG multiplicative V-cycle, zero initial guess on every level */
-static void vcycle(orc_mg_t *s, int l) {
+/* PCMGMCycle_Private of PETSc 3.11 (multiplicative): pre-smooth, residual, restrict, the coarse iterate zeroed ONCE
+ * and the coarser level cycled cycles[l] times on the same right-hand side (the second cycle starts from the first
+ * one's result) -- one cycle only into the coarsest level (`cycles = (level == 1) ? 1 : mglevels->cycles`) --,
+ * correction, post-smooth.  zero_guess: x[l] is taken as 0 (every level's first visit in a PCApply) */
+static void mcycle(orc_mg_t *s, int l, int zero_guess) {
     const csr_t *A = s->A[l];
     long n         = A->nrow;
     double lmin = s->cheb_lo * s->lam[l], lmax = s->cheb_hi * s->lam[l];
     if (l == s->nlv - 1) {
         if (l > 0) lmin = s->lam_min[l];
-        cheb_smooth(A, s->dinv[l], s->b[l], s->x[l], s->r[l], s->d[l], s->ncoarse, lmin, lmax, 1);
+        cheb_smooth(A, s->dinv[l], s->b[l], s->x[l], s->r[l], s->d[l], s->ncoarse, lmin, lmax, zero_guess);
         return;
     }
-    cheb_smooth(A, s->dinv[l], s->b[l], s->x[l], s->r[l], s->d[l], s->nsmooth, lmin, lmax, 1);
+    cheb_smooth(A, s->dinv[l], s->b[l], s->x[l], s->r[l], s->d[l], s->nsmooth, lmin, lmax, zero_guess);
     csr_spmv(A, s->x[l], s->r[l]);
     for (long i = 0; i < n; i++) s->r[l][i] = s->b[l][i] - s->r[l][i];
     csr_spmv_t(s->P[l], s->r[l], s->b[l + 1]); /* restriction = P^T */
-    vcycle(s, l + 1);
+    const int cyc = (l + 1 == s->nlv - 1) ? 1 : s->cycles[l];
+    for (int c = 0; c < cyc; c++) mcycle(s, l + 1, c == 0);
     csr_spmv(s->P[l], s->x[l + 1], s->r[l]);
     for (long i = 0; i < n; i++) s->x[l][i] += s->r[l][i];
     cheb_smooth(A, s->dinv[l], s->b[l], s->x[l], s->r[l], s->d[l], s->nsmooth, lmin, lmax, 0);
 }
+static void vcycle(orc_mg_t *s, int l) { mcycle(s, l, 1); }
 
 /* z = M r */
 ORC_API void orc_mg_precond(orc_mg_t *s, const double *r, double *z) {

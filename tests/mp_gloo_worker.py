@@ -110,6 +110,7 @@ def gpu_mode(rank, world):
     torch.cuda.set_device(0)
     ex, ey, ez, nlv = [int(v) for v in sys.argv[2:6]] if len(sys.argv) >= 6 else (16, 8, 16, 3)
     nsm, nco = [int(v) for v in sys.argv[6:8]] if len(sys.argv) >= 8 else (4, 30)   # Chebyshev steps: smoothing, coarse solve
+    cyc = [int(v) for v in sys.argv[8].split(",")] if len(sys.argv) >= 9 else None    # cycles per level (W-cycles)
     nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
     grid = tp.Grid(nx, ny, nz, h, rank=rank, nranks=world)
     part = grid.part
@@ -118,6 +119,8 @@ def gpu_mode(rank, world):
     ok = ctypes.c_int(0)
     assert grid.L.tp_grid_comm_selfcheck(grid.handle, ctypes.byref(ok)) == 0 and ok.value == 1
     le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=nlv, rtol=1e-9, max_it=300, nsmooth=nsm, ncoarse=nco))
+    if cyc:
+        le.set_cycles(cyc)
     le.SetUpLoadAndBC()
     x = grid.synth_density()
     flt = tp.Filter(grid, 1, 2.56 * h)
@@ -135,6 +138,8 @@ def gpu_mode(rank, world):
     KE = orc.hex8_ke_box(h, h, h, 0.3)
     N, R = orc.cantilever_bc(nx, ny, nz, h)
     mg = orc.MG(nx, ny, nz, 3, nlv, nsm, nco)
+    if cyc:
+        mg.set_cycles(cyc)
     mg.assemble(KE, orc.simp(xpo), N)
     U, its, hist = mg.solve(R * N, rtol=1e-9, maxit=300)
     fo, go, dfo, dgo = orc.compliance_sens(nx, ny, nz, KE, U, xpo)
@@ -174,6 +179,8 @@ def gpu_mode(rank, world):
     grid0 = tp.Grid(nx, ny, nz, h, rank=rank, nranks=world)
     os.environ.pop("TP_OVERLAP")
     le0 = tp.LinearElasticity(grid0, tp.SolverOptions(nlvls=nlv, rtol=1e-9, max_it=300, nsmooth=nsm, ncoarse=nco))
+    if cyc:
+        le0.set_cycles(cyc)
     le0.SetUpLoadAndBC()
     le0.ComputeObjectiveConstraintsSensitivities(grid0.elem_vec(), grid0.elem_vec(), xp_e, 1e-9, 1.0, 3.0, 0.12, hist_cap=400)
     assert grid0.halo_overlap == 0
@@ -190,6 +197,7 @@ def gpu_randbc_mode(rank, world):
     torch.cuda.set_device(0)
     ex, ey, ez, nlv = [int(v) for v in sys.argv[2:6]] if len(sys.argv) >= 6 else (16, 8, 16, 3)
     nsm, nco = [int(v) for v in sys.argv[6:8]] if len(sys.argv) >= 8 else (4, 30)   # Chebyshev steps: smoothing, coarse solve
+    cyc = [int(v) for v in sys.argv[8].split(",")] if len(sys.argv) >= 9 else None    # cycles per level (W-cycles)
     nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
     rng = np.random.default_rng(11)
     N = np.ones(3 * nx * ny * nz)

@@ -115,6 +115,37 @@ def test_bench_cycle_parameters(tp, orc, mesh, nlv, ns, nc):
         assert le.level_lambda(l) == pytest.approx(mg.lam(l), rel=1e-9)
 
 
+def test_bench_w_cycle_pattern(tp, orc):
+    """the pattern bench.py runs on the metric mesh: 5 levels, levels 2 and 3 cycled twice, Chebyshev(2) / coarse Chebyshev(20)"""
+    grid, le, mg, x, KE, N, R = make(tp, orc, 32, 32, 32, 5, "synth", rtol=1e-9, max_it=300, nsmooth=2, ncoarse=20)
+    le.set_cycles([1, 2, 2, 1])
+    mg.set_cycles([1, 2, 2, 1])
+    its = le.KSPSolve(hist_cap=400)
+    Uo, its_o, hist_o = mg.solve(R * N, rtol=1e-9, maxit=300)
+    assert its == its_o
+    assert np.abs(le.last_hist[:10] / hist_o[:10] - 1).max() <= 1e-9
+    assert rel(host(le.U), Uo) <= 1e-9
+
+
+@pytest.mark.parametrize("cycles", [[1, 2, 2], [2, 2, 2], [1, 3, 1]])
+def test_w_cycles(tp, orc, cycles):
+    """PCMGSetCycleTypeOnLevel (tp_elasticity_set_cycles): W-cycles in PETSc's form -- the coarser level cycled again on
+    the same right-hand side from its iterate -- against the oracle's (itself held against a numpy restatement of
+    PCMGMCycle_Private on the CPU): one cycle 1e-10, the solve: same iterations, history, solution"""
+    grid, le, mg, x, KE, N, R = make(tp, orc, 32, 16, 16, 4, "synth", rtol=1e-9, max_it=300, nsmooth=2, ncoarse=10)
+    le.set_cycles(cycles)
+    mg.set_cycles(cycles)
+    r = np.random.default_rng(8).standard_normal(mg.n)
+    assert rel(host(le.precond(dev(r))), mg.precond(r)) <= 1e-10
+    its = le.KSPSolve(hist_cap=400)
+    Uo, its_o, hist_o = mg.solve(R * N, rtol=1e-9, maxit=300)
+    assert its == its_o
+    assert np.abs(le.last_hist[:10] / hist_o[:10] - 1).max() <= 1e-9
+    assert np.abs(le.last_hist / hist_o - 1).max() <= 1e-6
+    assert rel(host(le.U), Uo) <= 1e-9
+    assert ("-pc_mg_cycle_type w" in le.petsc_options()) == (cycles == [2, 2, 2])
+
+
 @pytest.mark.parametrize("kind,nlv", [("uniform", 3), ("synth", 3), ("synth", 2)])
 def test_solve_residual_history(tp, orc, kind, nlv):
     """KSP residual history and solution against the oracle running the same

@@ -74,6 +74,13 @@ def test_bench_cycle_on_slabs():
 
 
 @pytest.mark.gpu
+def test_bench_w_cycle_on_slabs():
+    """the cycle of the bench's metric mesh since the W-cycle scan (5 levels, Chebyshev(2), coarse Chebyshev(20), levels 2 and 3
+    cycled twice) on two slabs, against the serial oracle; overlapped and blocking halos bit-equal"""
+    _launch("gpu", nproc=2, extra=(32, 16, 64, 5, 2, 20, "1,2,2,1"))
+
+
+@pytest.mark.gpu
 def test_eight_ranks_one_gpu_c3_c5_slab_geometry():
     """The 8-GPU slab geometry of BASELINE configs C3 (256x128x128) and C5 (512x256x256) before hardware sees it:
     8 ranks, 4 multigrid levels, 16 fine = 2 coarsest-level element layers per rank, replicated coarsest level,

@@ -331,3 +331,56 @@ def test_transfer_equals_dmda_q1_interpolation_restated(orc):
         Ac = (P.T @ mg.csr(l) @ P).tocsr()
         d = (Ac - mg.csr(l + 1)).tocoo()
         assert np.abs(d.data).max() <= 1e-12 * np.abs(Ac.data).max()
+
+
+@pytest.mark.parametrize("cycles", [[2, 2, 2], [1, 2, 1], [1, 2, 2], [3, 1, 1]])
+def test_w_cycles_equal_petsc_pcmg_restated(orc, cycles):
+    """PCMGSetCycleType(W) / PCMGSetCycleTypeOnLevel: PCMGMCycle_Private cycles the next coarser level `cycles` times on
+    the SAME right-hand side -- iterate zeroed once, the second cycle starts from the first one's result with the
+    pre-smoother's non-zero-guess branch -- and once only into the coarsest level.  Restated in numpy with PETSc's
+    Chebyshev recurrence; equal to the oracle's cycle.  The textbook form (new residual of the finer level, restricted
+    again, next cycle from zero) is the same map because the coarse operators are Galerkin: checked too."""
+    nx, ny, nz, h, KE, N, b, x, E = _problem(orc, 32, 16, 16, "synth")
+    nlv, ns, nc = 4, 2, 10
+    mg = orc.MG(nx, ny, nz, 3, nlv, ns, nc)
+    mg.set_cycles(cycles)
+    mg.assemble(KE, E, N)
+    A = [mg.csr(l) for l in range(nlv)]
+    dinv = [1.0 / mg.diag(l) for l in range(nlv)]
+    win = lambda l: ((mg.lam_min(l) if l == nlv - 1 else 0.1 * mg.lam(l)), 1.1 * mg.lam(l))
+
+    def petsc(l, rhs, x0, zero):
+        lo, hi = win(l)
+        if l == nlv - 1:
+            return _petsc_chebyshev(A[l], dinv[l], lo, hi, rhs, x0, nc, zero)
+        xl = _petsc_chebyshev(A[l], dinv[l], lo, hi, rhs, x0, ns, zero)
+        rc = mg.restrict(l, rhs - A[l] @ xl)
+        xc = np.zeros_like(rc)
+        for c in range(1 if l + 1 == nlv - 1 else cycles[l]):
+            xc = petsc(l + 1, rc, xc, c == 0)
+        return _petsc_chebyshev(A[l], dinv[l], lo, hi, rhs, xl + mg.prolong(l, xc), ns, False)
+
+    def textbook(l, rhs):
+        lo, hi = win(l)
+        if l == nlv - 1:
+            return _petsc_chebyshev(A[l], dinv[l], lo, hi, rhs, np.zeros_like(rhs), nc, True)
+        xl = _petsc_chebyshev(A[l], dinv[l], lo, hi, rhs, np.zeros_like(rhs), ns, True)
+        for c in range(1 if l + 1 == nlv - 1 else cycles[l]):
+            xl = xl + mg.prolong(l, textbook_inner(l + 1, mg.restrict(l, rhs - A[l] @ xl)))
+        return _petsc_chebyshev(A[l], dinv[l], lo, hi, rhs, xl, ns, False)
+
+    def textbook_inner(l, rhs):
+        return textbook(l, rhs)
+
+    r = np.random.default_rng(6).standard_normal(b.size) * N
+    z = mg.precond(r)
+    zp = petsc(0, r, np.zeros_like(r), True)
+    assert np.abs(z - zp).max() <= 1e-11 * np.abs(zp).max()
+    # the textbook W-cycle applies the WHOLE coarser cycle (with its own pre-smoothing from zero) to the new residual: the
+    # same affine map only where the cycled level's iteration is stationary -- it is (fixed Chebyshev coefficients)
+    zt = textbook(0, r)
+    assert np.abs(z - zt).max() <= 1e-9 * np.abs(zt).max()
+    # and it pays in Krylov iterations
+    its_w = mg.solve(b, rtol=1e-8)[1]
+    mg.set_cycles([1, 1, 1])
+    assert its_w < mg.solve(b, rtol=1e-8)[1] or cycles == [3, 1, 1]

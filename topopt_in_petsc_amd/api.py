@@ -309,6 +309,11 @@ class LinearElasticity:
         _chk(self.L.tp_elasticity_level_diag(self.handle, l, _ptr(d)), "tp_elasticity_level_diag")
         return d
 
+    def set_cycles(self, cycles):
+        """PCMGSetCycleTypeOnLevel: cycles[l] cycles of level l + 1 per visit of level l (l = 0 finest; 1 = V, 2 = W)"""
+        arr = (C.c_int * len(cycles))(*[int(v) for v in cycles])
+        _chk(self.L.tp_elasticity_set_cycles(self.handle, arr, len(cycles)), "tp_elasticity_set_cycles")
+
     def level_pc(self, l, pc, r):
         """ksp_mode 1: z = M^-1 r on level l, pc 0 = PCJACOBI, 1 = PCSOR (one symmetric Gauss-Seidel sweep)"""
         z = torch.zeros_like(r)

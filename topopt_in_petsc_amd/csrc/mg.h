@@ -969,11 +969,16 @@ struct MGSolver {
         head_for = b;
         return TP_OK;
     }
-    int vcycle(int l, const double *b, int dot_slot = -1, bool first_done = false) {
+    // cycles[l]: how often level l + 1 is cycled per visit of level l (1 = V, 2 = W: PCMGSetCycleType /
+    // PCMGSetCycleTypeOnLevel).  As PCMGMCycle_Private does it: the coarser level's iterate is zeroed once, further cycles
+    // run on the same right-hand side from the iterate (zero_guess = false: the pre-smoother's non-zero-guess branch);
+    // one cycle only into the coarsest level.
+    int cycles[TP_MAX_LEVELS + 1] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+    int vcycle(int l, const double *b, int dot_slot = -1, bool first_done = false, bool zero_guess = true) {
         Level<DOF> &L = lv[l];
-        if (l == nlv - 1) return smooth(l, b, opt.ncoarse, true, -1, first_done);
+        if (l == nlv - 1) return smooth(l, b, opt.ncoarse, zero_guess, -1, first_done);
         if (l == 0 && head_for == b) head_for = nullptr;  // pre-smoothed already (vcycle_head)
-        else TP_TRY(smooth(l, b, opt.nsmooth, true, -1, first_done));
+        else TP_TRY(smooth(l, b, opt.nsmooth, zero_guess, -1, first_done));
         {
             NodeArgs a{};
             a.x = L.x;
@@ -1002,6 +1007,7 @@ struct MGSolver {
         else TP_TRY(restrict_planes(C.g.own_lo, C.g.own_hi - C.g.own_lo + 1));
         count_launch(grid, 8.0 * DOF * (L.g.owned_nodes() + C.g.owned_nodes()), 2.0 * 27 * DOF * C.g.owned_nodes());
         TP_TRY(vcycle(l + 1, C.b, -1, fuse_first));
+        for (int c = 1; c < (l + 1 == nlv - 1 ? 1 : cycles[l]); c++) TP_TRY(vcycle(l + 1, C.b, -1, false, false));
         if (!(replicate && l + 1 == nlv - 1)) TP_TRY(halo(l + 1, C.x));  // the replicated solve returns its ghosts
         TP_TRY(planes_split(l, L.x, [&](int p0, int np) -> int {
             const long fpl = L.g.plane();

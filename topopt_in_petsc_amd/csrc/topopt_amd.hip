@@ -974,9 +974,15 @@ extern "C" int tp_elasticity_petsc_options(const tp_elasticity *e, char *buf, si
     }
     snprintf(t, sizeof t,
              "-ksp_type cg -ksp_norm_type unpreconditioned -ksp_rtol %.17g -ksp_atol %.17g -ksp_divtol %.17g -ksp_max_it %d "
-             "-ksp_initial_guess_nonzero true -pc_type mg -pc_mg_levels %d -pc_mg_type multiplicative -pc_mg_cycle_type v "
+             "-ksp_initial_guess_nonzero true -pc_type mg -pc_mg_levels %d -pc_mg_type multiplicative -pc_mg_cycle_type %s "
              "-pc_mg_galerkin both",
-             mg.opt.rtol, mg.opt.atol, mg.opt.dtol, mg.opt.max_it, mg.nlv);
+             mg.opt.rtol, mg.opt.atol, mg.opt.dtol, mg.opt.max_it, mg.nlv, [&] {
+                 // (per-level cycle types exist in PETSc through PCMGSetCycleTypeOnLevel only: the string says w when every
+                 // level that can cycle twice does)
+                 bool w = mg.nlv > 2;
+                 for (int l = 0; l + 2 < mg.nlv; l++) w = w && mg.cycles[l] == 2;
+                 return w ? "w" : "v";
+             }());
     o += t;
     for (int l = 0; l < mg.nlv; l++) {
         const Level<3> &L = mg.lv[l];
@@ -998,6 +1004,16 @@ extern "C" int tp_elasticity_petsc_options(const tp_elasticity *e, char *buf, si
         buf[n] = 0;
     }
     return (int)o.size();
+}
+// PCMGSetCycleType / PCMGSetCycleTypeOnLevel: cycles[l] cycles of level l + 1 per visit of level l (l = 0: the finest;
+// 1 = V, 2 = W); entries beyond n keep their value.  Into the coarsest level there is always one (as in PETSc).
+extern "C" int tp_elasticity_set_cycles(tp_elasticity *e, const int *cycles, int n) {
+    if (!e || !cycles || n < 0 || n > TP_MAX_LEVELS) return TP_ERR_ARG;
+    for (int l = 0; l < n; l++) {
+        if (cycles[l] < 1 || cycles[l] > 4) return TP_ERR_ARG;
+        e->mg.cycles[l] = cycles[l];
+    }
+    return TP_OK;
 }
 extern "C" int tp_elasticity_level_count(const tp_elasticity *e) { return e->mg.nlv; }
 extern "C" long tp_elasticity_level_nodes(const tp_elasticity *e, int l) { return e->mg.lv[l].g.nodes(); }
