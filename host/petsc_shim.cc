@@ -390,7 +390,9 @@ int resolve(KSP k, tp_solver_opts *o) {
     o->atol = k->atol;
     o->dtol = k->dtol;
     o->max_it = k->maxits;
-    if (pc->cycle != PC_MG_CYCLE_V || pc->mgtype != PC_MG_MULTIPLICATIVE) return sup("PCMG: only the multiplicative V-cycle");
+    if (pc->mgtype != PC_MG_MULTIPLICATIVE) return sup("PCMG: only PC_MG_MULTIPLICATIVE");
+    if (pc->cycle != PC_MG_CYCLE_V && pc->cycle != PC_MG_CYCLE_W) return sup("PCMG: cycle type neither V nor W");
+    if (pc->cycle == PC_MG_CYCLE_W && flexible) return sup("PCMG: W-cycles with the FGMRES / GMRES level solvers");
     if (nl > 1 && pc->galerkin != PC_MG_GALERKIN_BOTH) return sup("PCMG: only -pc_mg_galerkin both");
     if (flexible) {
         // the configuration SetUpSolver hard-codes, as written (csrc/refksp.h)
@@ -455,6 +457,11 @@ int ensure_elasticity(Mat A) {
                     return sup("dof-3 matrix: the ranks' element blocks are not multiples of one element matrix");
         }
         if (!rc) rc = tp_elasticity_create_ke(&A->e, mesh.g, &o, A->ref0.data());
+        if (!rc && A->ksp && A->ksp->pc->cycle == PC_MG_CYCLE_W) {  // PCMGSetCycleType(pc, PC_MG_CYCLE_W): every level
+            int two[TP_MAX_LEVELS];
+            for (int &v : two) v = 2;
+            rc = tp_elasticity_set_cycles(A->e, two, o.nlvls > 1 ? o.nlvls - 1 : 0);
+        }
         if (rc) return rc;
         rc = tp_malloc((void **)&A->dE, sizeof(double) * (size_t)nel);
         if (rc) return rc;
