@@ -178,7 +178,8 @@ def main():
     if not a.cycles and not a.nlvls:
         a.cycles = W.get("cycles", "")     # (--cycles 1 forces plain V-cycles; an overridden depth takes no pattern along)
     if a.scaling == "strong" and (ezg % world or (ezg // world) % (1 << (nlv - 1))):
-        raise SystemExit("strong scaling: %d element layers do not split into %d slabs of whole coarse layers" % (ezg, world))
+        raise SystemExit("strong scaling: %d element layers do not split into %d slabs of whole coarse layers of a %d-level "
+                         "hierarchy (try --nlvls %d)" % (ezg, world, nlv, max(1, (ezg // max(world, 1)).bit_length() - 1)))
     ez = ezg * world if a.scaling == "weak" else ezg  # weak: fixed slab per GPU; strong: fixed mesh
     nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
     ndof = 3 * nx * ny * nz

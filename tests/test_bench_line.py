@@ -55,3 +55,29 @@ def test_bench_spawns_its_own_ranks(scaling):
     ez = 32 if scaling == "weak" else 16
     assert "32x16x%d elements" % ez in d["config"]["workload"]
     assert "cpu_baseline" not in d          # rank 0 of a 1-GPU job only
+
+
+def test_bench_workloads_are_consistent():
+    """CPU check of bench.py's workload table: every mesh coarsens nlvls - 1 times, a cycle pattern has one entry per
+    level that has a coarser one, and the slab geometries of the driver's scaling runs (1, 2, 4, 8 GPUs, weak and --
+    where the layers divide -- strong) pass the library's own rule for slabs (topopt_amd.hip: every distributed level
+    keeps two element layers per rank; with three or more levels the coarsest one is the replicated copy)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert {"cantilever128", "c1", "c2", "c3", "c4", "c5", "cube256"} <= set(b.WORKLOADS)
+    for name, w in b.WORKLOADS.items():
+        ex, ey, ez = w["el"]
+        f = 1 << (w["nlvls"] - 1)
+        assert ex % f == 0 and ey % f == 0 and ez % f == 0, name
+        assert 1 <= w["nsmooth"] <= 8 and 1 <= w["ncoarse"] <= 96, name     # RUN_MAXK of csrc/coarse_run.h
+        if "cycles" in w:
+            c = [int(v) for v in w["cycles"].split(",")]
+            assert len(c) == w["nlvls"] - 1 and all(1 <= v <= 4 for v in c) and c[-1] == 1 and c[0] == 1, name
+        last_distributed = w["nlvls"] - 2 if w["nlvls"] >= 3 else w["nlvls"] - 1
+        for world in (2, 4, 8):
+            assert (ez >> last_distributed) >= 2, (name, "weak", world)          # weak: ez layers per rank
+            if ez % world == 0 and (ez // world) % f == 0:                        # strong: bench.py refuses otherwise
+                assert ((ez // world) >> last_distributed) >= 2 or name in ("c1",), (name, "strong", world)
+    assert b.WORKLOADS["c2"]["nlvls"] == 3 and b.WORKLOADS["c5"]["nlvls"] == 4      # stated by BASELINE.json configs[1], [4]
