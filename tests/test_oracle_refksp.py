@@ -126,3 +126,15 @@ def test_reference_pdefilter_configuration(orc):
     x, its, hist = S.solve(b, x0=b / h ** 3)
     assert 0 < its < 60
     assert np.abs(x - spla.spsolve(mg.csr(0).tocsc(), b)).max() <= 1e-6 * np.abs(x).max()
+
+
+def test_outer_restarts(orc):
+    """FGMRES(3): the outer solver restarts every three iterations -- more iterations than FGMRES(100), the same solution"""
+    mg, b, _ = _mg(orc, 16, 8, 8, 3)
+    A = mg.csr(0)
+    U = spla.spsolve(A.tocsc(), b)
+    x100, its100, _ = refksp.RefSolver(mg, rtol=1e-10).solve(b)
+    x3, its3, hist3 = refksp.RefSolver(mg, rtol=1e-10, restart=3).solve(b)
+    assert its3 >= its100 > 3
+    assert np.abs(x3 - U).max() <= 1e-8 * np.abs(U).max() and np.abs(x100 - U).max() <= 1e-8 * np.abs(U).max()
+    assert np.linalg.norm(b - A @ x3) == pytest.approx(hist3[-1], rel=1e-5)
