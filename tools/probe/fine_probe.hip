@@ -83,6 +83,10 @@ static Prob make(int ex, int ey, int ez, bool with_mask) {
     return p;
 }
 
+static int balanced(const Prob &p, int kz) {  // equal chunks: ceil(planes / number of chunks)
+    const int nch = (p.nz + kz - 1) / kz;
+    return (p.nz + nch - 1) / nch;
+}
 static TileArgs targs(const Prob &p, int kz) {
     return TileArgs{p.nx, p.ny, p.nz, p.ex, p.ey, p.ez, 0, p.nz - 1, kz, p.E, p.mask, p.colmask, p.slot * SYMKE_STRIDE, 0, 0, nullptr, 1, 0, 0, -1,
                     0, nullptr, nullptr, 0, nullptr};
@@ -101,11 +105,12 @@ static void launch_old(const Prob &p, int kz, double *out, bool prev) {
     const int tx = (p.nx + TOUT - 1) / TOUT, ty = (p.ny + TOUT - 1) / TOUT, tz = (p.nz + kz - 1) / kz;
     hipLaunchKernelGGL((k_fine_tile<EPI>), dim3(tx, ty, tz), dim3(TILE * TILE), 0, 0, targs(p, kz), nargs(p, out, EPI, prev));
 }
-template <int EPI, int TX, int TY, int D, int WPS>
+template <int EPI, int TX, int TY, int D, int WPS, bool CARRY = false>
 static void launch_new(const Prob &p, int kz, double *out, bool prev) {
     using S = FineDma<TX, TY, D>;
+    kz = balanced(p, kz);
     const int tx = (p.nx + S::TOX - 1) / S::TOX, ty = (p.ny + S::TOY - 1) / S::TOY, tz = (p.nz + kz - 1) / kz;
-    hipLaunchKernelGGL((k_fine_dma<EPI, TX, TY, D, WPS>), dim3(tx, ty, tz), dim3(TX * TY), 0, 0, targs(p, kz), nargs(p, out, EPI, prev));
+    hipLaunchKernelGGL((k_fine_dma<EPI, TX, TY, D, WPS, CARRY>), dim3(tx, ty, tz), dim3(TX * TY), 0, 0, targs(p, kz), nargs(p, out, EPI, prev));
 }
 
 static double bytes_of(const Prob &p, int epi, bool prev) {
@@ -180,7 +185,7 @@ static long diff_count(const Prob &p, double *red_ref, bool dot) {
     return bad;
 }
 
-template <int EPI, int TX, int TY, int D, int WPS>
+template <int EPI, int TX, int TY, int D, int WPS, bool CARRY = false>
 static int check(const Prob &p, int kz_old, int kz_new, bool prev, const char *name) {
     constexpr bool dot = EPI == EPI_APPLY_DOT || EPI == EPI_CHEB_DOT;
     CK(hipMemcpy(p.y0, p.init, 24 * p.nn, hipMemcpyDeviceToDevice));
@@ -189,7 +194,7 @@ static int check(const Prob &p, int kz_old, int kz_new, bool prev, const char *n
     CK(hipDeviceSynchronize());
     double red_ref = 0;
     if (dot) CK(hipMemcpy(&red_ref, p.red, 8, hipMemcpyDeviceToHost));
-    launch_new<EPI, TX, TY, D, WPS>(p, kz_new, p.y1, prev);
+    launch_new<EPI, TX, TY, D, WPS, CARRY>(p, kz_new, p.y1, prev);
     {
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
@@ -205,12 +210,12 @@ static int check(const Prob &p, int kz_old, int kz_new, bool prev, const char *n
     return bad != 0;
 }
 
-template <int EPI, int TX, int TY, int D, int WPS>
+template <int EPI, int TX, int TY, int D, int WPS, bool CARRY = false>
 static void timing(const Prob &p, int kz, bool prev, int reps, const char *name) {
     using S = FineDma<TX, TY, D>;
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (k_fine_dma<EPI, TX, TY, D, WPS>), TX * TY, 0) != hipSuccess) occ = -1;
-    launch_new<EPI, TX, TY, D, WPS>(p, kz, p.y1, prev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (k_fine_dma<EPI, TX, TY, D, WPS, CARRY>), TX * TY, 0) != hipSuccess) occ = -1;
+    launch_new<EPI, TX, TY, D, WPS, CARRY>(p, kz, p.y1, prev);
     {
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
@@ -218,7 +223,7 @@ static void timing(const Prob &p, int kz, bool prev, int reps, const char *name)
             return;
         }
     }
-    const double us = time_us([&] { launch_new<EPI, TX, TY, D, WPS>(p, kz, p.y1, prev); }, reps);
+    const double us = time_us([&] { launch_new<EPI, TX, TY, D, WPS, CARRY>(p, kz, p.y1, prev); }, reps);
     const double gb = bytes_of(p, EPI, prev) / 1e9;
     printf("time %-30s kz %3d lds %6d wg/CU %d : %8.1f us  %7.1f GB/s  frac %.3f\n", name, kz, S::LDS_BYTES, occ, us, gb / us * 1e6, gb / us * 1e6 / 8000.0);
     fflush(stdout);
@@ -264,47 +269,43 @@ int main(int argc, char **argv) {
             fails += check<EPI_APPLY_DOT, 16, 16, 2, 3>(p, 8, kz, false, "apply_dot 16x16 D2");
             fails += check<EPI_CHEB_DOT, 16, 16, 2, 3>(p, 8, kz, true, "cheb_dot 16x16 D2");
             if (ext) {
-            fails += check<EPI_APPLY, 16, 16, 1, 3>(p, 8, kz, false, "apply 16x16 D1");
-            fails += check<EPI_APPLY, 16, 16, 3, 2>(p, 8, kz, false, "apply 16x16 D3");
-            fails += check<EPI_APPLY, 16, 16, 4, 2>(p, 8, kz, false, "apply 16x16 D4");
-            fails += check<EPI_CHEB, 16, 16, 4, 2>(p, 8, kz, true, "cheb 16x16 D4");
-            fails += check<EPI_APPLY, 32, 8, 2, 3>(p, 8, kz, false, "apply 32x8 D2");
-            fails += check<EPI_APPLY, 32, 16, 1, 4>(p, 8, kz, false, "apply 32x16 D1");
-            fails += check<EPI_APPLY, 32, 16, 2, 2>(p, 8, kz, false, "apply 32x16 D2");
-            fails += check<EPI_CHEB, 32, 16, 2, 2>(p, 8, kz, true, "cheb 32x16 D2");
-            fails += check<EPI_APPLY, 32, 24, 2, 3>(p, 8, kz, false, "apply 32x24 D2");
-            fails += check<EPI_CHEB, 32, 24, 2, 3>(p, 8, kz, true, "cheb 32x24 D2");
-            fails += check<EPI_APPLY, 64, 8, 2, 2>(p, 8, kz, false, "apply 64x8 D2");
-            fails += check<EPI_APPLY, 64, 12, 2, 3>(p, 8, kz, false, "apply 64x12 D2");
+#define EXT_VARIANTS(F)                                                   \
+    F(EPI_APPLY, 16, 16, 1, 4, false, false, "apply 16x16 D1 w4")          \
+    F(EPI_APPLY, 16, 16, 2, 3, true, false, "apply 16x16 D2 carry")       \
+    F(EPI_CHEB, 16, 16, 2, 3, true, true, "cheb 16x16 D2 carry")          \
+    F(EPI_APPLY, 16, 16, 3, 2, false, false, "apply 16x16 D3")            \
+    F(EPI_APPLY, 32, 8, 1, 4, false, false, "apply 32x8 D1 w4")           \
+    F(EPI_APPLY, 32, 16, 1, 4, false, false, "apply 32x16 D1 w4")         \
+    F(EPI_APPLY, 32, 16, 1, 3, true, false, "apply 32x16 D1 carry")       \
+    F(EPI_APPLY, 32, 24, 2, 3, true, false, "apply 32x24 D2 carry")       \
+    F(EPI_CHEB, 32, 24, 2, 3, false, true, "cheb 32x24 D2")               \
+    F(EPI_APPLY, 32, 32, 1, 4, false, false, "apply 32x32 D1 w4")         \
+    F(EPI_CHEB, 32, 32, 1, 4, false, true, "cheb 32x32 D1 w4")            \
+    F(EPI_CHEB, 32, 16, 1, 3, false, true, "cheb 32x16 D1 (w3)")           \
+    F(EPI_APPLY, 32, 24, 2, 3, false, false, "apply 32x24 D2")            \
+    F(EPI_CHEB, 32, 8, 1, 3, false, true, "cheb 32x8 D1")
+#define CHK(E, TX, TY, D, W, C, PV, NAME) fails += check<E, TX, TY, D, W, C>(p, 8, kz, PV, NAME);
+                EXT_VARIANTS(CHK)
             }
         }
     }
     if (mode & 2) {
         Prob p = make(ex, ey, ez, false);
         const int kzs[3] = {kz, 2 * kz, 4 * kz};
+        const int nkz = getenv("PROBE_ONE_KZ") ? 1 : 3;
         for (int nb = 2048; nb <= 32768; nb *= 4) {
             const double us = time_us([&] { hipLaunchKernelGGL(k_stream_ref, dim3(nb), dim3(256), 0, 0, (const double2 *)p.u, (const double2 *)p.E, (double2 *)p.y1, 3 * p.nn / 2, p.ne / 2); }, reps);
             printf("time stream reference (%5d wgs)                        : %8.1f us  %7.1f GB/s  frac %.3f\n", nb, us, bytes_of(p, EPI_APPLY, false) / us * 1e-3, bytes_of(p, EPI_APPLY, false) / us * 1e-3 / 8000.0);
         }
         timing_old<EPI_APPLY>(p, 16, false, reps, "old apply");
         timing_old<EPI_CHEB>(p, 16, true, reps, "old cheb");
-        for (int q = 0; q < 3; q++) {
+        for (int q = 0; q < nkz; q++) {
             const int k = kzs[q];
             timing<EPI_APPLY, 16, 16, 2, 3>(p, k, false, reps, "apply 16x16 D2");
             timing<EPI_CHEB, 16, 16, 2, 3>(p, k, true, reps, "cheb 16x16 D2");
             if (ext) {
-            timing<EPI_APPLY, 16, 16, 1, 3>(p, k, false, reps, "apply 16x16 D1");
-            timing<EPI_APPLY, 16, 16, 3, 2>(p, k, false, reps, "apply 16x16 D3");
-            timing<EPI_APPLY, 16, 16, 4, 2>(p, k, false, reps, "apply 16x16 D4");
-            timing<EPI_CHEB, 16, 16, 4, 2>(p, k, true, reps, "cheb 16x16 D4");
-            timing<EPI_APPLY, 32, 8, 2, 3>(p, k, false, reps, "apply 32x8 D2");
-            timing<EPI_APPLY, 32, 16, 1, 4>(p, k, false, reps, "apply 32x16 D1");
-            timing<EPI_APPLY, 32, 16, 2, 2>(p, k, false, reps, "apply 32x16 D2");
-            timing<EPI_CHEB, 32, 16, 2, 2>(p, k, true, reps, "cheb 32x16 D2");
-            timing<EPI_APPLY, 32, 24, 2, 3>(p, k, false, reps, "apply 32x24 D2");
-            timing<EPI_CHEB, 32, 24, 2, 3>(p, k, true, reps, "cheb 32x24 D2");
-            timing<EPI_APPLY, 64, 8, 2, 2>(p, k, false, reps, "apply 64x8 D2");
-            timing<EPI_APPLY, 64, 12, 2, 3>(p, k, false, reps, "apply 64x12 D2");
+#define TIM(E, TX, TY, D, W, C, PV, NAME) timing<E, TX, TY, D, W, C>(p, k, PV, reps, NAME);
+                EXT_VARIANTS(TIM)
             }
         }
     }

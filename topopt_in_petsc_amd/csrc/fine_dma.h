@@ -61,9 +61,10 @@ struct FineDma {
     static constexpr int OFF_U = 0;
     static constexpr int OFF_E = OFF_U + RU * USLOT;
     static constexpr int OFF_Y = OFF_E + RE * ESLOT;
-    static constexpr int OFF_M = OFF_Y + 2 * NT * 3 * 8;
-    static constexpr int OFF_RED = OFF_M + 4 * MSZ;
-    static constexpr int LDS_BYTES = OFF_RED + 8 * NW + 16;
+    static constexpr int YBUF = (NT - TX) * 3 * 8;             // y-combination buffer: the last row of a tile has no reader
+    static constexpr int OFF_M = OFF_Y + 2 * YBUF;
+    static constexpr int OFF_RED = OFF_Y;                      // block reduction of the dot epilogues (after the loop)
+    static constexpr int LDS_BYTES = OFF_M + 4 * MSZ;
     static_assert(NT % 64 == 0, "whole waves");
     static_assert(TX == 16 || TX == 32 || TX == 64, "rows are 16, 32 or 64 lanes");
 };
@@ -124,7 +125,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t fd_window(const double *p, con
     return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, n, FD_RSRC_FLAGS);
 }
 
-template <int EPI, int TX, int TY, int D, bool MASKED>
+template <int EPI, int TX, int TY, int D, bool CARRY, bool MASKED>
 __device__ __forceinline__ void fine_dma_run(const TileArgs &t, const NodeArgs &a, char *lds, int bxi, int byi, int bzi) {
 #pragma clang fp contract(off)
     using S = FineDma<TX, TY, D>;
@@ -280,41 +281,53 @@ __device__ __forceinline__ void fine_dma_run(const TileArgs &t, const NodeArgs &
     };
     const int n00 = ty * S::UPTS + tx;
 
-    // The element's 8 nodes in the Walsh-Hadamard basis: planes jj (bottom) and jj + 1 (top) of the ring.  Both planes
-    // are read every step -- carrying the transformed bottom plane over from the previous step (k_fine_tile) costs 24
-    // VGPRs, re-reading it 12 ds_read_b64 and 24 additions; with the registers the Chebyshev epilogue fits 3 waves per
-    // SIMD without spilling (a spill reload is a vector-memory operation: its wait would drain the DMA queue).
+    // The element's 8 nodes in the Walsh-Hadamard basis: planes jj (bottom) and jj + 1 (top) of the ring.
+    // CARRY = false: both planes are read every step -- carrying the transformed bottom plane over from the previous step
+    //   (k_fine_tile) costs 24 VGPRs, re-reading it 12 ds_read_b64 and 24 additions; with the registers the Chebyshev
+    //   epilogue fits 3 waves per SIMD without spilling (a spill reload is a vector-memory operation: its wait would drain
+    //   the DMA queue) and the plain product 4.
+    // CARRY = true: the transformed top plane of a step is the bottom plane of the next (Ub).
     // xo = own node of the bottom plane, unmasked.
-    auto read_element = [&](int jj, double u[3][8], double xo[3]) {
-        const int rem0 = rem_u(jj), rem1 = rem_u(jj + 1);
-        const char *sp0 = lds + S::OFF_U + (jj % S::RU) * S::USLOT, *sp1 = lds + S::OFF_U + ((jj + 1) % S::RU) * S::USLOT;
-        const double *b0 = (const double *)(sp0 + aU0 + 8 * (rem0 ^ oddU0)), *b1 = (const double *)(sp0 + aU0 + S::ROWW_U * 8 + 8 * (rem0 ^ oddU1));
-        const double *t0 = (const double *)(sp1 + aU0 + 8 * (rem1 ^ oddU0)), *t1 = (const double *)(sp1 + aU0 + S::ROWW_U * 8 + 8 * (rem1 ^ oddU1));
-        unsigned mb[4] = {0, 0, 0, 0}, mt[4] = {0, 0, 0, 0};
+    double Ub[3][4];
+    constexpr bool NEED_XO = IS_CHEB || EPI == EPI_APPLY_DOT || MASKED;
+    auto read_plane = [&](int jj, double U[3][4], double x0[3]) {  // raw own node in x0, masked + transformed plane in U
+        const int rem = rem_u(jj);
+        const char *sp = lds + S::OFF_U + (jj % S::RU) * S::USLOT;
+        const double *r0 = (const double *)(sp + aU0 + 8 * (rem ^ oddU0)), *r1 = (const double *)(sp + aU0 + S::ROWW_U * 8 + 8 * (rem ^ oddU1));
+        unsigned mk[4] = {0, 0, 0, 0};
         if (MASKED) {
-            const uint8_t *m = slot_mask(jj), *mm = slot_mask(jj + 1);
-            mb[0] = m[n00], mb[1] = m[n00 + 1], mb[2] = m[n00 + S::UPTS], mb[3] = m[n00 + S::UPTS + 1];
-            mt[0] = mm[n00], mt[1] = mm[n00 + 1], mt[2] = mm[n00 + S::UPTS], mt[3] = mm[n00 + S::UPTS + 1];
+            const uint8_t *m = slot_mask(jj);
+            mk[0] = m[n00], mk[1] = m[n00 + 1], mk[2] = m[n00 + S::UPTS], mk[3] = m[n00 + S::UPTS + 1];
         }
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            double B[4] = {b0[c], b0[3 + c], b1[c], b1[3 + c]}, T[4] = {t0[c], t0[3 + c], t1[c], t1[3 + c]};
-            xo[c] = B[0];
+            U[c][0] = r0[c], U[c][1] = r0[3 + c], U[c][2] = r1[c], U[c][3] = r1[3 + c];
+            x0[c] = U[c][0];
             if (MASKED) {
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    B[q] = ((mb[q] >> c) & 1u) ? 0.0 : B[q];
-                    T[q] = ((mt[q] >> c) & 1u) ? 0.0 : T[q];
-                }
+                for (int q = 0; q < 4; q++) U[c][q] = ((mk[q] >> c) & 1u) ? 0.0 : U[c][q];
             }
-            wht4(B);
-            wht4(T);
+            wht4(U[c]);
+        }
+    };
+    auto read_element = [&](int jj, double u[3][8], double xo[3]) {
+        double Ut[3][4], xt[3];
+        if (!CARRY) {
+            read_plane(jj, Ub, xo);
+        } else if (NEED_XO) {
+            const double *r0 = (const double *)(lds + S::OFF_U + (jj % S::RU) * S::USLOT + aU0 + 8 * (rem_u(jj) ^ oddU0));
+#pragma unroll
+            for (int c = 0; c < 3; c++) xo[c] = r0[c];
+        }
+        read_plane(jj + 1, Ut, xt);
+#pragma unroll
+        for (int c = 0; c < 3; c++)
 #pragma unroll
             for (int m = 0; m < 4; m++) {
-                u[c][m] = B[m] + T[m];
-                u[c][m + 4] = B[m] - T[m];
+                u[c][m] = Ub[c][m] + Ut[c][m];
+                u[c][m + 4] = Ub[c][m] - Ut[c][m];
+                if (CARRY) Ub[c][m] = Ut[c][m];
             }
-        }
     };
     auto read_E = [&](int jl) -> double {
         return *(const double *)(lds + S::OFF_E + (jl % S::RE) * S::ESLOT + aE + 8 * (rem_e(jl) ^ oddE));
@@ -333,7 +346,7 @@ __device__ __forceinline__ void fine_dma_run(const TileArgs &t, const NodeArgs &
         const double ex2 = Ee + (okL ? eL : 0.0);
         return ex2 + ((okD ? eD : 0.0) + (okDL ? eDL : 0.0));
     };
-    double(*s_y)[S::NT * 3] = (double(*)[S::NT * 3])(lds + S::OFF_Y);
+    double(*s_y)[(S::NT - TX) * 3] = (double(*)[(S::NT - TX) * 3])(lds + S::OFF_Y);
 
     // ---- prologue: batches -D-1 .. -1 with the queue pattern of a step each
     unsigned pmk[NMK];
@@ -355,6 +368,13 @@ __device__ __forceinline__ void fine_dma_run(const TileArgs &t, const NodeArgs &
     }
     fd_wait<W_PRO>();  // batches -D-1 and -D have landed: planes 0, 1, moduli of layer 0
     __syncthreads();
+    // a wave whose lanes hold neither an element nor a node of the domain (rows beyond the last node row of the mesh)
+    // only takes part in the staging, the barriers and the (dropped) memory operations: idle_step below
+    const bool live = __builtin_amdgcn_readfirstlane((int)(__ballot(elem_ok || (tx >= 1 && ty >= 1 && ei < t.nx && ej < t.ny)) != 0ull)) != 0;
+    if (CARRY && live) {
+        double x0[3];
+        read_plane(0, Ub, x0);
+    }
     double Cy[3][4];
 #pragma unroll
     for (int c = 0; c < 3; c++)
@@ -409,7 +429,8 @@ __device__ __forceinline__ void fine_dma_run(const TileArgs &t, const NodeArgs &
         for (int c = 0; c < 3; c++) {
             wht4(P[c]);
             s0[c] = P[c][0] + dpp_left<TX>(P[c][1]);
-            s_y[s & 1][tid * 3 + c] = P[c][2] + dpp_left<TX>(P[c][3]);
+            const double up = P[c][2] + dpp_left<TX>(P[c][3]);
+            if (ty < TY - 1) s_y[s & 1][tid * 3 + c] = up;
         }
         double e4 = 0.0;
         if (DIAG_FLY) e4 = read_E4(s, Ee);
@@ -453,7 +474,22 @@ __device__ __forceinline__ void fine_dma_run(const TileArgs &t, const NodeArgs &
         tail_loads(el + 1, s + 1 < nsteps);
         tail_stores(el, s >= 1, o);
     };
-    if (read_prev) {
+    // the same queue pattern and barriers without the element: waves that hold no part of the domain
+    auto idle_step = [&](int s) {
+        batch(s);
+        if (MASKED) {
+            store_mask(s + 2, pmk);
+            load_mask(kz0 - 1 + s + 3, pmk);
+        }
+        fd_wait<W_MID>();
+        __syncthreads();
+        if (HAS_B) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b01), "+v"(b2), "+v"(p01), "+v"(p2) : "n"(W_EPI));
+        tail_loads(kz0 + s, false);
+        tail_stores(kz0 - 1 + s, false, zero3);
+    };
+    if (!live) {
+        for (int s = 0; s < nsteps; s++) idle_step(s);
+    } else if (read_prev) {
         for (int s = 0; s < nsteps; s++) step(s, std::true_type{});
     } else {
         for (int s = 0; s < nsteps; s++) step(s, std::false_type{});
@@ -485,7 +521,7 @@ __device__ __forceinline__ void fine_dma_run(const TileArgs &t, const NodeArgs &
     }
 }
 
-template <int EPI, int TX, int TY, int D, int WPS>
+template <int EPI, int TX, int TY, int D, int WPS, bool CARRY = false>
 __global__ __launch_bounds__(TX *TY, WPS) void k_fine_dma(TileArgs t, NodeArgs a) {
     using S = FineDma<TX, TY, D>;
     __shared__ __attribute__((aligned(1024))) char lds[S::LDS_BYTES];
@@ -512,7 +548,7 @@ __global__ __launch_bounds__(TX *TY, WPS) void k_fine_dma(TileArgs t, NodeArgs a
         masked = __builtin_amdgcn_readfirstlane(__syncthreads_or(any != 0u)) != 0;
     }
     if (masked)
-        fine_dma_run<EPI, TX, TY, D, true>(t, a, lds, bxi, byi, bzi);
+        fine_dma_run<EPI, TX, TY, D, CARRY, true>(t, a, lds, bxi, byi, bzi);
     else
-        fine_dma_run<EPI, TX, TY, D, false>(t, a, lds, bxi, byi, bzi);
+        fine_dma_run<EPI, TX, TY, D, CARRY, false>(t, a, lds, bxi, byi, bzi);
 }
