@@ -4,7 +4,7 @@
 // build: tools/probe/build_fine_probe.sh      run: fine_probe ex ey ez [reps] [kz] [mode]
 //   mode bit 0: bit checks, bit 1: timings, bit 2: all tile shapes / depths (default: 16x16, D = 2 only)
 #include "../../topopt_in_petsc_amd/csrc/elements.h"
-#include "../../topopt_in_petsc_amd/csrc/fine_dma.h"
+#include "../../topopt_in_petsc_amd/csrc/fine_u4.h"
 
 #include <chrono>
 #include <string>
@@ -61,7 +61,7 @@ static Prob make(int ex, int ey, int ez, bool with_mask) {
         for (long n = 0; n < p.nn; n++) {
             const int i = (int)(n % p.nx);
             if (i == 0) m[n] = 7;
-            else if (hash_u01(n, 11) < 2e-4) m[n] = (uint8_t)(1 + (int)(hash_u01(n, 12) * 6.99));
+            else if (!getenv("PROBE_FACE_ONLY") && hash_u01(n, 11) < 2e-4) m[n] = (uint8_t)(1 + (int)(hash_u01(n, 12) * 6.99));
             cm[n % ((long)p.nx * p.ny)] |= m[n];
         }
         CK(hipMalloc(&p.mask, p.nn));
@@ -111,6 +111,14 @@ static void launch_new(const Prob &p, int kz, double *out, bool prev) {
     kz = balanced(p, kz);
     const int tx = (p.nx + S::TOX - 1) / S::TOX, ty = (p.ny + S::TOY - 1) / S::TOY, tz = (p.nz + kz - 1) / kz;
     hipLaunchKernelGGL((k_fine_dma<EPI, TX, TY, D, WPS, CARRY>), dim3(tx, ty, tz), dim3(TX * TY), 0, 0, targs(p, kz), nargs(p, out, EPI, prev));
+}
+
+template <int EPI, int TX, int TY, int WPS, bool CARRY>
+static void launch_u4(const Prob &p, int kz, double *out, bool prev) {
+    using S = FineU4<TX, TY>;
+    kz = balanced(p, kz);
+    const int tx = (p.nx + S::TOX - 1) / S::TOX, ty = (p.ny + S::TOY - 1) / S::TOY, tz = (p.nz + kz - 1) / kz;
+    hipLaunchKernelGGL((k_fine_u4<EPI, TX, TY, WPS, CARRY>), dim3(tx, ty, tz), dim3(TX * TY), 0, 0, targs(p, kz), nargs(p, out, EPI, prev));
 }
 
 static double bytes_of(const Prob &p, int epi, bool prev) {
@@ -228,6 +236,48 @@ static void timing(const Prob &p, int kz, bool prev, int reps, const char *name)
     printf("time %-30s kz %3d lds %6d wg/CU %d : %8.1f us  %7.1f GB/s  frac %.3f\n", name, kz, S::LDS_BYTES, occ, us, gb / us * 1e6, gb / us * 1e6 / 8000.0);
     fflush(stdout);
 }
+template <int EPI, int TX, int TY, int WPS, bool CARRY>
+static int check_u4(const Prob &p, int kz_old, int kz_new, bool prev, const char *name) {
+    constexpr bool dot = EPI == EPI_APPLY_DOT || EPI == EPI_CHEB_DOT;
+    CK(hipMemcpy(p.y0, p.init, 24 * p.nn, hipMemcpyDeviceToDevice));
+    CK(hipMemcpy(p.y1, p.init, 24 * p.nn, hipMemcpyDeviceToDevice));
+    launch_old<EPI>(p, kz_old, p.y0, prev);
+    CK(hipDeviceSynchronize());
+    double red_ref = 0;
+    if (dot) CK(hipMemcpy(&red_ref, p.red, 8, hipMemcpyDeviceToHost));
+    launch_u4<EPI, TX, TY, WPS, CARRY>(p, kz_new, p.y1, prev);
+    {
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            printf("check %-28s LAUNCH FAILED: %s\n", name, hipGetErrorString(e));
+            return 1;
+        }
+    }
+    CK(hipDeviceSynchronize());
+    const long bad = diff_count(p, &red_ref, dot);
+    printf("check %-28s %dx%dx%d mask=%d kz %d/%d prev=%d: %s (%ld)\n", name, p.ex, p.ey, p.ez, p.mask != nullptr, kz_old, kz_new, (int)prev,
+           bad ? "DIFFERENT" : "bit-identical", bad);
+    fflush(stdout);
+    return bad != 0;
+}
+template <int EPI, int TX, int TY, int WPS, bool CARRY>
+static void timing_u4(const Prob &p, int kz, bool prev, int reps, const char *name) {
+    using S = FineU4<TX, TY>;
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (k_fine_u4<EPI, TX, TY, WPS, CARRY>), TX * TY, 0) != hipSuccess) occ = -1;
+    launch_u4<EPI, TX, TY, WPS, CARRY>(p, kz, p.y1, prev);
+    {
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            printf("time %-30s LAUNCH FAILED: %s\n", name, hipGetErrorString(e));
+            return;
+        }
+    }
+    const double us = time_us([&] { launch_u4<EPI, TX, TY, WPS, CARRY>(p, kz, p.y1, prev); }, reps);
+    const double gb = bytes_of(p, EPI, prev) / 1e9;
+    printf("time %-30s kz %3d lds %6d wg/CU %d : %8.1f us  %7.1f GB/s  frac %.3f\n", name, balanced(p, kz), S::LDS_BYTES, occ, us, gb / us * 1e6, gb / us * 1e6 / 8000.0);
+    fflush(stdout);
+}
 template <int EPI>
 static void timing_old(const Prob &p, int kz, bool prev, int reps, const char *name) {
     const double us = time_us([&] { launch_old<EPI>(p, kz, p.y1, prev); }, reps);
@@ -258,6 +308,7 @@ int main(int argc, char **argv) {
     const int kz = argc > 5 ? atoi(argv[5]) : 16;
     const int mode = argc > 6 ? atoi(argv[6]) : 3;
     const bool ext = (mode & 4) != 0;  // bit 2: the other tile shapes and depths too
+    const bool u4 = (mode & 8) != 0;   // bit 3: the unrolled kernel (fine_u4.h)
     int fails = 0;
     if (mode & 1) {
         for (int with_mask = 0; with_mask < 2; with_mask++) {
@@ -268,6 +319,15 @@ int main(int argc, char **argv) {
             fails += check<EPI_CHEB, 16, 16, 2, 3>(p, 8, kz, false, "cheb(c1=0) 16x16 D2");
             fails += check<EPI_APPLY_DOT, 16, 16, 2, 3>(p, 8, kz, false, "apply_dot 16x16 D2");
             fails += check<EPI_CHEB_DOT, 16, 16, 2, 3>(p, 8, kz, true, "cheb_dot 16x16 D2");
+#define U4_VARIANTS(F)                                                   \
+    F(EPI_APPLY, 16, 16, 3, true, false, "u4 apply 16x16 carry")         \
+    F(EPI_CHEB, 16, 16, 2, true, true, "u4 cheb 16x16 w2 carry")         \
+    F(EPI_APPLY, 32, 8, 2, true, false, "u4 apply 32x8 carry w2")        \
+    F(EPI_CHEB, 32, 8, 2, true, true, "u4 cheb 32x8 w2 carry")           \
+    F(EPI_APPLY, 64, 4, 2, true, false, "u4 apply 64x4 carry w2")        \
+    F(EPI_CHEB, 64, 4, 2, true, true, "u4 cheb 64x4 w2 carry")
+#define CHKU(E, TX, TY, W, C, PV, NAME) fails += check_u4<E, TX, TY, W, C>(p, 8, kz, PV, NAME);
+            if (u4) { U4_VARIANTS(CHKU) }
             if (ext) {
 #define EXT_VARIANTS(F)                                                   \
     F(EPI_APPLY, 16, 16, 1, 4, false, false, "apply 16x16 D1 w4")          \
@@ -290,7 +350,7 @@ int main(int argc, char **argv) {
         }
     }
     if (mode & 2) {
-        Prob p = make(ex, ey, ez, false);
+        Prob p = make(ex, ey, ez, getenv("PROBE_FACE_ONLY") != nullptr);
         const int kzs[3] = {kz, 2 * kz, 4 * kz};
         const int nkz = getenv("PROBE_ONE_KZ") ? 1 : 3;
         for (int nb = 2048; nb <= 32768; nb *= 4) {
@@ -303,6 +363,8 @@ int main(int argc, char **argv) {
             const int k = kzs[q];
             timing<EPI_APPLY, 16, 16, 2, 3>(p, k, false, reps, "apply 16x16 D2");
             timing<EPI_CHEB, 16, 16, 2, 3>(p, k, true, reps, "cheb 16x16 D2");
+#define TIMU(E, TX, TY, W, C, PV, NAME) timing_u4<E, TX, TY, W, C>(p, k, PV, reps, NAME);
+            if (u4) { U4_VARIANTS(TIMU) }
             if (ext) {
 #define TIM(E, TX, TY, D, W, C, PV, NAME) timing<E, TX, TY, D, W, C>(p, k, PV, reps, NAME);
                 EXT_VARIANTS(TIM)

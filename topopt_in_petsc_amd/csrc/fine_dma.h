@@ -369,8 +369,9 @@ __device__ __forceinline__ void fine_dma_run(const TileArgs &t, const NodeArgs &
     fd_wait<W_PRO>();  // batches -D-1 and -D have landed: planes 0, 1, moduli of layer 0
     __syncthreads();
     // a wave whose lanes hold neither an element nor a node of the domain (rows beyond the last node row of the mesh)
-    // only takes part in the staging, the barriers and the (dropped) memory operations: idle_step below
-    const bool live = __builtin_amdgcn_readfirstlane((int)(__ballot(elem_ok || (tx >= 1 && ty >= 1 && ei < t.nx && ej < t.ny)) != 0ull)) != 0;
+    // only takes part in the staging, the barriers and the (dropped) memory operations: idle_step below.  (The row
+    // below the first node row, ej < 0, is NOT idle: the first node row reads its -- zero -- contribution.)
+    const bool live = __builtin_amdgcn_readfirstlane((int)(__ballot(elem_ok || ej < 0 || (tx >= 1 && ty >= 1 && ei < t.nx && ej < t.ny)) != 0ull)) != 0;
     if (CARRY && live) {
         double x0[3];
         read_plane(0, Ub, x0);

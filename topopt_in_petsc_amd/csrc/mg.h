@@ -10,6 +10,7 @@
 #include "coarse_run.h"
 #include "matfree_tile.h"
 #include "fine_tile.h"
+#include "fine_u4.h"
 
 enum { LV_MATFREE = 0, LV_DIA = 1, LV_MACRO = 2 };
 
@@ -254,6 +255,10 @@ inline double elem_lambda_bound(int n, const double *KE) {
     return l;
 }
 
+inline int fine_version() {  // generation of the fine-level operator kernel (3: fine_u4.h, 2: fine_tile.h, 1: matfree_tile.h)
+    static const int v = getenv("TP_FINE_V") ? atoi(getenv("TP_FINE_V")) : 3;
+    return v;
+}
 inline int xcd_remap() {
     // on by default: tiles that share cache lines meet in one XCD's L2 (PMC: -30 % fetch traffic, -5 % time)
     static const int v = getenv("TP_XCD_REMAP") ? atoi(getenv("TP_XCD_REMAP")) : 1;
@@ -265,9 +270,8 @@ inline int xcd_remap() {
 // redundant z-halo (measured, DESIGN.md 4.1: 128^3 kz 15 -> 729 workgroups beats kz 8 -> 1377 by 10 %; 128x64x64
 // kz 4 -> 765 beats kz 8 by 20 %); that only pays while the chunks stay short enough to fill >= 90 % of the slots,
 // otherwise several rounds of kz ~ 8..32 are better (256x128x128: kz 8 beats kz 33).
-inline int fine_kz(int planes, int tiles, int fine_v) {
-    constexpr int SLOTS = 768;
-    if (fine_v == 2) {
+inline int fine_kz(int planes, int tiles, int fine_v, int SLOTS = 768) {
+    if (fine_v >= 2) {
         const int tz1 = SLOTS / tiles;
         if (tz1 >= 1) {
             const int kz1 = (planes + tz1 - 1) / tz1;
@@ -490,8 +494,51 @@ struct MGSolver {
             const int tx = (L.g.nx + TOUT - 1) / TOUT, ty = (L.g.ny + TOUT - 1) / TOUT;
             const int planes = L.g.own_hi - L.g.own_lo + 1;
             static const int kz_env = getenv("TP_TILE_KZ") ? atoi(getenv("TP_TILE_KZ")) : 0;
-            static const int fine_v = getenv("TP_FINE_V") ? atoi(getenv("TP_FINE_V")) : 2;
+            static const int fine_v = fine_version();
             int kz = kz_env > 0 ? kz_env : fine_kz(planes, tx * ty, fine_v);
+            // third generation (fine_u4.h; TP_FINE_V=2: k_fine_tile, 1: k_matfree_tile): tile shape by mesh size.  Its
+            // 32-bit window arithmetic needs every vector of the level below 2 GB.
+            if (fine_v >= 3 && 24.0 * L.g.nodes() < 2.0e9) {
+                constexpr bool IS_CHEB = (EPI == EPI_CHEB || EPI == EPI_CHEB_DOT);
+                static const int shape_env = getenv("TP_FINE_SHAPE") ? atoi(getenv("TP_FINE_SHAPE")) : 0;  // 1: 16x16, 2: 32x8
+                const int t32 = ((L.g.nx + 30) / 31) * ((L.g.ny + 6) / 7);   // 32 x 8 tiles per z-chunk
+                // measured on the BASELINE meshes (tools/probe/fine_probe.hip, profiles/r03_fine_probe.txt): the long
+                // rows of 32 x 8 win once a chunk of them fills the chip (256^3, 512x256x256; Chebyshev from 256x128x128)
+                const bool wide = shape_env ? shape_env == 2 : t32 >= (IS_CHEB ? 160 : 256);
+                const bool timed3 = grid->kt_on && IS_CHEB && !split && !sg_capturing;
+                if (timed3) kernel_timer_mark(grid);
+                for (int pass = 0; pass < (split ? 2 : 1); pass++) {
+                    int lo, hi, r1lo, r1hi;
+                    tile_ranges(pass, lo, hi, r1lo, r1hi);
+                    const int pl = hi - lo + 1;
+                    int kz3;
+                    dim3 gdim;
+                    if (wide) {
+                        const int nch = kz_env > 0 ? (pl + kz_env - 1) / kz_env : (pl + 42) / 43;  // chunks of <= 43 planes, balanced
+                        kz3 = (pl + nch - 1) / nch;
+                    } else {
+                        kz3 = kz_env > 0 ? kz_env : fine_kz(pl > 0 ? pl : 1, tx * ty, fine_v, IS_CHEB ? 512 : 768);
+                        if (kz3 > pl && pl > 0) kz3 = pl;
+                    }
+                    const int tz = (hi - lo + kz3) / kz3 + (r1hi - r1lo + kz3) / kz3;
+                    TileArgs ta{L.g.nx, L.g.ny, L.g.nzl, L.g.ex, L.g.ey, L.g.ezl, lo, hi, kz3,
+                                L.E, L.mask, L.colmask, L.sym_slot * SYMKE_STRIDE, 0, 0, nullptr, xcd_remap(), 0, r1lo, r1hi,
+                                0, nullptr, nullptr, 0, nullptr};
+                    if (wide) {
+                        gdim = dim3((L.g.nx + 30) / 31, (L.g.ny + 6) / 7, tz);
+                        last_nblocks = gdim.x * gdim.y * gdim.z;
+                        TP_LAUNCH((k_fine_u4<EPI, 32, 8, 2, true>), gdim, dim3(256), 0, grid->stream, ta, a);
+                    } else {
+                        gdim = dim3(tx, ty, tz);
+                        last_nblocks = gdim.x * gdim.y * gdim.z;
+                        TP_LAUNCH((k_fine_u4<EPI, 16, 16, IS_CHEB ? 2 : 3, true>), gdim, dim3(256), 0, grid->stream, ta, a);
+                    }
+                    if (split && pass == 0) TP_TRY(after_boundary());
+                }
+                if (timed3) kernel_timer_mark(grid);
+                bytes = 16.0 * DOF * nown + 8.0 * L.g.own_elems();
+                flops = 2.0 * 576 * (double)L.g.own_elems();
+            } else {
             if (kz > planes) kz = planes;
             const bool timed = grid->kt_on && (EPI == EPI_CHEB || EPI == EPI_CHEB_DOT) && !split && !sg_capturing;
             if (timed) kernel_timer_mark(grid);
@@ -503,7 +550,7 @@ struct MGSolver {
                 TileArgs ta{L.g.nx, L.g.ny, L.g.nzl, L.g.ex, L.g.ey, L.g.ezl, lo, hi, kz,
                             L.E, L.mask, L.colmask, L.sym_slot * SYMKE_STRIDE, 0, 0, nullptr, xcd_remap(), 0, r1lo, r1hi,
                             0, nullptr, nullptr, 0, nullptr};
-                if (fine_v == 2) {
+                if (fine_v >= 2) {
                     TP_LAUNCH((k_fine_tile<EPI>), dim3(tx, ty, tz), dim3(TILE * TILE), 0, grid->stream, ta, a);
                 } else {
                     if constexpr (EPI == EPI_CHEB_DOT) return TP_ERR_STATE;
@@ -514,6 +561,7 @@ struct MGSolver {
             if (timed) kernel_timer_mark(grid);
             bytes = 16.0 * DOF * nown + 8.0 * L.g.own_elems();
             flops = 2.0 * 576 * (double)L.g.own_elems();
+            }
         } else if constexpr (EPI == EPI_CHEB_DOT) {
             return TP_ERR_STATE;  // only the fine tile kernel carries the fused b . x_out
         } else if (DOF == 3 && L.kind == LV_MACRO) {
@@ -915,9 +963,9 @@ struct MGSolver {
     }
     // can the last post-smoothing step of a V-cycle return r . z ?  (fine tile kernel, at least one fused step)
     bool can_fuse_rz() const {
-        static const int fine_v = getenv("TP_FINE_V") ? atoi(getenv("TP_FINE_V")) : 2;
+        static const int fine_v = fine_version();
         static const bool off = getenv("TP_NO_FUSE_RZ") != nullptr;
-        return !off && fine_v == 2 && nlv > 1 && three_term(lv[0]) && opt.nsmooth >= 1;
+        return !off && fine_v >= 2 && nlv > 1 && three_term(lv[0]) && opt.nsmooth >= 1;
     }
 
     // every rank's owned rows of `nseg` consecutive level vectors (stride src_stride / dst_stride) -> the
