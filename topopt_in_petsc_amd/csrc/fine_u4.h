@@ -42,7 +42,7 @@ __device__ __forceinline__ void fu_dma16(unsigned m0a, unsigned m0b, unsigned vo
     asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 3\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds" ::"s"(m0a), "s"(m0b), "v"(voff), "s"(rs) : "memory");
 }
 
-template <int EPI, int TX, int TY, bool CARRY, bool MASKED>
+template <int EPI, int TX, int TY, bool CARRY, bool MASKED, bool BITOPS = true>
 __device__ __forceinline__ void fine_u4_run(const TileArgs &t, const NodeArgs &a, char *lds, int bxi, int byi, int bzi) {
 #pragma clang fp contract(off)
     using S = FineU4<TX, TY>;
@@ -221,12 +221,18 @@ __device__ __forceinline__ void fine_u4_run(const TileArgs &t, const NodeArgs &a
             U[c][0] = r0[c], U[c][1] = r0[3 + c], U[c][2] = r1[c], U[c][3] = r1[3 + c];
             x0v[c] = U[c][0];
             if (MASKED) {
-                // clamped dof -> +0.0, as a bit operation: (sign-extended "not clamped" bit) & both words.  The select form
-                // costs a compare and an SGPR pair per value (the masked variant spilled 500 SGPRs with it).
+                // clamped dof -> +0.0.  BITOPS: (sign-extended "not clamped" bit) & both words -- no compare, no SGPR pair
+                // per value (the select form spills hundreds of SGPRs) but more vector registers: the form of the kernels
+                // built for two waves per SIMD; those built for three keep the select (the bit form spills VGPRs there:
+                // 260 -> 340 us for the 256^3 product).
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const int keep = ((int)(~m12 << (31 - (3 * q + c)))) >> 31;
-                    U[c][q] = __hiloint2double(__double2hiint(U[c][q]) & keep, __double2loint(U[c][q]) & keep);
+                    if (BITOPS) {
+                        const int keep = ((int)(~m12 << (31 - (3 * q + c)))) >> 31;
+                        U[c][q] = __hiloint2double(__double2hiint(U[c][q]) & keep, __double2loint(U[c][q]) & keep);
+                    } else {
+                        U[c][q] = ((m12 >> (3 * q + c)) & 1u) ? 0.0 : U[c][q];
+                    }
                 }
             }
             wht4(U[c]);
@@ -437,7 +443,7 @@ __global__ __launch_bounds__(TX *TY, WPS) void k_fine_u4(TileArgs t, NodeArgs a)
         masked = __builtin_amdgcn_readfirstlane(__syncthreads_or(any != 0u)) != 0;
     }
     if (masked)
-        fine_u4_run<EPI, TX, TY, false, true>(t, a, lds, bxi, byi, bzi);
+        fine_u4_run<EPI, TX, TY, false, true, WPS == 2>(t, a, lds, bxi, byi, bzi);
     else
         fine_u4_run<EPI, TX, TY, CARRY, false>(t, a, lds, bxi, byi, bzi);
 }
