@@ -123,9 +123,13 @@ def fine_kernel_times(tp, torch, ex, ey, ez, reps):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def timed(fn, n):
-        for _ in range(2):
-            fn()
-        torch.cuda.synchronize()
+        # warm-up long enough for the clocks to settle: the first launches after an idle phase measured 15-20 % slower
+        # (rocprofv3: 274 .. 351 us for one kernel of this loop against 257 .. 273 us in a busy process)
+        t0 = time.time()
+        while time.time() - t0 < 0.15:
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
         e0.record()
         for _ in range(n):
             fn()
@@ -252,9 +256,11 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def timed(fn, reps):
-        for _ in range(3):
-            fn()
-        torch.cuda.synchronize()
+        t0 = time.time()
+        while time.time() - t0 < 0.15:  # clocks settled (see fine_kernel_times)
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
         ev0.record()
         for _ in range(reps):
             fn()
@@ -314,7 +320,7 @@ def main():
     # Infinity Cache), measured in this run on rank 0 of a 1-GPU job
     if world == 1 and not a.no_cube256 and a.workload == "cantilever128":
         u = y = None
-        s256, c256, nn, ne = fine_kernel_times(tp, torch, 256, 256, 256, 10)
+        s256, c256, nn, ne = fine_kernel_times(tp, torch, 256, 256, 256, 40)
         rec = json.load(open(tj)).get("256x256x256") if os.path.exists(tj) else None
         roofline["spmv256"] = {
             "mesh": "256x256x256 elements (50923779 DOF)",

@@ -1,0 +1,87 @@
+"""The three generations of the fine-level operator kernel (csrc/matfree_tile.h, fine_tile.h, fine_u4.h) must give the
+same BITS: product, fused Chebyshev steps (zero and non-zero guess), V-cycle and a whole solve, on a cantilever and on
+scattered Dirichlet sets, for both tile shapes of the third generation.  The generation is read from the environment
+once per process, hence one subprocess per setting."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, %(root)r)
+import topopt_in_petsc_amd as tp
+tp.load_library()
+ex, ey, ez, scattered, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
+grid = tp.Grid(nx, ny, nz, h)
+le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=3, rtol=1e-8))
+rng = np.random.default_rng(7)
+if scattered:
+    N = np.ones(3 * nx * ny * nz)
+    N[rng.random(N.size) < 2e-3] = 0.0
+    N[: 3 * nx].reshape(-1, 3)[:, :] = 0.0
+    R = rng.standard_normal(N.size) * 1e-3
+    le.SetBC(torch.from_numpy(N).cuda(), torch.from_numpy(R).cuda())
+else:
+    le.SetUpLoadAndBC()
+le.AssembleStiffnessMatrix(grid.synth_density(12345), 1e-9, 1.0, 3.0)
+u = torch.from_numpy(rng.standard_normal(3 * nx * ny * nz)).cuda()
+b = torch.from_numpy(rng.standard_normal(3 * nx * ny * nz)).cuda()
+res = {}
+res["apply"] = le.MatMult(u).cpu().numpy()
+x = torch.zeros_like(u)
+le.smooth(0, b, x, 3, True)
+res["cheb0"] = x.cpu().numpy()
+x = u.clone()
+le.smooth(0, b, x, 4, False)
+res["cheb1"] = x.cpu().numpy()
+res["pc"] = le.precond(b).cpu().numpy()
+its = le.KSPSolve(hist_cap=300)
+res["U"] = le.U.cpu().numpy()
+res["hist"] = np.asarray(le.last_hist)
+res["its"] = np.asarray([its])
+np.savez(out, **res)
+"""
+
+
+def run(tmp_path, tag, env, mesh, scattered):
+    out = str(tmp_path / ("%s.npz" % tag))
+    e = dict(os.environ)
+    for k in ("TP_FINE_V", "TP_FINE_SHAPE", "TP_TILE_KZ"):
+        e.pop(k, None)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", WORKER % {"root": ROOT}] + [str(v) for v in mesh] + [str(int(scattered)), out], env=e,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return np.load(out)
+
+
+@pytest.mark.parametrize("mesh,scattered", [((40, 24, 20), False), ((36, 28, 20), True), ((64, 32, 32), False)])
+def test_generations_bitwise(tmp_path, mesh, scattered):
+    ref = run(tmp_path, "g2", {"TP_FINE_V": "2"}, mesh, scattered)
+    settings = {"g1": {"TP_FINE_V": "1"}, "g3_16x16": {"TP_FINE_V": "3", "TP_FINE_SHAPE": "1"},
+                "g3_32x8": {"TP_FINE_V": "3", "TP_FINE_SHAPE": "2"}, "g3_32x8_kz3": {"TP_FINE_V": "3", "TP_FINE_SHAPE": "2", "TP_TILE_KZ": "3"},
+                "auto": {}}
+    for tag, env in settings.items():
+        got = run(tmp_path, tag, env, mesh, scattered)
+        assert int(got["its"][0]) == int(ref["its"][0]), tag
+        for k in ("apply", "cheb0", "cheb1"):
+            # generation 1 is compiled with implicit contraction and has another Chebyshev epilogue: bits only from 2 on
+            if tag == "g1":
+                assert np.abs(got[k] - ref[k]).max() <= 1e-12 * np.abs(ref[k]).max(), (tag, k)
+            else:
+                assert np.array_equal(got[k].view(np.int64), ref[k].view(np.int64)), (tag, k)
+        if tag != "g1":
+            assert np.array_equal(got["pc"].view(np.int64), ref["pc"].view(np.int64)), (tag, "pc")
+            # the solve also depends on the dot products fused into the kernels: one partial sum per workgroup, i.e. a
+            # summation order that follows the tile shape and the z-chunks -> last-bit differences in alpha, beta
+            for k in ("U", "hist"):
+                assert np.abs(got[k] - ref[k]).max() <= 1e-9 * np.abs(ref[k]).max(), (tag, k)

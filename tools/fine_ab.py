@@ -24,9 +24,12 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 
 
 def timed(fn, n):
-    for _ in range(3):
-        fn()
-    torch.cuda.synchronize()
+    import time
+    t0 = time.time()
+    while time.time() - t0 < 0.15:  # clocks settled
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
     e0.record()
     for _ in range(n):
         fn()

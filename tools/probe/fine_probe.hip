@@ -51,7 +51,12 @@ static Prob make(int ex, int ey, int ez, bool with_mask) {
     CK(hipMemcpy(p.init, h.data(), 24 * p.nn, hipMemcpyHostToDevice));
     std::vector<double> e(p.ne);
     for (long i = 0; i < p.ne; i++) {
-        const double x = 0.05 + 0.95 * hash_u01(i, 7);
+        double x = 0.05 + 0.95 * hash_u01(i, 7);
+        if (getenv("PROBE_SIMP")) {  // the bench's synthetic density: smooth field + noise, clamped at 1e-3
+            const double xc = ((i % ex) + 0.5) / ey, yc = (((i / ex) % ey) + 0.5) / ey, zc = ((i / ((long)ex * ey)) + 0.5) / ey;
+            x = 0.12 + 0.4 * sin(7 * M_PI * xc) * sin(5 * M_PI * yc) * sin(3 * M_PI * zc) + 0.3 * (hash_u01(i, 12345) - 0.5);
+            x = x < 1e-3 ? 1e-3 : (x > 1.0 ? 1.0 : x);
+        }
         e[i] = 1e-9 + x * x * x * (1.0 - 1e-9);
     }
     CK(hipMemcpy(p.E, e.data(), 8 * p.ne, hipMemcpyHostToDevice));

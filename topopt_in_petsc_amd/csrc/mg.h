@@ -255,8 +255,14 @@ inline double elem_lambda_bound(int n, const double *KE) {
     return l;
 }
 
-inline int fine_version() {  // generation of the fine-level operator kernel (3: fine_u4.h, 2: fine_tile.h, 1: matfree_tile.h)
-    static const int v = getenv("TP_FINE_V") ? atoi(getenv("TP_FINE_V")) : 3;
+// Generation of the fine-level operator kernel: 3 fine_u4.h, 2 fine_tile.h, 1 matfree_tile.h; 0 (default) = by mesh
+// size: the third generation from 160 tiles of 32 x 8 per z-chunk on (256x128x128 and larger), the second below --
+// measured through the library on the BASELINE meshes (tools/ab3.sh): 256^3 319 / 411 us against 334 / 471 (product /
+// Chebyshev step), 256x128x128 79 / 127 against 82 / 130, 128^3 41 / 65 against 41 / 60, 128x64x64 17.8 / 22.5 against
+// 16.7 / 21.7.  On the small meshes one round of workgroups covers the mesh and the launch lasts as long as its slowest
+// workgroup -- a tile with a Dirichlet condition, which the third generation serves ~25 % slower than a free one.
+inline int fine_version() {
+    static const int v = getenv("TP_FINE_V") ? atoi(getenv("TP_FINE_V")) : 0;
     return v;
 }
 inline int xcd_remap() {
@@ -271,7 +277,7 @@ inline int xcd_remap() {
 // kz 4 -> 765 beats kz 8 by 20 %); that only pays while the chunks stay short enough to fill >= 90 % of the slots,
 // otherwise several rounds of kz ~ 8..32 are better (256x128x128: kz 8 beats kz 33).
 inline int fine_kz(int planes, int tiles, int fine_v, int SLOTS = 768) {
-    if (fine_v >= 2) {
+    if (fine_v >= 2 || fine_v == 0) {
         const int tz1 = SLOTS / tiles;
         if (tz1 >= 1) {
             const int kz1 = (planes + tz1 - 1) / tz1;
@@ -498,10 +504,10 @@ struct MGSolver {
             int kz = kz_env > 0 ? kz_env : fine_kz(planes, tx * ty, fine_v);
             // third generation (fine_u4.h; TP_FINE_V=2: k_fine_tile, 1: k_matfree_tile): tile shape by mesh size.  Its
             // 32-bit window arithmetic needs every vector of the level below 2 GB.
-            if (fine_v >= 3 && 24.0 * L.g.nodes() < 2.0e9) {
+            const int t32 = ((L.g.nx + 30) / 31) * ((L.g.ny + 6) / 7);   // 32 x 8 tiles per z-chunk
+            if ((fine_v >= 3 || (fine_v == 0 && t32 >= 160)) && 24.0 * L.g.nodes() < 2.0e9) {
                 constexpr bool IS_CHEB = (EPI == EPI_CHEB || EPI == EPI_CHEB_DOT);
                 static const int shape_env = getenv("TP_FINE_SHAPE") ? atoi(getenv("TP_FINE_SHAPE")) : 0;  // 1: 16x16, 2: 32x8
-                const int t32 = ((L.g.nx + 30) / 31) * ((L.g.ny + 6) / 7);   // 32 x 8 tiles per z-chunk
                 // measured on the BASELINE meshes (tools/probe/fine_probe.hip, profiles/r03_fine_probe.txt): the long
                 // rows of 32 x 8 win once a chunk of them fills the chip (256^3, 512x256x256; Chebyshev from 256x128x128)
                 const bool wide = shape_env ? shape_env == 2 : t32 >= (IS_CHEB ? 160 : 256);
@@ -550,7 +556,7 @@ struct MGSolver {
                 TileArgs ta{L.g.nx, L.g.ny, L.g.nzl, L.g.ex, L.g.ey, L.g.ezl, lo, hi, kz,
                             L.E, L.mask, L.colmask, L.sym_slot * SYMKE_STRIDE, 0, 0, nullptr, xcd_remap(), 0, r1lo, r1hi,
                             0, nullptr, nullptr, 0, nullptr};
-                if (fine_v >= 2) {
+                if (fine_v >= 2 || fine_v == 0) {
                     TP_LAUNCH((k_fine_tile<EPI>), dim3(tx, ty, tz), dim3(TILE * TILE), 0, grid->stream, ta, a);
                 } else {
                     if constexpr (EPI == EPI_CHEB_DOT) return TP_ERR_STATE;
@@ -965,7 +971,7 @@ struct MGSolver {
     bool can_fuse_rz() const {
         static const int fine_v = fine_version();
         static const bool off = getenv("TP_NO_FUSE_RZ") != nullptr;
-        return !off && fine_v >= 2 && nlv > 1 && three_term(lv[0]) && opt.nsmooth >= 1;
+        return !off && (fine_v >= 2 || fine_v == 0) && nlv > 1 && three_term(lv[0]) && opt.nsmooth >= 1;
     }
 
     // every rank's owned rows of `nseg` consecutive level vectors (stride src_stride / dst_stride) -> the
