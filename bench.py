@@ -56,6 +56,8 @@ def parse():
     p.add_argument("--spmv-reps", type=int, default=50)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", default="96x48x48")
+    p.add_argument("--cpu-budget", type=float, default=240.0, help="host seconds the CPU baseline may take on the GPU line's own mesh (else: --cpu-sample)")
+    p.add_argument("--no-stated-cycle", action="store_true", help="skip the run of the SURVEY 8(d) cycle (4 levels, 4 / 30 steps, V)")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="gloo + --same-device validates the multi-rank path on a 1-GPU box")
     p.add_argument("--same-device", action="store_true")
@@ -76,15 +78,14 @@ def respawn_under_torchrun(n):
     os.execv(sys.executable, cmd)
 
 
-def cpu_baseline(sample, rtol, fine_eig, gpu_ndof, nlv=4, nsmooth=4, ncoarse=30, cycles=""):
-    """The oracle (a port of the reference's assembled-CSR path, OpenMP) timed on
-    the host cores for one step of the same algorithm on a bounded sample mesh."""
-    from oracle import oracle as orc
-    ex, ey, ez = [int(v) for v in sample.split("x")]
+def cpu_step(orc, el, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, matfree_too):
+    """One design iteration of the oracle (the reference's data path: assembled CSR + Galerkin SpGEMM) on `el` elements;
+    with matfree_too the solve is repeated with the fine-level operator applied matrix-free (OpenMP gather).  Returns
+    (n_dof, its, seconds assembled, seconds matrix-free or None, levels)."""
+    ex, ey, ez = el
     while nlv > 1 and (ex % (1 << (nlv - 1)) or ey % (1 << (nlv - 1)) or ez % (1 << (nlv - 1))):
         nlv -= 1
     nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
-    cores = int(os.environ.get("OMP_NUM_THREADS", min(os.cpu_count() or 1, 16)))
     x = orc.synth_density(ex, ey, ez, h)
     KE = orc.hex8_ke_box(h, h, h, 0.3)
     N, R = orc.cantilever_bc(nx, ny, nz, h)
@@ -95,19 +96,47 @@ def cpu_baseline(sample, rtol, fine_eig, gpu_ndof, nlv=4, nsmooth=4, ncoarse=30,
     t0 = time.perf_counter()
     xt, xp = flt.project(1, x)
     mg.assemble(KE, orc.simp(xp), N)
+    t1 = time.perf_counter()
     U, its, hist = mg.solve(R * N, rtol=rtol)
+    t2 = time.perf_counter()
     fx, gx, df, dg = orc.compliance_sens(nx, ny, nz, KE, U, xp)
     df = flt.gradient(1, x, xt, df)
     dg = flt.gradient(1, x, xt, dg)
-    t = time.perf_counter() - t0
-    ndof = 3 * nx * ny * nz
-    return {"value": ndof / t, "unit": "DOF-updates/s", "cores": cores, "kind": "port",
-            "sample_n_dof": ndof, "gpu_line_n_dof": gpu_ndof,
-            "sample": "1 step on %s elements (%d DOF -- NOT the GPU line's %d-DOF mesh: bounded to ~15 s of host time), "
-                      "%d levels, Chebyshev(%d) / coarse Chebyshev(%d)%s as on the GPU line, CG its %d, %.2f s; assembled CSR + "
-                      "Galerkin SpGEMM (the reference's data path), OpenMP on %d threads" % (sample, ndof, gpu_ndof, nlv, nsmooth,
-                                                                                             ncoarse, " / cycles per level " + cycles if cycles else "",
-                                                                                             its, t, cores)}
+    t3 = time.perf_counter()
+    t_mf = None
+    if matfree_too:
+        mg.fine_matfree(True)
+        t4 = time.perf_counter()
+        U2, its2, _ = mg.solve(R * N, rtol=rtol)
+        t_mf = (t1 - t0) + (time.perf_counter() - t4) + (t3 - t2)
+        mg.fine_matfree(False)
+    return 3 * nx * ny * nz, its, t3 - t0, t_mf, nlv
+
+
+def cpu_baseline(sample, rtol, fine_eig, gpu_el, gpu_ndof, budget_s, nlv=4, nsmooth=4, ncoarse=30, cycles=""):
+    """the oracle timed on the host cores beside the GPU line -- on the SAME mesh when the budget
+    (--cpu-budget seconds, default 240) allows it, judged from a first run on the bounded sample mesh; both data paths:
+    assembled CSR (the reference's) and matrix-free fine level."""
+    from oracle import oracle as orc
+    cores = int(os.environ.get("OMP_NUM_THREADS", min(os.cpu_count() or 1, 16)))
+    sel = tuple(int(v) for v in sample.split("x"))
+    nd, its, t, t_mf, lv = cpu_step(orc, sel, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, True)
+    est = (t + t_mf) * gpu_ndof / nd  # work per DOF and iteration count are close to mesh independent
+    what = "%dx%dx%d elements (%d DOF -- NOT the GPU line's %d-DOF mesh: the same mesh was estimated at %.0f s, over the --cpu-budget of %.0f s)" % (
+        sel + (nd, gpu_ndof, est, budget_s))
+    same = False
+    if est <= budget_s and tuple(gpu_el) != sel:
+        nd, its, t, t_mf, lv = cpu_step(orc, tuple(gpu_el), rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, True)
+        what = "%dx%dx%d elements (%d DOF: the GPU line's mesh)" % (tuple(gpu_el) + (nd,))
+        same = True
+    return {"value": nd / t, "unit": "DOF-updates/s", "cores": cores, "kind": "port", "same_mesh": same,
+            "sample_n_dof": nd, "gpu_line_n_dof": gpu_ndof,
+            "matrix_free": {"value": nd / t_mf, "unit": "DOF-updates/s", "seconds": t_mf,
+                            "what": "the same step with the fine-level operator of the solve applied from KE and the moduli (OpenMP gather over "
+                                    "the 8 elements of a node) instead of the assembled CSR; Galerkin operators as before"},
+            "sample": "1 step on %s, %d levels, Chebyshev(%d) / coarse Chebyshev(%d)%s as on the GPU line, CG its %d, %.2f s; assembled CSR + "
+                      "Galerkin SpGEMM (the reference's data path), OpenMP on %d threads" % (what, lv, nsmooth, ncoarse,
+                                                                                             " / cycles per level " + cycles if cycles else "", its, t, cores)}
 
 
 def fine_kernel_times(tp, torch, ex, ey, ez, reps):
@@ -198,7 +227,7 @@ def main():
     Emin, Emax, penal, volfrac = 1e-9, 1.0, 3.0, 0.12
     info = {}
 
-    def step():
+    def step(le=le):
         flt.FilterProject(x, xt, xp)                       # main.cc:98
         le.U.zero_()                                       # cold start: every step does the full solve
         fx, gx = le.ComputeObjectiveConstraintsSensitivities(df, dg, xp, Emin, Emax, penal, volfrac)  # main.cc:62
@@ -238,6 +267,25 @@ def main():
         t_m.append(time.perf_counter() - tm0)
     mma_ms = 1e3 * min(t_m)
     del mma
+    # ---- the cycle SURVEY 8(d) / BASELINE.md state for this metric (the reference's counts: 4 levels, 4 smoothing steps,
+    # 30 coarse steps, V-cycles; LinearElasticity.cc:621-635) in the same run, beside the tuned cycle of `value`
+    stated = None
+    if world == 1 and not a.no_stated_cycle and a.workload == "cantilever128":
+        keep = dict(info)
+        le4 = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=4, rtol=a.rtol, fine_eig=a.fine_eig, ncoarse=30, nsmooth=4))
+        le4.SetUpLoadAndBC()
+        step(le4)
+        barrier()
+        ts0 = time.perf_counter()
+        for _ in range(3):
+            step(le4)
+        barrier()
+        stated = {"ms_per_step": 1e3 * (time.perf_counter() - ts0) / 3, "cg_its": le4.last_its, "rel_residual": le4.last_rnorm / le4.last_bnorm,
+                  "value": ndof / ((time.perf_counter() - ts0) / 3),
+                  "cycle": "4 levels, Chebyshev(4)-Jacobi smoothing, coarse Chebyshev(30), V-cycles (the counts of LinearElasticity.cc:621-635)"}
+        del le4
+        info.clear()
+        info.update(keep)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -273,13 +321,21 @@ def main():
     # the library's stream.  In the step the kernel finds its four vectors displaced from the 256 MB Infinity Cache by
     # the kernels in between (128^3: 52 MB per vector), back to back it does not: both are reported, `achieved` is the
     # in-step one (the one a kernel trace of this command shows, profiles/)
-    cheb_in_step_ms, cheb_in_step_n = 0.0, 0
+    cheb_in_step_ms, cheb_in_step_n, cheb_in_step_bytes, cheb_step_share = 0.0, 0, 0.0, None
     if world == 1:
         grid.kernel_timer(True)
+        barrier()
+        tk0 = time.perf_counter()
         for _ in range(2):
             step()
-        cheb_in_step_ms, cheb_in_step_n = grid.kernel_timer_read()
+        barrier()
+        tk = time.perf_counter() - tk0
+        tot_ms, cheb_in_step_n, tot_bytes = grid.kernel_timer_read2()
         grid.kernel_timer(False)
+        if cheb_in_step_n:
+            cheb_in_step_ms = tot_ms / cheb_in_step_n
+            cheb_in_step_bytes = tot_bytes / cheb_in_step_n   # the first step of a sweep reads one vector less
+            cheb_step_share = tot_ms / (1e3 * tk)
     u = le.grid.node_vec(3).normal_()
     y = torch.zeros_like(u)
     ksm = 8
@@ -291,10 +347,12 @@ def main():
     b2b = {"avg_launch_ms": cheb_ms, "achieved": cheb_bytes / (cheb_ms * 1e-3) / 1e9, "frac": cheb_bytes / (cheb_ms * 1e-3) / 1e9 / 8000.0,
            "how": "HIP events around %d back-to-back launches on the same vectors (Infinity Cache warm)" % (ksm * max(a.spmv_reps // 4, 2))}
     how = "back-to-back launches"
+    roof_bytes = cheb_bytes
     if cheb_in_step_n:
         cheb_ms = cheb_in_step_ms
-        how = "HIP event pair around each of the %d launches inside two design iterations" % cheb_in_step_n
-    achieved = cheb_bytes / (cheb_ms * 1e-3) / 1e9
+        roof_bytes = cheb_in_step_bytes
+        how = "HIP event pair around each of the %d launches inside two design iterations; bytes per launch by variant (with / without previous iterate)" % cheb_in_step_n
+    achieved = roof_bytes / (cheb_ms * 1e-3) / 1e9
     # HBM traffic per launch of the plain SpMV from the rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
     # profiles/README.md); only valid for the mesh it was measured on
     traffic = None
@@ -303,15 +361,18 @@ def main():
         rec = json.load(open(tj)).get("%dx%dx%d" % (ex, ey, part.ez_own))
         if rec:
             traffic = rec
-    roofline = {"bound": "hbm", "kernel": "k_fine_tile<EPI_CHEB> (fine-level matrix-free hex8 operator fused with "
-                                          "the Chebyshev-Jacobi update)",
+    gen3 = os.environ.get("TP_FINE_V", "0") in ("3",) or (os.environ.get("TP_FINE_V", "0") == "0" and ((nx + 30) // 31) * ((ny + 6) // 7) >= 160)
+    kname = "k_fine_u4" if gen3 else "k_fine_tile"
+    roofline = {"bound": "hbm", "kernel": "%s<EPI_CHEB> (fine-level matrix-free hex8 operator fused with "
+                                          "the Chebyshev-Jacobi update; the largest kernel of the step: profiles/r03_bench_step_shares.txt)" % kname,
+                "share_of_step": cheb_step_share,
                 "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                 "traffic": (traffic or {}).get("cheb_hbm_bytes_per_launch", None) and traffic["cheb_hbm_bytes_per_launch"] / 1e9,
                 "traffic_unit": "GB per launch (PMC)",
                 "traffic_source": "profiles/spmv_traffic.json (static: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                                   "of tools/pmc_traffic.py on this mesh, not measured in this run)" if traffic else None,
-                "alg_bytes_per_launch": cheb_bytes, "avg_launch_ms": cheb_ms, "avg_launch_how": how, "back_to_back": b2b,
-                "spmv": {"kernel": "k_fine_tile<EPI_APPLY> (plain y = K u)", "alg_bytes_per_launch": spmv_bytes,
+                "alg_bytes_per_launch": roof_bytes, "avg_launch_ms": cheb_ms, "avg_launch_how": how, "back_to_back": b2b,
+                "spmv": {"kernel": "%s<EPI_APPLY> (plain y = K u)" % kname, "alg_bytes_per_launch": spmv_bytes,
                          "avg_launch_ms": spmv_ms, "achieved": spmv_bytes / (spmv_ms * 1e-3) / 1e9,
                          "frac": spmv_bytes / (spmv_ms * 1e-3) / 1e9 / 8000.0,
                          "traffic": (traffic or {}).get("hbm_bytes_per_launch", None) and traffic["hbm_bytes_per_launch"] / 1e9,
@@ -350,12 +411,13 @@ def main():
                    "mma_ms_per_update": mma_ms,
                    "parallelism": "zslab%d" % world, "comm": grid.comm_kind, "halo_overlap": grid.halo_overlap,
                    "scaling_note": "weak: %dx%dx%d elements per GPU" % (ex, ey, ezg) if a.scaling == "weak" else "strong: fixed %dx%dx%d mesh" % (ex, ey, ezg), "kernel_launches_per_step": launches / max(a.steps, 1),
+                   "stated_cycle": stated,
                    "alg_GB_per_step": alg_bytes / max(a.steps, 1) / 1e9,
                    "hot_path_alg_GBps": alg_bytes / dt / 1e9},
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.cpu_sample, a.rtol, a.fine_eig, ndof, nlv, a.nsmooth, a.ncoarse, a.cycles)
+        out["cpu_baseline"] = cpu_baseline(a.cpu_sample, a.rtol, a.fine_eig, (ex, ey, ezg), ndof, a.cpu_budget, nlv, a.nsmooth, a.ncoarse, a.cycles)
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

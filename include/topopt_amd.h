@@ -128,6 +128,8 @@ int tp_grid_comm_stats(const tp_grid *g, long *exchanges, long *reductions);   /
  * the summed elapsed time and the number of launches, and clears the list. */
 int tp_grid_kernel_timer(tp_grid *g, int on);
 int tp_grid_kernel_timer_read(tp_grid *g, double *total_ms, long *launches);
+/* the same plus the algorithmic bytes of exactly the timed launches */
+int tp_grid_kernel_timer_read2(tp_grid *g, double *total_ms, long *launches, double *alg_bytes);
 /* halos that travelled on the second stream, overlapped with the interior planes of their producer (0 if the hooks
  * lack set_stream / exchange_direct, or with TP_OVERLAP=0) */
 long tp_grid_overlapped_halos(const tp_grid *g);

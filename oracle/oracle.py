@@ -39,6 +39,7 @@ def lib():
         L.orc_mg_create.argtypes = [C.c_int] * 7 + [C.c_double] * 2
         L.orc_mg_destroy.argtypes = [C.c_void_p]
         L.orc_mg_set_fine_eig.argtypes = [C.c_void_p, C.c_int]
+        L.orc_mg_fine_matfree.argtypes = [C.c_void_p] * 4
         L.orc_mg_set_cycles.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_mg_assemble.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_mg_precond.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -195,8 +196,17 @@ class MG:
         self.L.orc_mg_set_cycles(self.h, C.addressof(c))
 
     def assemble(self, KE, E=None, N=None):
+        self.L.orc_mg_fine_matfree(None, None, None, None)
         self._keep = (f64(KE), None if E is None else f64(E), None if N is None else f64(N))
         self.L.orc_mg_assemble(self.h, *[_p(a) for a in self._keep])
+
+    def fine_matfree(self, on=True):
+        """CPU baseline variant: apply the fine-level operator of the solve matrix-free (OpenMP gather over the 8
+        elements of a node) instead of the assembled CSR.  Call after assemble(); assemble() switches it off."""
+        if on:
+            self.L.orc_mg_fine_matfree(self.h, *[_p(a) for a in self._keep])
+        else:
+            self.L.orc_mg_fine_matfree(None, None, None, None)
 
     def size(self, l):
         return self.L.orc_mg_level_size(self.h, l)

@@ -356,7 +356,45 @@ static void csr_free(csr_t *A) {
     free(A);
 }
 
+/* CPU baseline variant (bench.py, SURVEY 8d "assembled-CSR and matrix-free variants"): the fine-level operator of the
+ * solve applied from KE and the moduli, one node per loop trip (gather over the 8 adjacent elements: no write
+ * conflicts between threads), instead of the assembled CSR.  Same operator (N K N + I - N), other summation order. */
+static const csr_t *g_mf_A = NULL; /* the matrix the hook stands in for */
+static const double *g_mf_KE, *g_mf_E, *g_mf_N;
+static int g_mf_nx, g_mf_ny, g_mf_nz;
+static void matfree_apply_omp(const double *u, double *y) {
+    const int nx = g_mf_nx, ny = g_mf_ny, nz = g_mf_nz, ex = nx - 1, ey = ny - 1, ez = nz - 1;
+    const double *KE = g_mf_KE, *E = g_mf_E, *N = g_mf_N;
+    static const int LX[8] = {0, 1, 1, 0, 0, 1, 1, 0}, LY[8] = {0, 0, 1, 1, 0, 0, 1, 1}, LZ[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 0; k < nz; k++)
+        for (int j = 0; j < ny; j++)
+            for (int i = 0; i < nx; i++) {
+                const long n = (long)i + (long)nx * (j + (long)ny * k);
+                double acc[3] = {0.0, 0.0, 0.0};
+                for (int a = 0; a < 8; a++) { /* the element in which this node is corner a */
+                    const int ei = i - LX[a], ej = j - LY[a], ek = k - LZ[a];
+                    if (ei < 0 || ei >= ex || ej < 0 || ej >= ey || ek < 0 || ek >= ez) continue;
+                    const double Ee = E ? E[(long)ei + (long)ex * (ej + (long)ey * ek)] : 1.0;
+                    double f[3] = {0.0, 0.0, 0.0};
+                    for (int b = 0; b < 8; b++) {
+                        const long nb = (long)(ei + LX[b]) + (long)nx * ((ej + LY[b]) + (long)ny * (ek + LZ[b]));
+                        for (int c = 0; c < 3; c++) {
+                            const double ub = N ? N[3 * nb + c] * u[3 * nb + c] : u[3 * nb + c];
+                            for (int r = 0; r < 3; r++) f[r] += KE[(3 * a + r) * 24 + 3 * b + c] * ub;
+                        }
+                    }
+                    for (int r = 0; r < 3; r++) acc[r] += Ee * f[r];
+                }
+                for (int r = 0; r < 3; r++) y[3 * n + r] = N ? N[3 * n + r] * acc[r] + (1.0 - N[3 * n + r]) * u[3 * n + r] : acc[r];
+            }
+}
+
 static void csr_spmv(const csr_t *A, const double *x, double *y) {
+    if (A == g_mf_A && A) {
+        matfree_apply_omp(x, y);
+        return;
+    }
 #pragma omp parallel for schedule(static) if (A->nrow > 100000)
     for (long r = 0; r < A->nrow; r++) {
         double s = 0.0;
@@ -774,6 +812,17 @@ ORC_API orc_mg_t *orc_mg_create(int nx, int ny, int nz, int dof, int nlv, int ns
 }
 
 ORC_API void orc_mg_set_fine_eig(orc_mg_t *s, int mode) { s->fine_eig = mode; }
+/* CPU baseline only: from now on the fine-level operator of THIS hierarchy (dof 3) is applied matrix-free from KE, E, N
+ * (caller keeps the arrays alive); NULL KE switches back to the assembled matrix.  One hierarchy at a time. */
+ORC_API void orc_mg_fine_matfree(orc_mg_t *s, const double *KE, const double *E, const double *N) {
+    if (!KE || !s || s->dof != 3) {
+        g_mf_A = NULL;
+        return;
+    }
+    g_mf_A = s->A[0];
+    g_mf_KE = KE, g_mf_E = E, g_mf_N = N;
+    g_mf_nx = s->nx[0], g_mf_ny = s->ny[0], g_mf_nz = s->nz[0];
+}
 /* PCMGSetCycleType / PCMGSetCycleTypeOnLevel: c[l] cycles of level l + 1 per visit of level l (l = 0 finest) */
 ORC_API void orc_mg_set_cycles(orc_mg_t *s, const int *c) {
     for (int l = 0; l + 1 < s->nlv; l++) s->cycles[l] = c[l] < 1 ? 1 : c[l];

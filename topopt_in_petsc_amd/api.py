@@ -120,6 +120,12 @@ class Grid:
         _chk(self.L.tp_grid_kernel_timer_read(self.handle, C.byref(t), C.byref(n)), "tp_grid_kernel_timer_read")
         return (t.value / n.value if n.value else 0.0), n.value
 
+    def kernel_timer_read2(self):
+        """-> (total ms, launches, algorithmic bytes of exactly those launches)"""
+        t, n, b = C.c_double(0.0), C.c_long(0), C.c_double(0.0)
+        _chk(self.L.tp_grid_kernel_timer_read2(self.handle, C.byref(t), C.byref(n), C.byref(b)), "tp_grid_kernel_timer_read2")
+        return t.value, n.value, b.value
+
     def _use_rccl(self, group):
         """Hand the slab exchange to RCCL inside the library (tp_grid_use_rccl): same RCCL instance as
         torch.distributed's nccl backend, no Python round trip per halo.  Every rank takes the same decision."""

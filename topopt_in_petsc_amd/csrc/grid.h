@@ -30,6 +30,7 @@ struct tp_grid {
     // opt-in timer of the roofline kernel IN PLACE (tp_grid_kernel_timer): a HIP event pair around every launch of the
     // fine level's fused Chebyshev step, on the stream it is launched on
     bool kt_on = false;
+    double kt_bytes = 0.0;          // algorithmic bytes of the timed launches (per variant: with / without previous iterate)
     std::vector<hipEvent_t> kt_ev;  // pairs (start, stop)
 };
 inline void kernel_timer_mark(tp_grid *g) {

@@ -649,7 +649,9 @@ struct MGSolver {
         }
         if (EPI == EPI_RESID) bytes += 8.0 * DOF * nown;
         // d (r/w), b, dinv -- the fine tile kernel instead reads b and the previous iterate (3-term form, diagonal on the fly)
-        if (EPI == EPI_CHEB || EPI == EPI_CHEB_DOT) bytes += (three_term(L) ? 2.0 : 4.0) * 8.0 * DOF * nown;
+        // (3-term form: the first step of a sweep -- c1 = 0 or the zero guess -- does not read a previous iterate)
+        if (EPI == EPI_CHEB || EPI == EPI_CHEB_DOT) bytes += (three_term(L) ? ((a.c1 != 0.0 && !a.prev_zero) ? 2.0 : 1.0) : 4.0) * 8.0 * DOF * nown;
+        if (grid->kt_on && l == 0 && (EPI == EPI_CHEB || EPI == EPI_CHEB_DOT) && !split && !sg_capturing) grid->kt_bytes += bytes;
         count_launch(grid, bytes, flops);
         if (split) grid->launches++;
         return TP_OK;

@@ -157,7 +157,17 @@ extern "C" long tp_grid_overlapped_halos(const tp_grid *g) { return g ? g->n_ove
 extern "C" int tp_grid_kernel_timer(tp_grid *g, int on) {
     if (!g) return TP_ERR_ARG;
     g->kt_on = on != 0;
+    if (on) g->kt_bytes = 0.0;
     return TP_OK;
+}
+extern "C" int tp_grid_kernel_timer_read(tp_grid *g, double *total_ms, long *launches);
+// ... and the algorithmic bytes of exactly those launches (the first step of a smoothing sweep reads one vector less)
+extern "C" int tp_grid_kernel_timer_read2(tp_grid *g, double *total_ms, long *launches, double *alg_bytes) {
+    if (!g || !alg_bytes) return TP_ERR_ARG;
+    const double b = g->kt_bytes;
+    const int rc = tp_grid_kernel_timer_read(g, total_ms, launches);
+    if (rc == TP_OK) *alg_bytes = b;
+    return rc;
 }
 extern "C" int tp_grid_kernel_timer_read(tp_grid *g, double *total_ms, long *launches) {
     if (!g || !total_ms || !launches) return TP_ERR_ARG;
@@ -173,6 +183,7 @@ extern "C" int tp_grid_kernel_timer_read(tp_grid *g, double *total_ms, long *lau
     }
     for (hipEvent_t e : g->kt_ev) (void)hipEventDestroy(e);
     g->kt_ev.clear();
+    g->kt_bytes = 0.0;
     *total_ms = t;
     *launches = n;
     return TP_OK;

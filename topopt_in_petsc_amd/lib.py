@@ -62,6 +62,7 @@ SYMBOLS = {
     "tp_grid_comm_stats": (_i, [_vp, C.POINTER(_l), C.POINTER(_l)]),
     "tp_grid_kernel_timer": (_i, [_vp, _i]),
     "tp_grid_kernel_timer_read": (_i, [_vp, C.POINTER(_d), C.POINTER(_l)]),
+    "tp_grid_kernel_timer_read2": (_i, [_vp, C.POINTER(_d), C.POINTER(_l), C.POINTER(_d)]),
     "tp_grid_drop_rccl": (_i, [_vp]),
     "tp_grid_overlapped_halos": (_l, [_vp]),
     "tp_grid_comm_selfcheck": (_i, [_vp, C.POINTER(_i)]),
