@@ -98,15 +98,21 @@ CONFIGS = {
     "C3_256x128x128_one_gpu": (256, 128, 128, 4, 1, "cantilever"),
     "metric_128cubed": (128, 128, 128, 4, 1, "cantilever"),
     "C5_512x256x256_one_gpu": (512, 256, 256, 4, 1, "cantilever"),   # 101.6 M DOF, ~35 GB of the 288 GB
+    # the parameterisation bench.py actually runs (WORKLOADS): depth, step counts, W-cycles on the middle levels
+    "metric_128cubed_bench_cycle": (128, 128, 128, 5, 1, "cantilever", dict(nsmooth=2, ncoarse=20), [1, 2, 2, 1]),
+    "C3_256x128x128_bench_cycle": (256, 128, 128, 7, 1, "cantilever", dict(nsmooth=2, ncoarse=20), [1, 2, 2, 2, 2, 1]),
 }
 
 
 @pytest.mark.parametrize("name", sorted(CONFIGS))
 def test_config_full_size_properties(tp, name):
-    ex, ey, ez, nlv, ftype, bc = CONFIGS[name]
+    ex, ey, ez, nlv, ftype, bc = CONFIGS[name][:6]
+    kw, cycles = (CONFIGS[name][6], CONFIGS[name][7]) if len(CONFIGS[name]) > 6 else ({}, None)
     h = 1.0 / ey
     grid = tp.Grid(ex + 1, ey + 1, ez + 1, h)
-    le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=nlv, rtol=1e-8, max_it=400))
+    le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=nlv, rtol=1e-8, max_it=400, **kw))
+    if cycles:
+        le.set_cycles(cycles)
     popt = tp.SolverOptions(nlvls=3, rtol=1e-10, dtol=1e3, max_it=100, nsmooth=2, ncoarse=10) if ftype == 2 else None
     flt = tp.Filter(grid, ftype, 2.56 * h, popt)
     le.SetUpLoadAndBC_MBB() if bc == "mbb" else le.SetUpLoadAndBC()

@@ -8,7 +8,7 @@ import json
 import sys
 
 root, ex, ey, ez = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-KEYS = {"spmv": "k_fine_tile<0>", "cheb": "k_fine_tile<2>", "calib": "k_scale"}
+KEYS = {"spmv": ("k_fine_tile<0>", "k_fine_u4<0,"), "cheb": ("k_fine_tile<2>", "k_fine_u4<2,"), "calib": ("k_scale",)}  # second and third generation
 
 
 def mean_counter(name):
@@ -18,7 +18,7 @@ def mean_counter(name):
             if r["Counter_Name"] != name:
                 continue
             for k, pat in KEYS.items():
-                if pat in r["Kernel_Name"]:
+                if any(q in r["Kernel_Name"] for q in pat):
                     out[k].append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v) if v else None) for k, v in out.items()}, {k: len(v) for k, v in out.items()}
 
