@@ -64,6 +64,7 @@ def parse():
     p.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                    help="weak: the workload mesh per GPU (default); strong: the workload mesh split over the GPUs")
     p.add_argument("--no-cube256", action="store_true", help="skip the 256^3 fine-kernel roofline entry")
+    p.add_argument("--no-other-scaling", action="store_true", help="N > 1: do not also time the complementary scaling case (strong beside weak)")
     return p.parse_args()
 
 
@@ -316,6 +317,51 @@ def main():
         torch.cuda.synchronize()
         return ev0.elapsed_time(ev1) / reps
 
+    # ---- N > 1: the OTHER reading of BASELINE's metric in the same run.  `value` is the --scaling of the command line
+    # (weak by default: the workload mesh per GPU); this sub-object times the complementary case -- by default the
+    # metric's own fixed mesh split over the N GPUs (strong) -- with the same cycle, steps and barriers.
+    other = None
+    if world > 1 and not a.no_other_scaling:
+        o_scal = "strong" if a.scaling == "weak" else "weak"
+        ok = not (o_scal == "strong" and (ezg % world or (ezg // world) % (1 << (nlv - 1))))
+        if ok:
+            ez2 = ezg if o_scal == "strong" else ezg * world
+            grid2 = tp.Grid(nx, ny, ez2 + 1, h, rank=rank, nranks=world)
+            le2 = tp.LinearElasticity(grid2, tp.SolverOptions(nlvls=nlv, rtol=a.rtol, fine_eig=a.fine_eig, ncoarse=a.ncoarse, nsmooth=a.nsmooth))
+            if a.cycles:
+                le2.set_cycles([int(v) for v in a.cycles.split(",")])
+            flt2 = tp.Filter(grid2, ftype, 2.56 * h)
+            le2.SetUpLoadAndBC_MBB() if bc == "mbb" else le2.SetUpLoadAndBC()
+            x2 = grid2.synth_density(12345)
+            xt2, xp2, df2, dg2 = grid2.elem_vec(), grid2.elem_vec(), grid2.elem_vec(), grid2.elem_vec()
+
+            def step2():
+                flt2.FilterProject(x2, xt2, xp2)
+                le2.U.zero_()
+                fx2, _ = le2.ComputeObjectiveConstraintsSensitivities(df2, dg2, xp2, Emin, Emax, penal, volfrac)
+                df2.mul_(10.0 / fx2)
+                flt2.Gradients(x2, xt2, df2, [dg2])
+
+            for _ in range(a.warmup):
+                step2()
+            barrier()
+            t2 = time.perf_counter()
+            for _ in range(a.steps):
+                step2()
+            barrier()
+            dt2 = time.perf_counter() - t2
+            if world > 1:
+                tt2 = torch.tensor([dt2], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tt2, op=dist.ReduceOp.MAX)
+                dt2 = float(tt2[0])
+            ndof2 = 3 * nx * ny * (ez2 + 1)
+            other = {"scaling": o_scal, "value": ndof2 / (dt2 / a.steps), "unit": "DOF-updates/s", "ms_per_step": 1e3 * dt2 / a.steps,
+                     "n_dof": ndof2, "mesh": "%dx%dx%d elements over %d GPUs" % (ex, ey, ez2, world), "cg_its": le2.last_its,
+                     "rel_residual": le2.last_rnorm / le2.last_bnorm, "halo_overlap": grid2.halo_overlap, "comm": grid2.comm_kind}
+            del le2, flt2, grid2
+        else:
+            other = {"scaling": o_scal, "skipped": "%d element layers do not split into %d slabs of whole coarse layers of a %d-level hierarchy" % (ezg, world, nlv)}
+
     # ---- the roofline kernel where it runs: two more steps (outside the timed region, so that the 126 event pairs per
     # step do not touch `value`) with a HIP event pair around every launch of the fine level's fused Chebyshev step, on
     # the library's stream.  In the step the kernel finds its four vectors displaced from the 256 MB Infinity Cache by
@@ -416,6 +462,8 @@ def main():
                    "hot_path_alg_GBps": alg_bytes / dt / 1e9},
         "roofline": roofline,
     }
+    if other is not None:
+        out["other_scaling"] = other
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.cpu_sample, a.rtol, a.fine_eig, (ex, ey, ezg), ndof, a.cpu_budget, nlv, a.nsmooth, a.ncoarse, a.cycles)
     if rank == 0:

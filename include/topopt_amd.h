@@ -122,6 +122,9 @@ int tp_grid_elem_z0(const tp_grid *g);          /* global z index of local eleme
 int tp_rccl_load(const char *librccl_path);
 int tp_rccl_unique_id(void *id128);
 int tp_grid_use_rccl(tp_grid *g, const void *id128);
+/* the same with a second unique id: the neighbour exchanges (halo stream) get a communicator of their own, so that RCCL
+ * does not order them behind the all-reduces of the solver's stream (one communicator = one queue) */
+int tp_grid_use_rccl2(tp_grid *g, const void *id128, const void *id128_halo);
 int tp_grid_comm_stats(const tp_grid *g, long *exchanges, long *reductions);   /* RCCL path only, else zeros */
 /* The roofline kernel timed where it runs (bench.py): with on = 1 every launch of the fine level's fused operator +
  * Chebyshev step is bracketed by a pair of HIP events on the grid's stream; the read waits for the stream, returns

@@ -55,6 +55,10 @@ def test_bench_spawns_its_own_ranks(scaling):
     ez = 32 if scaling == "weak" else 16
     assert "32x16x%d elements" % ez in d["config"]["workload"]
     assert "cpu_baseline" not in d          # rank 0 of a 1-GPU job only
+    # the complementary reading of the metric is timed in the same run
+    o = d["other_scaling"]
+    assert o["scaling"] == ("strong" if scaling == "weak" else "weak") and o["value"] > 0 and o["cg_its"] > 0
+    assert "32x16x%d elements" % (16 if scaling == "weak" else 32) in o["mesh"]
 
 
 def test_bench_workloads_are_consistent():

@@ -132,18 +132,21 @@ class Grid:
         import torch.distributed as dist
         path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         ok = os.path.exists(path) and self.L.tp_rccl_load(path.encode()) == 0
-        idbuf = C.create_string_buffer(128)
-        if ok and self.part.rank == 0:
-            ok = self.L.tp_rccl_unique_id(idbuf) == 0
+        idbuf, idbuf2 = C.create_string_buffer(128), C.create_string_buffer(128)
+        if ok and self.part.rank == 0:   # two ids: collectives and neighbour exchanges on communicators of their own
+            ok = self.L.tp_rccl_unique_id(idbuf) == 0 and self.L.tp_rccl_unique_id(idbuf2) == 0
         flag = torch.tensor([1 if ok else 0], device=self.device, dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
         if int(flag[0]) == 0:
             return
-        obj = [idbuf.raw if self.part.rank == 0 else None]
+        obj = [idbuf.raw + idbuf2.raw if self.part.rank == 0 else None]
         src = 0 if group is None else dist.get_global_rank(group, 0)
         dist.broadcast_object_list(obj, src=src, group=group)
-        idb = C.create_string_buffer(obj[0], 128)
-        rc = self.L.tp_grid_use_rccl(self.handle, idb)
+        idb, idb2 = C.create_string_buffer(obj[0][:128], 128), C.create_string_buffer(obj[0][128:], 128)
+        if os.environ.get("TP_RCCL_ONE_COMM"):
+            rc = self.L.tp_grid_use_rccl(self.handle, idb)
+        else:
+            rc = self.L.tp_grid_use_rccl2(self.handle, idb, idb2)
         flag = torch.tensor([1 if rc == 0 else 0], device=self.device, dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
         if int(flag[0]) == 0:   # some rank could not create its communicator: every rank goes back to the hooks

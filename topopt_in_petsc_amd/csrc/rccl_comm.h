@@ -30,7 +30,12 @@ inline RcclApi &rccl_api() {
 }
 
 struct RcclComm {
-    ncclComm_t comm = nullptr;
+    ncclComm_t comm = nullptr;          // collectives (all-reduce, all-gather) of the solver's stream
+    // Neighbour exchanges get a communicator of their own: RCCL orders the operations of ONE communicator, so a halo
+    // in flight on the second stream and an all-reduce issued on the solver's stream would run one behind the other
+    // and the overlap of the halo with the interior planes (grid.h) would not survive contact with hardware.
+    // Null (tp_grid_use_rccl with one id): both kinds share `comm` as in round 2.
+    ncclComm_t comm_halo = nullptr;
     hipStream_t stream = nullptr;       // stream the operations are issued on (set_stream hook)
     hipStream_t home_stream = nullptr;  // the grid's stream
     int rank = 0, nranks = 1;
@@ -53,11 +58,12 @@ static int rccl_pairs(RcclComm *c, const double *to_lo, double *from_lo, const d
     RcclApi &A = rccl_api();
     const int lo = c->periodic ? c->rank : c->rank - 1, hi = c->periodic ? c->rank : c->rank + 1;
     const bool has_lo = c->periodic || lo >= 0, has_hi = c->periodic || hi < c->nranks;
+    ncclComm_t cm = c->comm_halo ? c->comm_halo : c->comm;
     TP_NCCL(A.GroupStart());
-    if (has_hi && to_hi) TP_NCCL(A.Send(to_hi, (size_t)n, ncclDouble, hi, c->comm, c->stream));
-    if (has_lo && from_lo) TP_NCCL(A.Recv(from_lo, (size_t)n, ncclDouble, lo, c->comm, c->stream));
-    if (has_lo && to_lo) TP_NCCL(A.Send(to_lo, (size_t)n, ncclDouble, lo, c->comm, c->stream));
-    if (has_hi && from_hi) TP_NCCL(A.Recv(from_hi, (size_t)n, ncclDouble, hi, c->comm, c->stream));
+    if (has_hi && to_hi) TP_NCCL(A.Send(to_hi, (size_t)n, ncclDouble, hi, cm, c->stream));
+    if (has_lo && from_lo) TP_NCCL(A.Recv(from_lo, (size_t)n, ncclDouble, lo, cm, c->stream));
+    if (has_lo && to_lo) TP_NCCL(A.Send(to_lo, (size_t)n, ncclDouble, lo, cm, c->stream));
+    if (has_hi && from_hi) TP_NCCL(A.Recv(from_hi, (size_t)n, ncclDouble, hi, cm, c->stream));
     TP_NCCL(A.GroupEnd());
     c->n_exchanges++;
     return 0;
@@ -124,8 +130,9 @@ inline int rccl_load(const char *path) {
 }
 
 // collective over the ranks that hold the same unique id; cap = doubles per staging buffer
+// id128_halo (may be null): a second unique id for the communicator of the neighbour exchanges
 inline int rccl_comm_create(RcclComm **out, const void *id128, int rank, int nranks, int device, hipStream_t stream,
-                            long cap) {
+                            long cap, const void *id128_halo = nullptr) {
     RcclApi &A = rccl_api();
     if (!A.handle || !out || !id128 || cap < 16) return TP_ERR_ARG;
     TP_HIP(hipSetDevice(device));
@@ -139,8 +146,18 @@ inline int rccl_comm_create(RcclComm **out, const void *id128, int rank, int nra
         delete c;
         return TP_ERR_COMM;
     }
+    if (id128_halo) {
+        ncclUniqueId id2;
+        memcpy(&id2, id128_halo, sizeof(id2));
+        if (A.CommInitRank(&c->comm_halo, nranks, id2, rank) != ncclSuccess) {
+            A.CommDestroy(c->comm);
+            delete c;
+            return TP_ERR_COMM;
+        }
+    }
     const size_t total = (size_t)cap * (4 + (size_t)nranks) + 16;
     if (hipMalloc((void **)&c->buf, sizeof(double) * total) != hipSuccess) {
+        if (c->comm_halo) A.CommDestroy(c->comm_halo);
         A.CommDestroy(c->comm);
         delete c;
         return TP_ERR_HIP + (int)hipErrorOutOfMemory;
@@ -167,6 +184,7 @@ inline int rccl_comm_create(RcclComm **out, const void *id128, int rank, int nra
 inline void rccl_comm_destroy(RcclComm *c) {
     if (!c) return;
     (void)hipStreamSynchronize(c->home_stream);
+    if (c->comm_halo) rccl_api().CommDestroy(c->comm_halo);
     if (c->comm) rccl_api().CommDestroy(c->comm);
     (void)hipFree(c->buf);
     delete c;

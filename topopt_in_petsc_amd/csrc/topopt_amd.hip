@@ -64,16 +64,17 @@ extern "C" int tp_rccl_unique_id(void *id128) {
     memcpy(id128, &id, sizeof(id));
     return TP_OK;
 }
-extern "C" int tp_grid_use_rccl(tp_grid *g, const void *id128) {
+extern "C" int tp_grid_use_rccl2(tp_grid *g, const void *id128, const void *id128_halo) {
     if (!g || !id128 || !g->has_comm || g->rccl) return TP_ERR_ARG;
     if (!rccl_api().handle) return TP_ERR_STATE;
     RcclComm *c = nullptr;
-    const int rc = rccl_comm_create(&c, id128, g->rank, g->nranks, g->o.device, g->stream, g->comm.cap);
+    const int rc = rccl_comm_create(&c, id128, g->rank, g->nranks, g->o.device, g->stream, g->comm.cap, id128_halo);
     if (rc) return rc;
     g->rccl = c;
     g->comm = c->hooks;
     return TP_OK;
 }
+extern "C" int tp_grid_use_rccl(tp_grid *g, const void *id128) { return tp_grid_use_rccl2(g, id128, nullptr); }
 extern "C" int tp_grid_drop_rccl(tp_grid *g) {
     if (!g) return TP_ERR_ARG;
     if (g->rccl) {
@@ -199,11 +200,11 @@ __global__ void k_selftest_fill(double *p, long n, double base) {
 }
 extern "C" int tp_rccl_selftest(int device, void *stream, long n, double *max_err) {
     if (!rccl_api().handle || n < 1 || !max_err) return TP_ERR_STATE;
-    ncclUniqueId id;
-    if (rccl_api().GetUniqueId(&id) != ncclSuccess) return TP_ERR_COMM;
+    ncclUniqueId id, id2;
+    if (rccl_api().GetUniqueId(&id) != ncclSuccess || rccl_api().GetUniqueId(&id2) != ncclSuccess) return TP_ERR_COMM;
     RcclComm *c = nullptr;
     hipStream_t st = (hipStream_t)stream;
-    int rc = rccl_comm_create(&c, &id, 0, 1, device, st, n < 16 ? 16 : n);
+    int rc = rccl_comm_create(&c, &id, 0, 1, device, st, n < 16 ? 16 : n, &id2);  // exchanges on their own communicator
     if (rc) return rc;
     c->periodic = true;
     tp_comm &h = c->hooks;
