@@ -27,8 +27,9 @@
  *    with real PETSc, the options database overrides it (KSPSetFromOptions; level KSPs at set-up):
  *      -ksp_type cg -mg_levels_ksp_type chebyshev -mg_levels_pc_type jacobi
  *      -mg_coarse_ksp_type chebyshev -mg_coarse_pc_type jacobi
- *    (argv of PetscInitialize, $PETSC_OPTIONS, or PetscOptionsSetValue).  Without them KSPSolve fails with
- *    PETSC_ERR_SUP and says so -- no silent substitution of the algorithm.
+ *    (argv of PetscInitialize, $PETSC_OPTIONS, or PetscOptionsSetValue).  Without them the hard-coded configuration
+ *    itself is run (tp_solver_opts::ksp_mode = 1, csrc/refksp.h: FGMRES + PCMG with GMRES/SOR level solvers, one
+ *    device) -- never a silent substitution of the algorithm.
  */
 #ifndef TOPOPT_PETSC_COMPAT_H
 #define TOPOPT_PETSC_COMPAT_H
