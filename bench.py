@@ -37,6 +37,8 @@ WORKLOADS = {
     "c3": dict(el=(256, 128, 128), nlvls=7, nsmooth=2, ncoarse=20, cycles="1,2,2,2,2,1"),  # configs[2] on ONE GPU (12.8 M DOF); with --gpus 8: 256x128x(128*8)
     "c4": dict(el=(192, 64, 64), nlvls=6, nsmooth=2, ncoarse=45, ftype=2, bc="mbb"),  # configs[3]: MBB beam, Helmholtz (PDE) filter
     "c5": dict(el=(512, 256, 256), nlvls=4, nsmooth=2, ncoarse=60),             # configs[4] ("4-level GMG") on ONE GPU (101.7 M DOF, ~35 GB of the 288 GB); with --gpus 8 --scaling strong: its slabs
+    # configs[1] with the reference's own absolute filter radius (TopOpt.cc:121 rmin = 0.08: ElemConn 5, 1331-tap cone)
+    "c2_rmin008": dict(el=(128, 64, 64), nlvls=3, nsmooth=2, ncoarse=45, rmin=0.08),
     "tiny": dict(el=(32, 16, 16), nlvls=3, nsmooth=2, ncoarse=30),
 }
 
@@ -221,7 +223,8 @@ def main():
     le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=nlv, rtol=a.rtol, fine_eig=a.fine_eig, ncoarse=a.ncoarse, nsmooth=a.nsmooth))
     if a.cycles:
         le.set_cycles([int(v) for v in a.cycles.split(",")])
-    flt = tp.Filter(grid, ftype, 2.56 * h)
+    rmin = W.get("rmin", 2.56 * h)
+    flt = tp.Filter(grid, ftype, rmin)
     le.SetUpLoadAndBC_MBB() if bc == "mbb" else le.SetUpLoadAndBC()
     x = grid.synth_density(12345)
     xt, xp, df, dg = grid.elem_vec(), grid.elem_vec(), grid.elem_vec(), grid.elem_vec()
@@ -443,10 +446,10 @@ def main():
         "value": ndof / t_step, "unit": "DOF-updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": t_step * 1e3, "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "%s: %s %dx%dx%d elements (%d DOF), z-slabs over %d GPU(s), rmin=2.56h %s "
+        "config": {"workload": "%s: %s %dx%dx%d elements (%d DOF), z-slabs over %d GPU(s), rmin=%s %s "
                                "filter, CG + %d-level GMG (Chebyshev(%d)-Jacobi, coarse Chebyshev(%d), Galerkin%s), rtol %g, fine-level eig %s, cold start, "
                                "filtered synthetic density seed 12345" % (a.workload, "MBB beam" if bc == "mbb" else "cantilever", ex, ey, ez, ndof, world,
-                                                                         "Helmholtz (PDE)" if ftype == 2 else "density", nlv, a.nsmooth, a.ncoarse,
+                                                                         ("%g (ElemConn %d)" % (rmin, flt.ElemConn)) if "rmin" in W else "2.56h", "Helmholtz (PDE)" if ftype == 2 else "density", nlv, a.nsmooth, a.ncoarse,
                                                                          ", cycles per level %s" % a.cycles if a.cycles else "", a.rtol,
                                                                          "Lanczos(10)" if a.fine_eig else "element bound"),
                    "n_dof": ndof, "cg_its": info.get("its"), "rel_residual": info.get("rel_res"), "fx": info.get("fx"),

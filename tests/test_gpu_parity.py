@@ -204,6 +204,85 @@ def test_objective_and_sensitivities(tp, orc):
     assert rel(host(df), dfo2) <= 1e-9
 
 
+@pytest.mark.parametrize("rfac", [4.3, 5.12, 6.5, 7.2, 8.9])
+def test_conv_filter_wide_radius(tp, orc, rfac):
+    """ElemConn 4 .. 8 (k_conv_filter_wide: the reference's default rmin = 0.08 gives 5 on 128x64x64, TopOpt.cc:121,
+    Filter.cc:326-327) against the oracle's explicit H, filter types 1 and 0, forward and gradients."""
+    ex, ey, ez = 26, 20, 18
+    h = 1.0 / ey
+    grid = tp.Grid(ex + 1, ey + 1, ez + 1, h)
+    of = orc.Filter(ex + 1, ey + 1, ez + 1, h, rfac * h)
+    rng = np.random.default_rng(5)
+    x = rng.random(ex * ey * ez) * 0.9 + 0.05
+    df0 = rng.standard_normal(x.size)
+    dg0 = np.full(x.size, 1.0 / x.size)
+    for ftype in (1, 0):
+        f = tp.Filter(grid, ftype, rfac * h)
+        assert f.ElemConn == of.conn == int(np.ceil(rfac)) - 1
+        assert rel(host(f.Hs()), of.hs()) <= 1e-14
+        xt, xp = grid.elem_vec(), grid.elem_vec()
+        f.FilterProject(dev(x), xt, xp)
+        xto, xpo = of.project(ftype, x)
+        assert rel(host(xt), xto) <= 1e-14
+        df, dg = dev(df0), dev(dg0)
+        f.Gradients(dev(x), xt, df, [dg])
+        assert rel(host(df), of.gradient(ftype, x, xto, df0)) <= 1e-13
+        dgo = of.gradient(ftype, x, xto, dg0) if ftype == 1 else dg0
+        assert rel(host(dg), dgo) <= 1e-13
+
+
+def test_conv_filter_default_radius_64x32x32(tp, orc):
+    """the reference's absolute default rmin = 0.08 (TopOpt.cc:121) on 64x32x32: ElemConn 2, against the oracle's H"""
+    ex, ey, ez = 64, 32, 32
+    h = 1.0 / ey
+    grid = tp.Grid(ex + 1, ey + 1, ez + 1, h)
+    of = orc.Filter(ex + 1, ey + 1, ez + 1, h, 0.08)
+    f = tp.Filter(grid, 1, 0.08)
+    assert f.ElemConn == of.conn == 2
+    x = orc.synth_density(ex, ey, ez, h)
+    xt, xp = grid.elem_vec(), grid.elem_vec()
+    f.FilterProject(dev(x), xt, xp)
+    xto, _ = of.project(1, x)
+    assert rel(host(xt), xto) <= 1e-14
+    df0 = np.cos(np.arange(x.size) * 0.37)
+    df = dev(df0)
+    f.Gradients(dev(x), xt, df, [])
+    assert rel(host(df), of.gradient(1, x, xto, df0)) <= 1e-13
+
+
+def test_conv_filter_default_radius_c2_bits(tmp_path):
+    """rmin = 0.08 on 128x64x64 (ElemConn 5, 1331 taps): the LDS-tiled kernel and the direct stencil loop give the same
+    bits (the direct form is selected with TP_NO_FILTER_TILE=1; the environment is read once per process)."""
+    import subprocess, sys
+    worker = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import topopt_in_petsc_amd as tp\n"
+        "tp.load_library()\n"
+        "grid = tp.Grid(129, 65, 65, 1.0 / 64)\n"
+        "f = tp.Filter(grid, 1, 0.08)\n"
+        "assert f.ElemConn == 5\n"
+        "x = grid.synth_density(12345)\n"
+        "xt, xp = grid.elem_vec(), grid.elem_vec()\n"
+        "f.FilterProject(x, xt, xp)\n"
+        "df = torch.sin(torch.arange(x.numel(), dtype=torch.float64, device='cuda'))\n"
+        "f.Gradients(x, xt, df, [])\n"
+        "np.savez(sys.argv[1], xt=xt.cpu().numpy(), df=df.cpu().numpy(), hs=f.Hs().cpu().numpy())\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env in (("tiled", {}), ("direct", {"TP_NO_FILTER_TILE": "1"})):
+        e = dict(os.environ)
+        e.pop("TP_NO_FILTER_TILE", None)
+        e.update(env)
+        out = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", worker, out], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = np.load(out)
+    for k in ("xt", "df", "hs"):
+        assert np.array_equal(res["tiled"][k].view(np.int64), res["direct"][k].view(np.int64)), k
+    assert np.abs(res["tiled"]["xt"]).max() > 0
+
+
 @pytest.mark.parametrize("rfac", [1.5, 2.56, 3.2])
 def test_conv_filter(tp, orc, rfac):
     ex, ey, ez = 12, 8, 8

@@ -1336,6 +1336,12 @@ struct MGSolver {
         }
         head_for = nullptr;
         TP_TRY(drain_halos());
+        if (rc == TP_ERR_DIVERGED && run_cnt) {
+            // a multi-workgroup coarse run that gave up leaves its give-up flag set and fewer arrivals than run_base
+            // assumes: every later run would time out as well.  Start the counters over.
+            TP_HIP(hipMemsetAsync(run_cnt, 0, 2 * sizeof(unsigned long long), s));
+            run_base = 0;
+        }
         if (its_out) *its_out = its;
         if (rnorm_out) *rnorm_out = rnorm;
         return rc;
