@@ -237,14 +237,15 @@ def test_graphed_coarsest_smoothing_bits(tp):
 def test_coarsest_run_in_one_launch_bits(tp, mesh, nl, single):
     """csrc/coarse_run.h: the Chebyshev steps of the coarsest level as iterations inside ONE kernel.  Coarsest grids of
     <= 448 rows (7 x 4 x 4, 5^3, 3^3 nodes here) run in ONE workgroup with the iterate in LDS -- the default; larger ones
-    (9 x 5 x 5, 13 x 7 x 7 nodes: 1 and 4 rows per thread) across workgroups with a barrier per step, opt-in
-    (TP_COARSE_RUN=1).  Either way: the same bits as the separate launches (TP_NO_COARSE_RUN=1), fewer launches."""
+    (9 x 5 x 5, 13 x 7 x 7 nodes) across workgroups with a barrier per step: by default (round 3) workgroups that have
+    gathered on ONE XCD and exchange the iterate through its L2, opt-in (TP_COARSE_RUN=1) workgroups anywhere.  Either way:
+    the same bits as the separate launches (TP_NO_COARSE_RUN=1), fewer launches."""
     ex, ey, ez = mesh
     g = tp.Grid(ex + 1, ey + 1, ez + 1, 1.0 / ey)
     le = tp.LinearElasticity(g, tp.SolverOptions(nlvls=nl, nsmooth=2, ncoarse=45))
     le.SetUpLoadAndBC()
     res = {}
-    for mode, env in (("launches", {"TP_NO_COARSE_RUN": "1"}), ("default", {}), ("run", {"TP_COARSE_RUN": "1"})):
+    for mode, env in (("launches", {"TP_NO_COARSE_RUN": "1"}), ("default", {}), ("run", {"TP_COARSE_RUN": "1"}), ("no_xcd", {"TP_NO_COARSE_XCD": "1"})):
         os.environ.update(env)
         try:
             le.AssembleStiffnessMatrix(g.synth_density(3), 1e-9, 1.0, 3.0)
@@ -255,7 +256,8 @@ def test_coarsest_run_in_one_launch_bits(tp, mesh, nl, single):
         finally:
             for k in env:
                 os.environ.pop(k, None)
-    for mode in ("default", "run"):
+    for mode in ("default", "run", "no_xcd"):
         assert np.array_equal(res["launches"][0], res[mode][0]) and res["launches"][1] == res[mode][1] > 4, mode
     assert res["run"][2] < 0.6 * res["launches"][2], (res["run"][2], res["launches"][2])
-    assert (res["default"][2] < 0.6 * res["launches"][2]) == single, (res["default"][2], res["launches"][2])
+    assert res["default"][2] < 0.6 * res["launches"][2], (res["default"][2], res["launches"][2])
+    assert (res["no_xcd"][2] < 0.6 * res["launches"][2]) == single, (res["no_xcd"][2], res["launches"][2])

@@ -169,3 +169,186 @@ __global__ __launch_bounds__(RUN_WG) void k_dia_cheb_run(DiaOp<DOF> op, const do
     if (SINGLE && fin) xa[qf] = xo;  // the result goes back to where the start came from
     if (dead && fin) xa[qf] = xb[qf] = __builtin_nan("");
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same run with all its workgroups on ONE XCD (round 3).  The step above is slow because the XCDs' L2 slices are not
+// coherent: the iterate goes out with write-through stores and comes back past the L2 (2.6-3.6 us per step, the price of
+// a launch).  Inside one XCD the L2 IS the common memory: plain stores land there, L1-bypassing loads (sc1) and the
+// arrival counter are served from there -- tools/probe/xcd_probe.hip: 1.7-1.9 us per step for 8-32 workgroups that
+// exchange the whole iterate, against 3.2-3.6 us for workgroups anywhere and 3.0 us per launch.
+// Placement is not something HIP promises, so it is established at run time: 8 x P workgroups are launched, each reads
+// the id of the XCD it runs on (HW_REG_XCC_ID) and takes a ticket on that XCD's join counter; the first XCD to hand out
+// P tickets wins (8 P workgroups on 8 XCDs: at least one does), its first P ticket holders are ranks 0 .. P-1 of the
+// run, everybody else leaves at once.  Which rows a workgroup serves depends on its ticket, the arithmetic of a row
+// does not: same bits as the launches.  The control block is left zeroed by the last workgroup of the 8 P to finish.
+// Give-up: a workgroup that waits ~1 s (join or barrier) raises the flag, the run poisons its result with NaN and the
+// Krylov loop reports divergence (the host then resets the block); TP_NO_COARSE_XCD=1 switches the path off.
+struct XcdRunCtrl {
+    unsigned long long join[8][16];  // one cache line each
+    unsigned long long winner[16];   // 0: none yet, else 1 + XCC id
+    unsigned long long cnt[16];      // barrier arrivals of this run
+    unsigned long long finished[16]; // workgroups of the launch that have left
+    unsigned long long gaveup[16];   // sticky until the host clears it
+};
+
+__device__ inline unsigned run_xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 7u;
+}
+
+template <int DOF, int R>
+__global__ __launch_bounds__(RUN_WG) void k_dia_cheb_run_xcd(DiaOp<DOF> op, const double *__restrict__ b, const double *__restrict__ dinv,
+                                                             const double *__restrict__ d0, double *xa, double *xb, ChebRunCoef cr,
+                                                             XcdRunCtrl *ctl, int P) {
+    __shared__ double s_part[9][RUN_RPB * R];
+    __shared__ double xs[RUN_XS];
+    __shared__ int s_dead, s_rank;
+    // ---- who takes part
+    if (threadIdx.x == 0) {
+        const unsigned xcc = run_xcc_id();
+        int rank = -1;
+        const unsigned long long tk = __hip_atomic_fetch_add(&ctl->join[xcc][0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tk < (unsigned long long)P) {
+            if (tk == (unsigned long long)(P - 1)) {
+                unsigned long long expect = 0ull;
+                __hip_atomic_compare_exchange_strong(&ctl->winner[0], &expect, 1ull + xcc, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            unsigned long long w;
+            long spins = 0;
+            while ((w = __hip_atomic_load(&ctl->winner[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0ull) {
+                if (++spins > 2000000L || ((spins & 1023) == 0 && __hip_atomic_load(&ctl->gaveup[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    __hip_atomic_store(&ctl->gaveup[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            rank = (w == 1ull + xcc) ? (int)tk : -1;
+        }
+        s_rank = rank;
+    }
+    __syncthreads();
+    const int rank = s_rank;
+    auto leave = [&]() {  // the last of the 8 P workgroups to leave hands the control block back zeroed
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long f = __hip_atomic_fetch_add(&ctl->finished[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (f + 1 == (unsigned long long)gridDim.x) {
+                for (int x = 0; x < 8; x++) __hip_atomic_store(&ctl->join[x][0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&ctl->winner[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&ctl->cnt[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&ctl->finished[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+    if (rank < 0) {
+        leave();
+        return;
+    }
+    const Geom &g = op.g;
+    const long plane = g.plane();
+    const long nown = g.owned_nodes() * DOF;
+    const long off = plane * g.own_lo * DOF;
+    const int part = threadIdx.x / RUN_RPB, r = threadIdx.x % RUN_RPB;
+    const bool lane_ok = part < 9;
+    const long t_lo = (long)rank * R * RUN_RPB, t_hi = min(t_lo + (long)R * RUN_RPB, nown) - 1;
+    const long reach = plane + g.nx + 1;
+    const long n_first = max((t_lo + off) / DOF - reach, 0L);
+    const long n_last = min((t_hi + off) / DOF + reach, g.nodes() - 1);
+    const int stage_n = (int)((n_last - n_first + 1) * DOF);
+    double coef[R][3 * DOF];
+    int nbi[R][3];
+    bool valid[R];
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+        const long t = t_lo + (long)m * RUN_RPB + r;
+        valid[m] = lane_ok && t < nown;
+        const long q = (valid[m] ? t : 0) + off;
+        const long n = q / DOF;
+        const int k = (int)(n / plane);
+        const int rem = (int)(n % plane);
+        const int j = rem / g.nx, i = rem % g.nx;
+        const int dk = part / 3 - 1, dj = part % 3 - 1;
+        const bool okj = k + dk >= 0 && k + dk < g.nzl && j + dj >= 0 && j + dj < g.ny;
+#pragma unroll
+        for (int di = -1; di <= 1; di++) {
+            const bool ok = okj && i + di >= 0 && i + di < g.nx;
+            const int blk = ((lane_ok ? dk : 0) + 1) * 9 + ((lane_ok ? dj : 0) + 1) * 3 + (di + 1);
+            const long nb = ok ? n + di + (long)g.nx * (dj + (long)g.ny * dk) : n;
+            nbi[m][di + 1] = valid[m] ? (int)((nb - n_first) * DOF) : 0;
+#pragma unroll
+            for (int c = 0; c < DOF; c++) coef[m][(di + 1) * DOF + c] = valid[m] ? op.S[(long)(blk * DOF + c) * op.nrows + q] : 0.0;
+        }
+    }
+    const int f = threadIdx.x;
+    const bool fin = f < R * RUN_RPB && t_lo + f < nown;
+    const long qf = (fin ? t_lo + f : 0) + off;
+    const double e_b = fin ? b[qf] : 0.0, e_di = fin ? dinv[qf] : 0.0;
+    double dcur = fin ? d0[qf] : 0.0, xo = fin ? xa[qf] : 0.0;
+    const double *xin = xa;
+    double *xout = xb;
+    bool dead = false;
+    for (int s = 0; s < cr.nsteps; s++) {
+        {   // this step's input: the stretch of the iterate my rows couple to, past the L1 (served by the XCD's L2)
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(xin) + n_first * DOF, 0, stage_n * 8, 0x00020000);
+            constexpr int NST = RUN_XS / RUN_WG;
+            double tmp[NST];
+#pragma unroll
+            for (int q = 0; q < NST; q++)
+                tmp[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, (threadIdx.x + q * RUN_WG) * 8, 0, 16 /* sc1 */));
+#pragma unroll
+            for (int q = 0; q < NST; q++)
+                if (threadIdx.x + q * RUN_WG < stage_n) xs[threadIdx.x + q * RUN_WG] = tmp[q];
+            __syncthreads();
+        }
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+            double y = 0.0;
+            if (valid[m]) {
+#pragma unroll
+                for (int d3 = 0; d3 < 3; d3++)
+#pragma unroll
+                    for (int c = 0; c < DOF; c++) y = fma(coef[m][d3 * DOF + c], xs[nbi[m][d3] + c], y);
+            }
+            if (lane_ok) s_part[part][m * RUN_RPB + r] = y;
+        }
+        __syncthreads();
+        if (fin) {
+            double y = s_part[0][f];
+#pragma unroll
+            for (int p = 1; p < 9; p++) y += s_part[p][f];
+            const double dn = cheb_dn(cr.c1[s], dcur, cr.c2[s], e_di, e_b, y);
+            dcur = dn;
+            xo = xo + dn;
+            xout[qf] = xo;  // plain store: into this XCD's L2, where every reader of the run looks
+        }
+        if (s + 1 == cr.nsteps) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my part of the iterate has arrived in the L2
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(&ctl->cnt[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long target = (unsigned long long)(s + 1) * (unsigned long long)P;
+            long spins = 0;
+            int gave_up = 0;
+            while (__hip_atomic_load(&ctl->cnt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                if ((++spins & 4095) == 0 && (spins > 2000000L || __hip_atomic_load(&ctl->gaveup[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    __hip_atomic_store(&ctl->gaveup[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    gave_up = 1;
+                    break;
+                }
+            }
+            s_dead = gave_up;
+        }
+        __syncthreads();
+        if (s_dead) {
+            dead = true;
+            break;
+        }
+        const double *tmp = xout;
+        xout = const_cast<double *>(xin);
+        xin = tmp;
+    }
+    if (dead && fin) xa[qf] = xb[qf] = __builtin_nan("");
+    leave();
+}

@@ -418,6 +418,8 @@ struct MGSolver {
         for (double *p : {cg_r, cg_p, cg_w}) (void)hipFree(p);
         (void)hipFree(run_cnt);
         run_cnt = nullptr;
+        (void)hipFree(run_ctl);
+        run_ctl = nullptr;
         for (LanBuf &b : lan) {
             (void)hipFree(b.V);
             (void)hipFree(b.coef);
@@ -830,6 +832,7 @@ struct MGSolver {
     }
     // ---- the coarsest level's run in one launch (coarse_run.h)
     unsigned long long *run_cnt = nullptr;  // [dev] arrival counter (monotone over the runs) + give-up flag
+    XcdRunCtrl *run_ctl = nullptr;          // [dev] control block of the one-XCD run (zero between runs)
     unsigned long long run_base = 0;        // arrivals of all runs so far
     long coarse_runs = 0;
     // rows per thread: the fewest that bring the run down to `want` workgroups (barrier cost grows with their number)
@@ -840,6 +843,14 @@ struct MGSolver {
         *wgs = (int)((rows + (long)RUN_RPB * R - 1) / ((long)RUN_RPB * R));
         return R;
     }
+    static int xcd_rows_per_thread(long rows, int *wgs) {  // as few rows per thread as 32 workgroups allow
+        int R = 1;
+        while (R < 8 && (rows + (long)RUN_RPB * R - 1) / ((long)RUN_RPB * R) > 32) R *= 2;
+        *wgs = (int)((rows + (long)RUN_RPB * R - 1) / ((long)RUN_RPB * R));
+        return R;
+    }
+    // 3: one launch whose workgroups all sit on ONE XCD and exchange the iterate through its L2 (coarse_run.h; on for
+    //    449 .. 3584 rows on one rank unless TP_NO_COARSE_XCD / TP_NO_COARSE_RUN: 1.8 us per step against 3.0 per launch)
     // 0: separate launches; 1: one launch of ONE workgroup (iterate in LDS; on unless TP_NO_COARSE_RUN);
     // 2: one launch of several workgroups with a barrier per step (opt-in TP_COARSE_RUN=1: measured at 128^3 / C1 / C3 it
     // costs what its launches cost, 19.7 against 19.6 ms at 654 against 1471 launches per design iteration -- a step inside
@@ -854,8 +865,12 @@ struct MGSolver {
         const int R = run_rows_per_thread(L.own_n(), &wgs);
         if (L.own_n() <= (long)RUN_RPB * 8 && L.ndof() <= RUN_XS && L.own_n() == L.ndof()) return getenv("TP_NO_COARSE_RUN") ? 0 : 1;
         const char *sw = getenv("TP_COARSE_RUN");  // read per call: the tests switch it within a process
-        if (!(sw && atoi(sw) == 1)) return 0;
-        return wgs <= RUN_MAX_WGS && run_stage_doubles(L.g, DOF, R) <= RUN_XS ? 2 : 0;
+        if (sw && atoi(sw) == 1) return wgs <= RUN_MAX_WGS && run_stage_doubles(L.g, DOF, R) <= RUN_XS ? 2 : 0;
+        // 3: the run on one XCD (coarse_run.h): one rank, at most 32 workgroups (one per CU of an XCD), R <= 2
+        if (getenv("TP_NO_COARSE_RUN") || getenv("TP_NO_COARSE_XCD") || grid->has_comm || tp_debug_sync()) return 0;
+        int wx;
+        const int Rx = xcd_rows_per_thread(L.own_n(), &wx);
+        return (Rx <= 2 && wx <= 32 && wx >= 2 && run_stage_doubles(L.g, DOF, Rx) <= RUN_XS && L.own_n() == L.ndof()) ? 3 : 0;
     }
     // steps it0 .. k-1 of smooth() (it0 >= 1: the direction vector L.d is valid)
     int coarse_run(int l, const double *b, int it0, int k, double sigma, double delta, int mode) {
@@ -876,6 +891,16 @@ struct MGSolver {
         DiaOp<DOF> o{L.S, L.ndof(), L.g};
         if (mode == 1) {
             TP_LAUNCH((k_dia_cheb_run<DOF, 8, true>), dim3(1), dim3(RUN_WG), 0, grid->stream, o, b, L.dinv, L.d, L.x, L.x2, cr, run_cnt, run_base);
+        } else if (mode == 3) {
+            if (!run_ctl) {
+                TP_HIP(hipMalloc((void **)&run_ctl, sizeof(XcdRunCtrl)));
+                TP_HIP(hipMemsetAsync(run_ctl, 0, sizeof(XcdRunCtrl), grid->stream));
+            }
+            int P;
+            const int R = xcd_rows_per_thread(L.own_n(), &P);
+            if (R == 1) TP_LAUNCH((k_dia_cheb_run_xcd<DOF, 1>), dim3(8 * P), dim3(RUN_WG), 0, grid->stream, o, b, L.dinv, L.d, L.x, L.x2, cr, run_ctl, P);
+            else TP_LAUNCH((k_dia_cheb_run_xcd<DOF, 2>), dim3(8 * P), dim3(RUN_WG), 0, grid->stream, o, b, L.dinv, L.d, L.x, L.x2, cr, run_ctl, P);
+            if (cr.nsteps & 1) std::swap(L.x, L.x2);
         } else {
             int wgs;
             const int R = run_rows_per_thread(L.own_n(), &wgs);
@@ -1342,6 +1367,7 @@ struct MGSolver {
             TP_HIP(hipMemsetAsync(run_cnt, 0, 2 * sizeof(unsigned long long), s));
             run_base = 0;
         }
+        if (rc == TP_ERR_DIVERGED && run_ctl) TP_HIP(hipMemsetAsync(run_ctl, 0, sizeof(XcdRunCtrl), s));
         if (its_out) *its_out = its;
         if (rnorm_out) *rnorm_out = rnorm;
         return rc;
