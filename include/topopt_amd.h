@@ -225,6 +225,9 @@ int tp_elasticity_set_cycles(tp_elasticity *e, const int *cycles, int n);
 int tp_elasticity_level_count(const tp_elasticity *e);
 long tp_elasticity_level_nodes(const tp_elasticity *e, int level);
 double tp_elasticity_level_lambda(const tp_elasticity *e, int level);
+/* lower end of the Chebyshev window of the coarsest level (smallest Ritz value of its 40-step Lanczos run; the reference
+ * has GMRES there and needs no window: /root/reference/src/LinearElasticity.cc:760-790); 0 on the other levels */
+double tp_elasticity_level_lambda_min(const tp_elasticity *e, int level);
 int tp_elasticity_level_apply(tp_elasticity *e, int level, const double *u, double *y); /* [dev, level local dofs] */
 int tp_elasticity_level_diag(tp_elasticity *e, int level, double *d);
 int tp_elasticity_precond(tp_elasticity *e, const double *r, double *z); /* one V-cycle */

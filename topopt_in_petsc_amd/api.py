@@ -305,6 +305,9 @@ class LinearElasticity:
     def level_lambda(self, l):
         return self.L.tp_elasticity_level_lambda(self.handle, l)
 
+    def level_lambda_min(self, l):
+        return self.L.tp_elasticity_level_lambda_min(self.handle, l)
+
     def level_vec(self, l):
         return torch.zeros(3 * self.level_nodes(l), dtype=torch.float64, device=self.grid.device)
 

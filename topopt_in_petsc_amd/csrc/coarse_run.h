@@ -352,3 +352,251 @@ __global__ __launch_bounds__(RUN_WG) void k_dia_cheb_run_xcd(DiaOp<DOF> op, cons
     if (dead && fin) xa[qf] = xb[qf] = __builtin_nan("");
     leave();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The Lanczos run of the coarsest level (40 steps with full reorthogonalisation, the longest chain of the set-up phase:
+// 287 launches, 1.3 ms of a 3.5 ms set-up at 128^3) as ONE launch on one XCD.  Same join protocol and the same matrix
+// split as the Chebyshev run above; in addition every workgroup keeps ITS rows of the whole Lanczos basis in LDS, so per
+// step only three things travel through the XCD's L2, each followed by one barrier:
+//   (1) the partial sums of the first Gram-Schmidt pass  (P x (j+1) doubles),
+//   (2) the partial sums of the second pass,
+//   (3) the un-normalised new vector and the partial sums of its norm; the reader normalises and scales while staging.
+// Row arithmetic as in k_dia_row_split<DOF, EPI_APPLY, 9> / k_multi_axpy / k_lanczos_next (same products, same order);
+// the dot products add per-workgroup partial sums in rank order, i.e. in another order than k_multi_dot: alpha and beta
+// agree with the chain of launches to rounding (tests: 1e-12 on the Ritz values), not to the bit.
+constexpr int LAN_XS = 3072;     // doubles of the staged stretch (24 KB; twice: vector and D^-1/2)
+constexpr int LAN_MAXS = 40;     // steps (basis of 41 vectors x R x 56 rows in LDS)
+constexpr int LAN_PSTRIDE = 64;  // doubles per rank in a partial-sum region
+
+__device__ inline int xcd_join(XcdRunCtrl *ctl, int P) {  // thread 0 of a workgroup: rank in the run or -1
+    const unsigned xcc = run_xcc_id();
+    const unsigned long long tk = __hip_atomic_fetch_add(&ctl->join[xcc][0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tk >= (unsigned long long)P) return -1;
+    if (tk == (unsigned long long)(P - 1)) {
+        unsigned long long expect = 0ull;
+        __hip_atomic_compare_exchange_strong(&ctl->winner[0], &expect, 1ull + xcc, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    unsigned long long w;
+    long spins = 0;
+    while ((w = __hip_atomic_load(&ctl->winner[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0ull) {
+        if (++spins > 2000000L || ((spins & 1023) == 0 && __hip_atomic_load(&ctl->gaveup[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            __hip_atomic_store(&ctl->gaveup[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return (w == 1ull + xcc) ? (int)tk : -1;
+}
+__device__ inline void xcd_leave(XcdRunCtrl *ctl) {  // all threads; the last workgroup of the launch zeroes the block
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long f = __hip_atomic_fetch_add(&ctl->finished[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (f + 1 == (unsigned long long)gridDim.x) {
+            for (int x = 0; x < 8; x++) __hip_atomic_store(&ctl->join[x][0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl->winner[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl->cnt[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl->finished[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+// barrier number `k` (0, 1, 2 ..) of the run: the caller's stores are drained first; returns true if the run gave up
+__device__ inline bool xcd_barrier(XcdRunCtrl *ctl, int k, int P, int *s_dead) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(&ctl->cnt[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long target = (unsigned long long)(k + 1) * (unsigned long long)P;
+        long spins = 0;
+        int gave_up = 0;
+        while (__hip_atomic_load(&ctl->cnt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if ((++spins & 4095) == 0 && (spins > 2000000L || __hip_atomic_load(&ctl->gaveup[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(&ctl->gaveup[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gave_up = 1;
+                break;
+            }
+        }
+        *s_dead = gave_up;
+    }
+    __syncthreads();
+    return *s_dead != 0;
+}
+
+// exch: [0, 32*64) partial sums pass 1 | [2048, 4096) pass 2 | [4096, 4096+32) norm partials | [4160, ..) the new vector
+template <int DOF, int R>
+__global__ __launch_bounds__(RUN_WG) void k_lanczos_run_xcd(DiaOp<DOF> op, const double *__restrict__ dinv, double *exch, double *__restrict__ alpha,
+                                                            double *__restrict__ beta, int steps, XcdRunCtrl *ctl, int P) {
+    constexpr int ROWS = RUN_RPB * R;
+    __shared__ double s_part[9][ROWS];
+    __shared__ double xs[LAN_XS], dis_s[LAN_XS];
+    __shared__ double Vs[LAN_MAXS + 1][ROWS];
+    __shared__ double ws[ROWS], hs[LAN_PSTRIDE];
+    __shared__ double s_inv;
+    __shared__ int s_dead, s_rank;
+    if (threadIdx.x == 0) s_rank = xcd_join(ctl, P);
+    __syncthreads();
+    const int rank = s_rank;
+    if (rank < 0) {
+        xcd_leave(ctl);
+        return;
+    }
+    const Geom &g = op.g;
+    const long plane = g.plane();
+    const long nown = g.owned_nodes() * DOF;  // == all rows (one rank; checked by the host)
+    const int part = threadIdx.x / RUN_RPB, r = threadIdx.x % RUN_RPB;
+    const bool lane_ok = part < 9;
+    const long t_lo = (long)rank * ROWS, t_hi = min(t_lo + (long)ROWS, nown) - 1;
+    const int nrows = (int)(t_hi - t_lo + 1);
+    const long reach = plane + g.nx + 1;
+    const long n_first = max(t_lo / DOF - reach, 0L);
+    const long n_last = min(t_hi / DOF + reach, g.nodes() - 1);
+    const int stage_n = (int)((n_last - n_first + 1) * DOF);
+    double coef[R][3 * DOF];
+    int nbi[R][3];
+    bool valid[R];
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+        const long t = t_lo + (long)m * RUN_RPB + r;
+        valid[m] = lane_ok && t < nown;
+        const long q = valid[m] ? t : 0;
+        const long n = q / DOF;
+        const int k = (int)(n / plane);
+        const int rem = (int)(n % plane);
+        const int j = rem / g.nx, i = rem % g.nx;
+        const int dk = part / 3 - 1, dj = part % 3 - 1;
+        const bool okj = k + dk >= 0 && k + dk < g.nzl && j + dj >= 0 && j + dj < g.ny;
+#pragma unroll
+        for (int di = -1; di <= 1; di++) {
+            const bool ok = okj && i + di >= 0 && i + di < g.nx;
+            const int blk = ((lane_ok ? dk : 0) + 1) * 9 + ((lane_ok ? dj : 0) + 1) * 3 + (di + 1);
+            const long nb = ok ? n + di + (long)g.nx * (dj + (long)g.ny * dk) : n;
+            nbi[m][di + 1] = valid[m] ? (int)((nb - n_first) * DOF) : 0;
+#pragma unroll
+            for (int c = 0; c < DOF; c++) coef[m][(di + 1) * DOF + c] = valid[m] ? op.S[(long)(blk * DOF + c) * op.nrows + q] : 0.0;
+        }
+    }
+    for (int idx = threadIdx.x; idx < stage_n; idx += RUN_WG) dis_s[idx] = sqrt(dinv[n_first * DOF + idx]);
+    const int f = threadIdx.x;
+    const bool fin = f < nrows;
+    const long qf = fin ? t_lo + f : 0;
+    const int xsf = (int)(qf - n_first * DOF);
+    double *p1 = exch, *p2 = exch + 32 * LAN_PSTRIDE, *pn = exch + 64 * LAN_PSTRIDE, *wx = exch + 64 * LAN_PSTRIDE + 64;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(wx + n_first * DOF, 0, stage_n * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_n = __builtin_amdgcn_make_buffer_rsrc(pn, 0, P * 8, 0x00020000);
+    double wf = fin ? hash_u01((uint64_t)qf, 0x5eedULL) - 0.5 : 0.0;  // the start vector of k_lanczos_init
+    __syncthreads();
+    const double e_dis = fin ? dis_s[xsf] : 0.0;
+    int nbar = 0;
+    bool dead = false;
+    // partial sums of this workgroup's rows against the first nv basis vectors (8 threads per vector), rank-ordered
+    // total after a barrier -> hs[0 .. nv)
+    auto gram = [&](int nv, double *region) -> bool {
+        const int q = threadIdx.x >> 3, sub = threadIdx.x & 7;
+        double s = 0.0;
+        if (q < nv)
+            for (int i = sub; i < nrows; i += 8) s = fma(Vs[q][i], ws[i], s);
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        if (q < nv && sub == 0) region[rank * LAN_PSTRIDE + q] = s;
+        if (xcd_barrier(ctl, nbar++, P, &s_dead)) return true;
+        if ((int)threadIdx.x < nv) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(region, 0, P * LAN_PSTRIDE * 8, 0x00020000);
+            double tmp[32];
+#pragma unroll
+            for (int rk = 0; rk < 32; rk++)  // ranks >= P: out of range, zeros
+                tmp[rk] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, (rk * LAN_PSTRIDE + threadIdx.x) * 8, 0, 16 /* sc1 */));
+            double h = tmp[0];
+#pragma unroll
+            for (int rk = 1; rk < 32; rk++) h += tmp[rk];
+            hs[threadIdx.x] = h;
+        }
+        __syncthreads();
+        return false;
+    };
+    for (int j = -1; j < steps; j++) {
+        // ---- (3) norm of the new vector, the vector itself
+        if (fin) {
+            ws[f] = wf;
+            wx[qf] = wf;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            double s = 0.0;
+            for (int i = threadIdx.x; i < nrows; i += 64) s = fma(ws[i], ws[i], s);
+            s = wave_sum(s);
+            if (threadIdx.x == 0) pn[rank] = s;
+        }
+        if (xcd_barrier(ctl, nbar++, P, &s_dead)) {
+            dead = true;
+            break;
+        }
+        if (threadIdx.x < 64) {
+            double v = threadIdx.x < 32 ? __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs_n, threadIdx.x * 8, 0, 16)) : 0.0;
+            double bb = 0.0;
+            for (int rk = 0; rk < 32; rk++) bb += __shfl(v, rk);
+            const double bt = sqrt(bb);
+            if (threadIdx.x == 0) {
+                s_inv = bt > 0.0 ? 1.0 / bt : 0.0;
+                if (rank == 0 && j >= 0) beta[j] = bt;
+            }
+        }
+        {
+            constexpr int NST = LAN_XS / RUN_WG;
+            double tmp[NST];
+#pragma unroll
+            for (int q = 0; q < NST; q++)
+                tmp[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs_w, (threadIdx.x + q * RUN_WG) * 8, 0, 16 /* sc1 */));
+            __syncthreads();  // s_inv
+            const double inv = s_inv;
+#pragma unroll
+            for (int q = 0; q < NST; q++)
+                if (threadIdx.x + q * RUN_WG < stage_n) xs[threadIdx.x + q * RUN_WG] = dis_s[threadIdx.x + q * RUN_WG] * (tmp[q] * inv);
+            if (fin) Vs[j + 1][f] = wf * inv;
+            __syncthreads();
+        }
+        if (j + 1 == steps) break;
+        // ---- w = D^-1/2 A D^-1/2 v_{j+1}
+#pragma unroll
+        for (int m = 0; m < R; m++) {
+            double y = 0.0;
+            if (valid[m]) {
+#pragma unroll
+                for (int d3 = 0; d3 < 3; d3++)
+#pragma unroll
+                    for (int c = 0; c < DOF; c++) y = fma(coef[m][d3 * DOF + c], xs[nbi[m][d3] + c], y);
+            }
+            if (lane_ok) s_part[part][m * RUN_RPB + r] = y;
+        }
+        __syncthreads();
+        if (fin) {
+            double y = s_part[0][f];
+#pragma unroll
+            for (int p = 1; p < 9; p++) y += s_part[p][f];
+            wf = e_dis * y;
+            ws[f] = wf;
+        }
+        __syncthreads();
+        // ---- (1), (2) classical Gram-Schmidt, twice, against v_0 .. v_{j+1}
+        const int nv = j + 2;
+        double h1_last = 0.0;
+        for (int pass = 0; pass < 2 && !dead; pass++) {
+            if (gram(nv, pass ? p2 : p1)) {
+                dead = true;
+                break;
+            }
+            if (fin) {
+                double acc = wf;
+                for (int q = 0; q < nv; q++) acc = fma(-hs[q], Vs[q][f], acc);
+                wf = acc;
+            }
+            if (pass == 0) h1_last = hs[nv - 1];
+            else if (threadIdx.x == 0 && rank == 0) alpha[nv - 1] = h1_last + hs[nv - 1];
+            __syncthreads();  // hs, ws are rewritten
+            if (fin) ws[f] = wf;
+            __syncthreads();
+        }
+        if (dead) break;
+    }
+    if (dead && threadIdx.x == 0 && rank == 0) alpha[0] = beta[0] = __builtin_nan("");
+    xcd_leave(ctl);
+}

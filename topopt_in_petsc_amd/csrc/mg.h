@@ -420,6 +420,8 @@ struct MGSolver {
         run_cnt = nullptr;
         (void)hipFree(run_ctl);
         run_ctl = nullptr;
+        (void)hipFree(lan_ctl);
+        lan_ctl = nullptr;
         for (LanBuf &b : lan) {
             (void)hipFree(b.V);
             (void)hipFree(b.coef);
@@ -867,10 +869,16 @@ struct MGSolver {
         const char *sw = getenv("TP_COARSE_RUN");  // read per call: the tests switch it within a process
         if (sw && atoi(sw) == 1) return wgs <= RUN_MAX_WGS && run_stage_doubles(L.g, DOF, R) <= RUN_XS ? 2 : 0;
         // 3: the run on one XCD (coarse_run.h): one rank, at most 32 workgroups (one per CU of an XCD), R <= 2
-        if (getenv("TP_NO_COARSE_RUN") || getenv("TP_NO_COARSE_XCD") || grid->has_comm || tp_debug_sync()) return 0;
+        if (getenv("TP_NO_COARSE_RUN") || getenv("TP_NO_COARSE_XCD")) return 0;
+        return xcd_eligible(l, RUN_XS) ? 3 : 0;
+    }
+    // the level fits a run on one XCD: one rank, 2 .. 32 workgroups (one per CU of an XCD) of at most 2 rows per thread
+    bool xcd_eligible(int l, long stage_cap) const {
+        const Level<DOF> &L = lv[l];
+        if (sg_capturing || DOF != 3 || L.kind != LV_DIA || grid->has_comm || tp_debug_sync()) return false;
         int wx;
         const int Rx = xcd_rows_per_thread(L.own_n(), &wx);
-        return (Rx <= 2 && wx <= 32 && wx >= 2 && run_stage_doubles(L.g, DOF, Rx) <= RUN_XS && L.own_n() == L.ndof()) ? 3 : 0;
+        return Rx <= 2 && wx <= 32 && wx >= 2 && run_stage_doubles(L.g, DOF, Rx) <= stage_cap && L.own_n() == L.ndof();
     }
     // steps it0 .. k-1 of smooth() (it0 >= 1: the direction vector L.d is valid)
     int coarse_run(int l, const double *b, int it0, int k, double sigma, double delta, int mode) {
@@ -1200,11 +1208,41 @@ struct MGSolver {
         TP_HIP(hipMemcpyAsync(B.hc, coef, sizeof(double) * 520, hipMemcpyDeviceToHost, s));
         return TP_OK;
     }
+    // The coarsest level's run as ONE launch on one XCD (coarse_run.h: k_lanczos_run_xcd): where the Chebyshev run of the
+    // level qualifies for the one-XCD form; TP_NO_LANCZOS_XCD=1 keeps the chain of launches.
+    XcdRunCtrl *lan_ctl = nullptr;
+    bool lanczos_xcd_ok(int l, int steps) const {
+        if (getenv("TP_NO_LANCZOS_XCD") || steps > LAN_MAXS || steps < 2 || !(l == nlv - 1 && l > 0)) return false;
+        return xcd_eligible(l, LAN_XS);
+    }
+    int lanczos_xcd(int l, int steps) {
+        Level<DOF> &L = lv[l];
+        LanBuf &B = lan[l];
+        hipStream_t s = grid->stream;
+        if (!B.coef) TP_HIP(hipMalloc((void **)&B.coef, sizeof(double) * 520));
+        if (!B.part) TP_HIP(hipMalloc((void **)&B.part, sizeof(double) * 256 * 130));
+        if (!B.hc) TP_HIP(hipHostMalloc((void **)&B.hc, sizeof(double) * 520));
+        if (!lan_ctl) {
+            TP_HIP(hipMalloc((void **)&lan_ctl, sizeof(XcdRunCtrl)));
+            TP_HIP(hipMemsetAsync(lan_ctl, 0, sizeof(XcdRunCtrl), s));
+        }
+        TP_HIP(hipMemsetAsync(B.coef, 0, sizeof(double) * 520, s));
+        DiaOp<DOF> o{L.S, L.ndof(), L.g};
+        int P;
+        const int R = xcd_rows_per_thread(L.own_n(), &P);
+        if (R == 1) TP_LAUNCH((k_lanczos_run_xcd<DOF, 1>), dim3(8 * P), dim3(RUN_WG), 0, s, o, L.dinv, B.part, B.coef + 258, B.coef + 386, steps, lan_ctl, P);
+        else TP_LAUNCH((k_lanczos_run_xcd<DOF, 2>), dim3(8 * P), dim3(RUN_WG), 0, s, o, L.dinv, B.part, B.coef + 258, B.coef + 386, steps, lan_ctl, P);
+        grid->launches += 1;
+        B.m = steps;
+        TP_HIP(hipMemcpyAsync(B.hc, B.coef, sizeof(double) * 520, hipMemcpyDeviceToHost, s));
+        return TP_OK;
+    }
     // replay (or capture, or plain enqueue) of the run of level l on grid->stream
     int lanczos_graph(int l, int steps) {
         static const bool no_graph = getenv("TP_NO_GRAPH") != nullptr || tp_debug_sync();
         Level<DOF> &L = lv[l];
         hipStream_t s = grid->stream;
+        if (lanczos_xcd_ok(l, steps)) return lanczos_xcd(l, steps);
         // the chain reads/writes these vectors by address, and set_bc may rebuild the correction lists
         const void *key[5] = {L.r, L.b, L.d, L.corr, (const void *)(intptr_t)topology_epoch};
         if (lan_graph_state[l] == 1 && memcmp(key, lan_graph_key[l], sizeof(key)) != 0) {
@@ -1262,7 +1300,8 @@ struct MGSolver {
         if (lam_min_out) *lam_min_out = tridiag_lmin(m, ha, hb);
     }
     int lanczos(int l, int steps, double *lam_out, double *lam_min_out = nullptr) {
-        TP_TRY(lanczos_enqueue(l, steps));
+        if (lanczos_xcd_ok(l, steps)) TP_TRY(lanczos_xcd(l, steps));
+        else TP_TRY(lanczos_enqueue(l, steps));
         TP_HIP(hipStreamSynchronize(grid->stream));
         lanczos_finish(l, lam_out, lam_min_out);
         return TP_OK;
@@ -1368,6 +1407,7 @@ struct MGSolver {
             run_base = 0;
         }
         if (rc == TP_ERR_DIVERGED && run_ctl) TP_HIP(hipMemsetAsync(run_ctl, 0, sizeof(XcdRunCtrl), s));
+        if (rc == TP_ERR_DIVERGED && lan_ctl) TP_HIP(hipMemsetAsync(lan_ctl, 0, sizeof(XcdRunCtrl), s));
         if (its_out) *its_out = its;
         if (rnorm_out) *rnorm_out = rnorm;
         return rc;

@@ -1030,6 +1030,7 @@ extern "C" int tp_elasticity_set_cycles(tp_elasticity *e, const int *cycles, int
 extern "C" int tp_elasticity_level_count(const tp_elasticity *e) { return e->mg.nlv; }
 extern "C" long tp_elasticity_level_nodes(const tp_elasticity *e, int l) { return e->mg.lv[l].g.nodes(); }
 extern "C" double tp_elasticity_level_lambda(const tp_elasticity *e, int l) { return e->mg.lv[l].lam; }
+extern "C" double tp_elasticity_level_lambda_min(const tp_elasticity *e, int l) { return e->mg.lv[l].lam_min; }
 extern "C" int tp_elasticity_level_apply(tp_elasticity *e, int l, const double *u, double *y) {
     if (!e->assembled || l < 0 || l >= e->mg.nlv) return TP_ERR_STATE;
     return e->mg.apply(l, const_cast<double *>(u), y);

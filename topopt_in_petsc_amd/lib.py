@@ -96,6 +96,7 @@ SYMBOLS = {
     "tp_elasticity_level_count": (_i, [_vp]),
     "tp_elasticity_level_nodes": (_l, [_vp, _i]),
     "tp_elasticity_level_lambda": (_d, [_vp, _i]),
+    "tp_elasticity_level_lambda_min": (_d, [_vp, _i]),
     "tp_elasticity_level_apply": (_i, [_vp, _i, _vp, _vp]),
     "tp_elasticity_level_diag": (_i, [_vp, _i, _vp]),
     "tp_elasticity_set_cycles": (_i, [_vp, _vp, _i]),
