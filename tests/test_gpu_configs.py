@@ -235,12 +235,14 @@ def test_graphed_coarsest_smoothing_bits(tp):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mesh,nl,single", [((64, 32, 32), 4, False), ((32, 32, 32), 5, True), ((48, 24, 24), 3, False),
-                                            ((48, 24, 24), 4, True), ((64, 64, 64), 5, True)])
+                                            ((48, 24, 24), 4, True), ((64, 64, 64), 5, True), ((64, 64, 128), 4, False),
+                                            ((64, 64, 256), 4, False)])
 def test_coarsest_run_in_one_launch_bits(tp, mesh, nl, single):
     """csrc/coarse_run.h: the Chebyshev steps of the coarsest level as iterations inside ONE kernel.  Coarsest grids of
     <= 448 rows (7 x 4 x 4, 5^3, 3^3 nodes here) run in ONE workgroup with the iterate in LDS -- the default; larger ones
-    (9 x 5 x 5, 13 x 7 x 7 nodes) across workgroups with a barrier per step: by default (round 3) workgroups that have
-    gathered on ONE XCD and exchange the iterate through its L2, opt-in (TP_COARSE_RUN=1) workgroups anywhere.  Either way:
+    (9 x 5 x 5, 13 x 7 x 7 nodes; 9 x 9 x 17 and 9 x 9 x 33 with 4 and 8 rows per thread) across workgroups with a barrier
+    per step: by default (round 3) workgroups that have gathered on ONE XCD and exchange the iterate through its L2, opt-in
+    (TP_COARSE_RUN=1) workgroups anywhere.  Either way:
     the same bits as the separate launches (TP_NO_COARSE_RUN=1), fewer launches."""
     ex, ey, ez = mesh
     g = tp.Grid(ex + 1, ey + 1, ez + 1, 1.0 / ey)
@@ -266,7 +268,7 @@ def test_coarsest_run_in_one_launch_bits(tp, mesh, nl, single):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mesh,nl", [((64, 32, 32), 4), ((48, 24, 24), 3), ((64, 64, 64), 4), ((40, 40, 24), 3)])
+@pytest.mark.parametrize("mesh,nl", [((64, 32, 32), 4), ((48, 24, 24), 3), ((64, 64, 64), 4), ((40, 40, 24), 3), ((64, 64, 128), 4)])
 def test_coarsest_spectrum_in_one_launch(tp, mesh, nl):
     """csrc/coarse_run.h, k_lanczos_run_xcd: the 40 Lanczos steps of the coarsest level (full reorthogonalisation) inside ONE
     kernel on one XCD.  Row arithmetic as in the chain of launches, dot products summed in another order: both ends of the

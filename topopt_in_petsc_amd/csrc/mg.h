@@ -852,7 +852,7 @@ struct MGSolver {
         return R;
     }
     // 3: one launch whose workgroups all sit on ONE XCD and exchange the iterate through its L2 (coarse_run.h; on for
-    //    449 .. 3584 rows on one rank unless TP_NO_COARSE_XCD / TP_NO_COARSE_RUN: 1.8 us per step against 3.0 per launch)
+    //    449 .. 14336 rows held by one rank unless TP_NO_COARSE_XCD / TP_NO_COARSE_RUN: 2.3 us per step against 3-4 per launch)
     // 0: separate launches; 1: one launch of ONE workgroup (iterate in LDS; on unless TP_NO_COARSE_RUN);
     // 2: one launch of several workgroups with a barrier per step (opt-in TP_COARSE_RUN=1: measured at 128^3 / C1 / C3 it
     // costs what its launches cost, 19.7 against 19.6 ms at 654 against 1471 launches per design iteration -- a step inside
@@ -870,15 +870,16 @@ struct MGSolver {
         if (sw && atoi(sw) == 1) return wgs <= RUN_MAX_WGS && run_stage_doubles(L.g, DOF, R) <= RUN_XS ? 2 : 0;
         // 3: the run on one XCD (coarse_run.h): one rank, at most 32 workgroups (one per CU of an XCD), R <= 2
         if (getenv("TP_NO_COARSE_RUN") || getenv("TP_NO_COARSE_XCD")) return 0;
-        return xcd_eligible(l, RUN_XS) ? 3 : 0;
+        return xcd_eligible(l, RUN_XS, 8) ? 3 : 0;
     }
-    // the level fits a run on one XCD: one rank, 2 .. 32 workgroups (one per CU of an XCD) of at most 2 rows per thread
-    bool xcd_eligible(int l, long stage_cap) const {
+    // the level fits a run on one XCD: all its rows on this rank (one rank, or the replicated copy of the coarsest
+    // level), 2 .. 32 workgroups (one per CU of an XCD) of at most max_r rows per thread
+    bool xcd_eligible(int l, long stage_cap, int max_r) const {
         const Level<DOF> &L = lv[l];
-        if (sg_capturing || DOF != 3 || L.kind != LV_DIA || grid->has_comm || tp_debug_sync()) return false;
+        if (sg_capturing || DOF != 3 || L.kind != LV_DIA || (grid->has_comm && !L.no_comm) || tp_debug_sync()) return false;
         int wx;
         const int Rx = xcd_rows_per_thread(L.own_n(), &wx);
-        return Rx <= 2 && wx <= 32 && wx >= 2 && run_stage_doubles(L.g, DOF, Rx) <= stage_cap && L.own_n() == L.ndof();
+        return Rx <= max_r && wx <= 32 && wx >= 2 && run_stage_doubles(L.g, DOF, Rx) <= stage_cap && L.own_n() == L.ndof();
     }
     // steps it0 .. k-1 of smooth() (it0 >= 1: the direction vector L.d is valid)
     int coarse_run(int l, const double *b, int it0, int k, double sigma, double delta, int mode) {
@@ -907,7 +908,9 @@ struct MGSolver {
             int P;
             const int R = xcd_rows_per_thread(L.own_n(), &P);
             if (R == 1) TP_LAUNCH((k_dia_cheb_run_xcd<DOF, 1>), dim3(8 * P), dim3(RUN_WG), 0, grid->stream, o, b, L.dinv, L.d, L.x, L.x2, cr, run_ctl, P);
-            else TP_LAUNCH((k_dia_cheb_run_xcd<DOF, 2>), dim3(8 * P), dim3(RUN_WG), 0, grid->stream, o, b, L.dinv, L.d, L.x, L.x2, cr, run_ctl, P);
+            else if (R == 2) TP_LAUNCH((k_dia_cheb_run_xcd<DOF, 2>), dim3(8 * P), dim3(RUN_WG), 0, grid->stream, o, b, L.dinv, L.d, L.x, L.x2, cr, run_ctl, P);
+            else if (R == 4) TP_LAUNCH((k_dia_cheb_run_xcd<DOF, 4>), dim3(8 * P), dim3(RUN_WG), 0, grid->stream, o, b, L.dinv, L.d, L.x, L.x2, cr, run_ctl, P);
+            else TP_LAUNCH((k_dia_cheb_run_xcd<DOF, 8>), dim3(8 * P), dim3(RUN_WG), 0, grid->stream, o, b, L.dinv, L.d, L.x, L.x2, cr, run_ctl, P);
             if (cr.nsteps & 1) std::swap(L.x, L.x2);
         } else {
             int wgs;
@@ -1212,8 +1215,9 @@ struct MGSolver {
     // level qualifies for the one-XCD form; TP_NO_LANCZOS_XCD=1 keeps the chain of launches.
     XcdRunCtrl *lan_ctl = nullptr;
     bool lanczos_xcd_ok(int l, int steps) const {
-        if (getenv("TP_NO_LANCZOS_XCD") || steps > LAN_MAXS || steps < 2 || !(l == nlv - 1 && l > 0)) return false;
-        return xcd_eligible(l, LAN_XS);
+        if (getenv("TP_NO_LANCZOS_XCD") || steps > LAN_MAXS || steps < 2) return false;
+        if (!(replicate ? l == nlv : (l == nlv - 1 && l > 0))) return false;
+        return xcd_eligible(l, LAN_XS, 4);  // (8 rows per thread: the basis no longer fits the LDS)
     }
     int lanczos_xcd(int l, int steps) {
         Level<DOF> &L = lv[l];
@@ -1231,7 +1235,8 @@ struct MGSolver {
         int P;
         const int R = xcd_rows_per_thread(L.own_n(), &P);
         if (R == 1) TP_LAUNCH((k_lanczos_run_xcd<DOF, 1>), dim3(8 * P), dim3(RUN_WG), 0, s, o, L.dinv, B.part, B.coef + 258, B.coef + 386, steps, lan_ctl, P);
-        else TP_LAUNCH((k_lanczos_run_xcd<DOF, 2>), dim3(8 * P), dim3(RUN_WG), 0, s, o, L.dinv, B.part, B.coef + 258, B.coef + 386, steps, lan_ctl, P);
+        else if (R == 2) TP_LAUNCH((k_lanczos_run_xcd<DOF, 2>), dim3(8 * P), dim3(RUN_WG), 0, s, o, L.dinv, B.part, B.coef + 258, B.coef + 386, steps, lan_ctl, P);
+        else TP_LAUNCH((k_lanczos_run_xcd<DOF, 4>), dim3(8 * P), dim3(RUN_WG), 0, s, o, L.dinv, B.part, B.coef + 258, B.coef + 386, steps, lan_ctl, P);
         grid->launches += 1;
         B.m = steps;
         TP_HIP(hipMemcpyAsync(B.hc, B.coef, sizeof(double) * 520, hipMemcpyDeviceToHost, s));
