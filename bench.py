@@ -54,6 +54,8 @@ def parse():
     p.add_argument("--nlvls", type=int, default=0, help="override the multigrid depth of the workload")
     p.add_argument("--ncoarse", type=int, default=0, help="coarse-solve Chebyshev steps (0: the workload's)")
     p.add_argument("--nsmooth", type=int, default=0, help="Chebyshev steps per smoothing sweep (0: the workload's)")
+    p.add_argument("--coarse", default="cheb", choices=["direct", "cheb"],
+                   help="coarsest level: exact solve (banded Cholesky + explicit triangular inverse per assembly, where the level has <= 4096 rows; else falls back) or the Chebyshev run of --ncoarse steps")
     p.add_argument("--cycles", default="", help="cycles of the next coarser level per level, finest first, e.g. 1,2,2 (1 = V, 2 = W)")
     p.add_argument("--spmv-reps", type=int, default=50)
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -81,7 +83,7 @@ def respawn_under_torchrun(n):
     os.execv(sys.executable, cmd)
 
 
-def cpu_step(orc, el, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, matfree_too):
+def cpu_step(orc, el, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, matfree_too, coarse_direct=False):
     """One design iteration of the oracle (the reference's data path: assembled CSR + Galerkin SpGEMM) on `el` elements;
     with matfree_too the solve is repeated with the fine-level operator applied matrix-free (OpenMP gather).  Returns
     (n_dof, its, seconds assembled, seconds matrix-free or None, levels)."""
@@ -94,6 +96,7 @@ def cpu_step(orc, el, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, matfree_too
     N, R = orc.cantilever_bc(nx, ny, nz, h)
     flt = orc.Filter(nx, ny, nz, h, 2.56 * h)
     mg = orc.MG(nx, ny, nz, 3, nlv, nsmooth, ncoarse, fine_eig=fine_eig)
+    mg.set_coarse_direct(coarse_direct)
     if cycles:
         mg.set_cycles([int(v) for v in cycles.split(",")][: max(nlv - 1, 0)])
     t0 = time.perf_counter()
@@ -116,20 +119,20 @@ def cpu_step(orc, el, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, matfree_too
     return 3 * nx * ny * nz, its, t3 - t0, t_mf, nlv
 
 
-def cpu_baseline(sample, rtol, fine_eig, gpu_el, gpu_ndof, budget_s, nlv=4, nsmooth=4, ncoarse=30, cycles=""):
+def cpu_baseline(sample, rtol, fine_eig, gpu_el, gpu_ndof, budget_s, nlv=4, nsmooth=4, ncoarse=30, cycles="", coarse_direct=False):
     """the oracle timed on the host cores beside the GPU line -- on the SAME mesh when the budget
     (--cpu-budget seconds, default 240) allows it, judged from a first run on the bounded sample mesh; both data paths:
     assembled CSR (the reference's) and matrix-free fine level."""
     from oracle import oracle as orc
     cores = int(os.environ.get("OMP_NUM_THREADS", min(os.cpu_count() or 1, 16)))
     sel = tuple(int(v) for v in sample.split("x"))
-    nd, its, t, t_mf, lv = cpu_step(orc, sel, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, True)
+    nd, its, t, t_mf, lv = cpu_step(orc, sel, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, True, coarse_direct)
     est = (t + t_mf) * gpu_ndof / nd  # work per DOF and iteration count are close to mesh independent
     what = "%dx%dx%d elements (%d DOF -- NOT the GPU line's %d-DOF mesh: the same mesh was estimated at %.0f s, over the --cpu-budget of %.0f s)" % (
         sel + (nd, gpu_ndof, est, budget_s))
     same = False
     if est <= budget_s and tuple(gpu_el) != sel:
-        nd, its, t, t_mf, lv = cpu_step(orc, tuple(gpu_el), rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, True)
+        nd, its, t, t_mf, lv = cpu_step(orc, tuple(gpu_el), rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, True, coarse_direct)
         what = "%dx%dx%d elements (%d DOF: the GPU line's mesh)" % (tuple(gpu_el) + (nd,))
         same = True
     return {"value": nd / t, "unit": "DOF-updates/s", "cores": cores, "kind": "port", "same_mesh": same,
@@ -220,7 +223,8 @@ def main():
     nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
     ndof = 3 * nx * ny * nz
     grid = tp.Grid(nx, ny, nz, h, rank=rank, nranks=world)
-    le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=nlv, rtol=a.rtol, fine_eig=a.fine_eig, ncoarse=a.ncoarse, nsmooth=a.nsmooth))
+    le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=nlv, rtol=a.rtol, fine_eig=a.fine_eig, ncoarse=a.ncoarse, nsmooth=a.nsmooth,
+                                                    coarse_direct=int(a.coarse == "direct")))
     if a.cycles:
         le.set_cycles([int(v) for v in a.cycles.split(",")])
     rmin = W.get("rmin", 2.56 * h)
@@ -258,6 +262,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     alg_bytes, flops, launches = le.pop_stats()
+    coarse_is_direct = bool(le.coarse_direct_active())  # (falls back to the Chebyshev run where the level is too large / distributed)
     # MMA::Update on the same design vectors (MMA.cc:522-946 on the device), reported separately
     mma = tp.MMA(grid, x, 1)
     xmin, xmax, xw = grid.elem_vec(), grid.elem_vec(), x.clone()
@@ -330,7 +335,8 @@ def main():
         if ok:
             ez2 = ezg if o_scal == "strong" else ezg * world
             grid2 = tp.Grid(nx, ny, ez2 + 1, h, rank=rank, nranks=world)
-            le2 = tp.LinearElasticity(grid2, tp.SolverOptions(nlvls=nlv, rtol=a.rtol, fine_eig=a.fine_eig, ncoarse=a.ncoarse, nsmooth=a.nsmooth))
+            le2 = tp.LinearElasticity(grid2, tp.SolverOptions(nlvls=nlv, rtol=a.rtol, fine_eig=a.fine_eig, ncoarse=a.ncoarse, nsmooth=a.nsmooth,
+                                                              coarse_direct=int(a.coarse == "direct")))
             if a.cycles:
                 le2.set_cycles([int(v) for v in a.cycles.split(",")])
             flt2 = tp.Filter(grid2, ftype, 2.56 * h)
@@ -360,7 +366,8 @@ def main():
             ndof2 = 3 * nx * ny * (ez2 + 1)
             other = {"scaling": o_scal, "value": ndof2 / (dt2 / a.steps), "unit": "DOF-updates/s", "ms_per_step": 1e3 * dt2 / a.steps,
                      "n_dof": ndof2, "mesh": "%dx%dx%d elements over %d GPUs" % (ex, ey, ez2, world), "cg_its": le2.last_its,
-                     "rel_residual": le2.last_rnorm / le2.last_bnorm, "halo_overlap": grid2.halo_overlap, "comm": grid2.comm_kind}
+                     "rel_residual": le2.last_rnorm / le2.last_bnorm, "halo_overlap": grid2.halo_overlap, "comm": grid2.comm_kind,
+                     "coarse_solve": "direct" if le2.coarse_direct_active() else "chebyshev(%d)" % a.ncoarse}
             del le2, flt2, grid2
         else:
             other = {"scaling": o_scal, "skipped": "%d element layers do not split into %d slabs of whole coarse layers of a %d-level hierarchy" % (ezg, world, nlv)}
@@ -447,12 +454,14 @@ def main():
         "ms_per_step": t_step * 1e3, "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s: %s %dx%dx%d elements (%d DOF), z-slabs over %d GPU(s), rmin=%s %s "
-                               "filter, CG + %d-level GMG (Chebyshev(%d)-Jacobi, coarse Chebyshev(%d), Galerkin%s), rtol %g, fine-level eig %s, cold start, "
+                               "filter, CG + %d-level GMG (Chebyshev(%d)-Jacobi, coarse %s, Galerkin%s), rtol %g, fine-level eig %s, cold start, "
                                "filtered synthetic density seed 12345" % (a.workload, "MBB beam" if bc == "mbb" else "cantilever", ex, ey, ez, ndof, world,
-                                                                         ("%g (ElemConn %d)" % (rmin, flt.ElemConn)) if "rmin" in W else "2.56h", "Helmholtz (PDE)" if ftype == 2 else "density", nlv, a.nsmooth, a.ncoarse,
+                                                                         ("%g (ElemConn %d)" % (rmin, flt.ElemConn)) if "rmin" in W else "2.56h", "Helmholtz (PDE)" if ftype == 2 else "density", nlv, a.nsmooth,
+                                                                         ("exact (banded Cholesky + explicit triangular inverse per assembly)" if coarse_is_direct else "Chebyshev(%d)" % a.ncoarse),
                                                                          ", cycles per level %s" % a.cycles if a.cycles else "", a.rtol,
                                                                          "Lanczos(10)" if a.fine_eig else "element bound"),
-                   "n_dof": ndof, "cg_its": info.get("its"), "rel_residual": info.get("rel_res"), "fx": info.get("fx"),
+                   "n_dof": ndof, "coarse_solve": "direct (%d rows)" % le.coarse_direct_active() if coarse_is_direct else "chebyshev(%d)" % a.ncoarse,
+                   "cg_its": info.get("its"), "rel_residual": info.get("rel_res"), "fx": info.get("fx"),
                    # SURVEY 8(d) secondary metrics: Krylov work rate (KSPSolve only, assembly/setup excluded) and the
                    # MMA update that follows the measured path in the optimisation loop (not part of `value`)
                    "solver_dof_its_per_s": ndof * info.get("solve_its", 0) / max(info.get("solve_s", 0.0), 1e-30),
@@ -468,7 +477,7 @@ def main():
     if other is not None:
         out["other_scaling"] = other
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.cpu_sample, a.rtol, a.fine_eig, (ex, ey, ezg), ndof, a.cpu_budget, nlv, a.nsmooth, a.ncoarse, a.cycles)
+        out["cpu_baseline"] = cpu_baseline(a.cpu_sample, a.rtol, a.fine_eig, (ex, ey, ezg), ndof, a.cpu_budget, nlv, a.nsmooth, a.ncoarse, a.cycles, coarse_is_direct)
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -175,6 +175,11 @@ typedef struct tp_solver_opts {
     int coarse_pc;       /* PC of the coarse solve, :731 */
     int coarse_restart;  /* :632 (30) */
     double coarse_rtol;  /* :628 (1e-8) */
+    /* ksp_mode 0, coarsest level: 0 = Chebyshev run of ncoarse steps on [smallest Ritz value, cheb_hi * largest];
+     * 1 = exact solve (banded Cholesky + explicit triangular inverse, csrc/coarse_direct.h) where the level has at most
+     * 4096 rows on one rank (or is replicated) -- closer to the reference's coarse KSP to rtol 1e-8 (:628-632) than a
+     * fixed polynomial; other levels / larger coarsest grids fall back to 0 */
+    int coarse_direct;
 } tp_solver_opts;
 void tp_solver_default_opts(tp_solver_opts *o);
 
@@ -228,6 +233,9 @@ double tp_elasticity_level_lambda(const tp_elasticity *e, int level);
 /* lower end of the Chebyshev window of the coarsest level (smallest Ritz value of its 40-step Lanczos run; the reference
  * has GMRES there and needs no window: /root/reference/src/LinearElasticity.cc:760-790); 0 on the other levels */
 double tp_elasticity_level_lambda_min(const tp_elasticity *e, int level);
+/* rows of the coarsest level if the last assembly factored it for the exact coarse solve (tp_solver_opts.coarse_direct),
+ * 0 if the Chebyshev run is in use (option off, level too large or distributed) */
+int tp_elasticity_coarse_direct_active(const tp_elasticity *e);
 int tp_elasticity_level_apply(tp_elasticity *e, int level, const double *u, double *y); /* [dev, level local dofs] */
 int tp_elasticity_level_diag(tp_elasticity *e, int level, double *d);
 int tp_elasticity_precond(tp_elasticity *e, const double *r, double *z); /* one V-cycle */

@@ -39,6 +39,7 @@ def lib():
         L.orc_mg_create.argtypes = [C.c_int] * 7 + [C.c_double] * 2
         L.orc_mg_destroy.argtypes = [C.c_void_p]
         L.orc_mg_set_fine_eig.argtypes = [C.c_void_p, C.c_int]
+        L.orc_mg_set_coarse_direct.argtypes = [C.c_void_p, C.c_int]
         L.orc_mg_fine_matfree.argtypes = [C.c_void_p] * 4
         L.orc_mg_set_cycles.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_mg_assemble.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -189,6 +190,10 @@ class MG:
         if getattr(self, "h", None):
             self.L.orc_mg_destroy(self.h)
             self.h = None
+
+    def set_coarse_direct(self, on=True):
+        """coarsest level solved exactly (banded Cholesky) instead of the Chebyshev run; takes effect at the next assemble()"""
+        self.L.orc_mg_set_coarse_direct(self.h, int(on))
 
     def set_cycles(self, cycles):
         """cycles[l] cycles of level l + 1 per visit of level l (l = 0 finest): 1 = V, 2 = W (PCMGSetCycleTypeOnLevel)"""

@@ -633,6 +633,11 @@ typedef struct {
     int nsmooth, ncoarse, nlanczos, nlanczos_coarse, fine_eig;
     double cheb_lo, cheb_hi;
     int cycles[MAXLV]; /* cycles[l]: how often level l + 1 is cycled from level l (1 = V, 2 = W; PCMGSetCycleTypeOnLevel) */
+    /* coarsest level solved exactly (the reference's coarse KSP runs to rtol 1e-8, LinearElasticity.cc:628-632; the
+     * product's csrc/coarse_direct.h): banded Cholesky factor, row i holds columns i - hb .. i */
+    int coarse_direct;
+    long chol_hb;
+    double *chol;
 } orc_mg_t;
 
 /* largest eigenvalue of the symmetric tridiagonal (a[0..m-1], b[0..m-2]) by
@@ -812,6 +817,57 @@ ORC_API orc_mg_t *orc_mg_create(int nx, int ny, int nz, int dof, int nlv, int ns
 }
 
 ORC_API void orc_mg_set_fine_eig(orc_mg_t *s, int mode) { s->fine_eig = mode; }
+/* coarsest level: 0 = Chebyshev run of ncoarse steps, 1 = exact solve (takes effect at the next orc_mg_assemble) */
+ORC_API void orc_mg_set_coarse_direct(orc_mg_t *s, int on) { s->coarse_direct = on; }
+
+/* A = L L^T for the banded SPD matrix of the coarsest level; returns 0 or -1 (non-positive pivot) */
+static int chol_band_factor(orc_mg_t *s) {
+    const csr_t *A = s->A[s->nlv - 1];
+    long n = A->nrow, hb = 0;
+    for (long r = 0; r < n; r++)
+        for (long p = A->rp[r]; p < A->rp[r + 1]; p++)
+            if (r - A->ci[p] > hb) hb = r - A->ci[p];
+    free(s->chol);
+    s->chol_hb = hb;
+    s->chol    = (double *)xcalloc((size_t)n * (size_t)(hb + 1), sizeof(double));
+    double *L  = s->chol;
+#define LB(i, j) L[(size_t)(i) * (size_t)(hb + 1) + (size_t)((j) - (i) + hb)]
+    for (long r = 0; r < n; r++)
+        for (long p = A->rp[r]; p < A->rp[r + 1]; p++)
+            if (A->ci[p] <= r) LB(r, A->ci[p]) = A->v[p];
+    for (long i = 0; i < n; i++) {
+        long j0 = i - hb < 0 ? 0 : i - hb;
+        for (long j = j0; j <= i; j++) {
+            long k0  = j - hb < j0 ? j0 : j - hb;
+            double t = LB(i, j);
+            for (long k = k0; k < j; k++) t -= LB(i, k) * LB(j, k);
+            if (j < i) {
+                LB(i, j) = t / LB(j, j);
+            } else {
+                if (!(t > 0.0)) return -1;
+                LB(i, i) = sqrt(t);
+            }
+        }
+    }
+    return 0;
+}
+static void chol_band_solve(const orc_mg_t *s, const double *b, double *x) {
+    long n = s->A[s->nlv - 1]->nrow, hb = s->chol_hb;
+    const double *L = s->chol;
+    for (long i = 0; i < n; i++) {
+        long j0  = i - hb < 0 ? 0 : i - hb;
+        double t = b[i];
+        for (long j = j0; j < i; j++) t -= LB(i, j) * x[j];
+        x[i] = t / LB(i, i);
+    }
+    for (long i = n - 1; i >= 0; i--) {
+        long j1  = i + hb > n - 1 ? n - 1 : i + hb;
+        double t = x[i];
+        for (long j = i + 1; j <= j1; j++) t -= LB(j, i) * x[j];
+        x[i] = t / LB(i, i);
+    }
+#undef LB
+}
 /* CPU baseline only: from now on the fine-level operator of THIS hierarchy (dof 3) is applied matrix-free from KE, E, N
  * (caller keeps the arrays alive); NULL KE switches back to the assembled matrix.  One hierarchy at a time. */
 ORC_API void orc_mg_fine_matfree(orc_mg_t *s, const double *KE, const double *E, const double *N) {
@@ -839,6 +895,7 @@ ORC_API void orc_mg_destroy(orc_mg_t *s) {
         free(s->r[l]);
         free(s->d[l]);
     }
+    free(s->chol);
     free(s);
 }
 
@@ -871,6 +928,9 @@ ORC_API void orc_mg_assemble(orc_mg_t *s, const double *KE, const double *E, con
         if (l == 0 && !s->fine_eig) {
             double lb = elem_lambda_bound(8 * s->dof, KE);
             s->lam[0] = lb > 1.0 ? lb : 1.0;
+        } else if (l == s->nlv - 1 && l > 0 && s->coarse_direct) {
+            s->lam[l] = s->lam_min[l] = 1.0; /* not used */
+            if (chol_band_factor(s)) s->lam[l] = s->lam_min[l] = NAN;
         } else if (l == s->nlv - 1 && l > 0) {
             /* coarsest level: the Chebyshev iteration there is a SOLVE (the reference uses a Krylov
              * method, LinearElasticity.cc:720-731), so its window spans the whole spectrum:
@@ -921,6 +981,10 @@ static void mcycle(orc_mg_t *s, int l, int zero_guess) {
     long n         = A->nrow;
     double lmin = s->cheb_lo * s->lam[l], lmax = s->cheb_hi * s->lam[l];
     if (l == s->nlv - 1) {
+        if (l > 0 && s->coarse_direct) {
+            chol_band_solve(s, s->b[l], s->x[l]);
+            return;
+        }
         if (l > 0) lmin = s->lam_min[l];
         cheb_smooth(A, s->dinv[l], s->b[l], s->x[l], s->r[l], s->d[l], s->ncoarse, lmin, lmax, zero_guess);
         return;

@@ -569,3 +569,41 @@ def test_random_dirichlet_sets(tp, orc, seed, frac):
     assert rel(host(le.U), Uo) <= 1e-7
     k = min(10, its)
     assert np.abs(le.last_hist[:k] / hist_o[:k] - 1).max() <= 1e-8
+
+
+@pytest.mark.parametrize("mesh,nlv,cycles", [((64, 32, 32), 4, (1, 2, 1)), ((48, 24, 24), 3, (1, 1)), ((64, 64, 64), 4, (1, 2, 2)),
+                                             ((40, 40, 24), 3, (2, 1)), ((32, 32, 32), 3, (1, 1))])
+def test_coarsest_level_solved_exactly(tp, orc, mesh, nlv, cycles):
+    """SolverOptions.coarse_direct (csrc/coarse_direct.h): the coarsest level's Chebyshev run replaced by
+    x = W^T (W b), W the explicit inverse of the banded Cholesky factor computed per assembly.  The solve itself
+    (residual against the level's operator), the V-/W-cycle and the whole CG history against the oracle's banded
+    Cholesky (oracle: chol_band_factor / chol_band_solve), for band widths of 6 .. 13 blocks and a padded last block."""
+    ex, ey, ez = mesh
+    nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
+    grid = tp.Grid(nx, ny, nz, h)
+    le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=nlv, nsmooth=2, ncoarse=20, rtol=1e-6, max_it=300, coarse_direct=1))
+    le.set_cycles(list(cycles))
+    le.SetUpLoadAndBC()
+    x = orc.synth_density(ex, ey, ez, h)
+    KE = orc.hex8_ke_box(h, h, h, 0.3)
+    N, R = orc.cantilever_bc(nx, ny, nz, h)
+    mg = orc.MG(nx, ny, nz, 3, nlv, 2, 20)
+    mg.set_coarse_direct(True)
+    mg.set_cycles(list(cycles))
+    mg.assemble(KE, orc.simp(x), N)
+    for rep in range(2):   # the factor is rebuilt per assembly; the control block must come back clean
+        le.AssembleStiffnessMatrix(dev(x), 1e-9, 1.0, 3.0)
+    lc = nlv - 1
+    rng = np.random.default_rng(5)
+    b = rng.standard_normal(mg.size(lc))
+    xs = host(le.smooth(lc, dev(b), dev(np.zeros_like(b)), 20, True))
+    assert rel(host(le.level_apply(lc, dev(xs))), b) <= 1e-10, "not the solution of the coarsest system"
+    assert rel(mg.apply(lc, xs), b) <= 1e-10
+    r = rng.standard_normal(mg.n)
+    assert rel(host(le.precond(dev(r))), mg.precond(r)) <= 1e-10
+    its = le.KSPSolve(hist_cap=300)
+    Uo, its_o, hist_o = mg.solve(R * N, rtol=1e-6, maxit=300)
+    assert its == its_o < 300
+    assert np.abs(le.last_hist / hist_o - 1).max() <= 1e-6
+    assert rel(host(le.U), Uo) <= 1e-9
+    assert le.coarse_direct_active() == mg.size(lc)

@@ -61,6 +61,9 @@ class SolverOptions:
     coarse_pc: int = 1
     coarse_restart: int = 30
     coarse_rtol: float = 1.0e-8
+    # ksp_mode 0: coarsest level solved exactly (banded Cholesky + explicit triangular inverse, csrc/coarse_direct.h) where it
+    # has at most 4096 rows on one rank; 0: Chebyshev run of ncoarse steps
+    coarse_direct: int = 0
 
     @classmethod
     def reference_elasticity(cls, **kw):
@@ -77,7 +80,8 @@ class SolverOptions:
     def c_struct(self):
         return _lib.SolverOpts(self.nlvls, self.nu, self.rtol, self.atol, self.dtol, self.max_it, self.nsmooth,
                                self.ncoarse, self.cheb_lo, self.cheb_hi, self.nlanczos, self.fine_eig, self.ksp_mode,
-                               self.restart, self.smooth_pc, self.coarse_pc, self.coarse_restart, self.coarse_rtol)
+                               self.restart, self.smooth_pc, self.coarse_pc, self.coarse_restart, self.coarse_rtol,
+                               self.coarse_direct)
 
 
 class Grid:
@@ -307,6 +311,10 @@ class LinearElasticity:
 
     def level_lambda_min(self, l):
         return self.L.tp_elasticity_level_lambda_min(self.handle, l)
+
+    def coarse_direct_active(self):
+        """rows of the coarsest level if the last assembly factored it (SolverOptions.coarse_direct), else 0"""
+        return self.L.tp_elasticity_coarse_direct_active(self.handle)
 
     def level_vec(self, l):
         return torch.zeros(3 * self.level_nodes(l), dtype=torch.float64, device=self.grid.device)

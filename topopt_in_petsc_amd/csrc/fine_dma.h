@@ -185,6 +185,7 @@ __device__ __forceinline__ void fine_dma_run(const TileArgs &t, const NodeArgs &
     const int oddU0 = (bx - 1 + t.nx * ej) & 1, oddU1 = oddU0 ^ (t.nx & 1);
     const int oddE = (bx - 1 + t.ex * ej) & 1, oddEd = oddE ^ (t.ex & 1);
     const unsigned aU0 = (unsigned)((ty * S::ROWW_U + 3 * tx) * 8), aU1 = aU0 + S::ROWW_U * 8;
+    (void)aU1;
     const unsigned aE = (unsigned)((ty * S::ROWW_E + tx) * 8);
 
     const double *xend = a.x + 3 * plane * t.nzl, *Eend = t.E + lay * t.ezl;

@@ -11,6 +11,7 @@
 #include "matfree_tile.h"
 #include "fine_tile.h"
 #include "fine_u4.h"
+#include "coarse_direct.h"
 
 enum { LV_MATFREE = 0, LV_DIA = 1, LV_MACRO = 2 };
 
@@ -323,6 +324,9 @@ struct MGSolver {
         // One rank: the estimates of the levels are independent chains of small kernels -> one stream per level,
         // forked from and joined to the solver's stream (the device overlaps their launch-latency-bound steps).
         static const bool serial = getenv("TP_LANCZOS_SERIAL") != nullptr;
+        // the coarsest level solved exactly needs no window: its factorisation takes the place of its Lanczos run
+        const bool direct = coarse_direct_ok();
+        cd.factored = false;
         if (!grid->has_comm && !serial && nlv - first_level >= 2) {
             hipStream_t main = grid->stream;
             if (!lan_fork) TP_HIP(hipEventCreateWithFlags(&lan_fork, hipEventDisableTiming));
@@ -334,7 +338,7 @@ struct MGSolver {
                 TP_HIP(hipStreamWaitEvent(lan_stream[l], lan_fork, 0));
                 const int steps = (l == nlv - 1 && l > 0) ? NLANCZOS_COARSE : opt.nlanczos;
                 grid->stream = lan_stream[l];  // everything the run launches goes to the level's stream
-                rc = lanczos_graph(l, steps);
+                rc = (direct && l == nlv - 1) ? coarse_direct_factor() : lanczos_graph(l, steps);
                 grid->stream = main;
                 if (rc == TP_OK && hipEventRecord(lan_done[l], lan_stream[l]) != hipSuccess) rc = TP_ERR_HIP;
             }
@@ -344,7 +348,9 @@ struct MGSolver {
                 if (lan_stream[l]) (void)hipStreamSynchronize(lan_stream[l]);
             if (rc) return rc;
             for (int l = first_level; l < nlv; l++) {
-                if (l == nlv - 1 && l > 0)
+                if (direct && l == nlv - 1)
+                    lv[l].lam = lv[l].lam_min = 1.0;  // (not used)
+                else if (l == nlv - 1 && l > 0)
                     lanczos_finish(l, &lv[l].lam, &lv[l].lam_min);
                 else
                     lanczos_finish(l, &lv[l].lam);
@@ -352,7 +358,11 @@ struct MGSolver {
             return TP_OK;
         }
         for (int l = first_level; l < nlv; l++) {
-            if (l == nlv - 1 && l > 0) {
+            if (l == nlv - 1 && l > 0 && direct) {
+                TP_TRY(coarse_direct_factor());
+                lv[l].lam = lv[l].lam_min = 1.0;
+                if (replicate) lv[nlv].lam = lv[nlv].lam_min = 1.0;
+            } else if (l == nlv - 1 && l > 0) {
                 if (replicate) {  // same operator, same hashed start vector, no communication
                     TP_TRY(lanczos(nlv, NLANCZOS_COARSE, &lv[nlv].lam, &lv[nlv].lam_min));
                     lv[l].lam = lv[nlv].lam;
@@ -422,6 +432,7 @@ struct MGSolver {
         run_ctl = nullptr;
         (void)hipFree(lan_ctl);
         lan_ctl = nullptr;
+        coarse_direct_free();
         for (LanBuf &b : lan) {
             (void)hipFree(b.V);
             (void)hipFree(b.coef);
@@ -832,6 +843,80 @@ struct MGSolver {
         *victim = ng;
         return TP_OK;
     }
+    // ---- the coarsest level solved exactly (coarse_direct.h): opt.coarse_direct, one rank or the replicated copy
+    struct CoarseDirect {
+        CdGeom g{};
+        double *Lb = nullptr, *Linv = nullptr, *W = nullptr, *Wt = nullptr, *y = nullptr;
+        XcdRunCtrl *ctl = nullptr;
+        int level = -1;       // the level the factor belongs to (nlv - 1, or nlv: the replicated copy)
+        bool factored = false;
+    } cd;
+    int cd_level() const { return replicate ? nlv : nlv - 1; }
+    bool coarse_direct_ok() const {
+        if (!opt.coarse_direct || getenv("TP_NO_COARSE_DIRECT") || nlv < 2 || DOF != 3) return false;
+        const Level<DOF> &L = lv[cd_level()];
+        if (L.kind != LV_DIA || (grid->has_comm && !L.no_comm) || L.own_n() != L.ndof() || L.ndof() > CD_MAXROWS) return false;
+        const long hb = (long)DOF * (L.g.plane() + L.g.nx + 1) + DOF - 1;
+        const int KB = (int)((hb + CD_NB - 1) / CD_NB);
+        return KB >= 1 && KB <= CD_KBMAX && L.ndof() >= 4 * CD_NB;
+    }
+    void coarse_direct_free() {
+        for (double **p : {&cd.Lb, &cd.Linv, &cd.W, &cd.Wt, &cd.y}) {
+            (void)hipFree(*p);
+            *p = nullptr;
+        }
+        (void)hipFree(cd.ctl);
+        cd.ctl = nullptr;
+        cd.factored = false;
+        cd.level = -1;
+    }
+    // factor + invert on grid->stream (the caller puts it on a stream of its own beside the spectra chains)
+    int coarse_direct_factor() {
+        const int l = cd_level();
+        Level<DOF> &L = lv[l];
+        hipStream_t s = grid->stream;
+        CdGeom g;
+        g.n = (int)L.ndof();
+        g.np = (g.n + CD_NB - 1) / CD_NB * CD_NB;
+        g.nblk = g.np / CD_NB;
+        g.KB = (int)(((long)DOF * (L.g.plane() + L.g.nx + 1) + DOF - 1 + CD_NB - 1) / CD_NB);
+        if (cd.level != l || cd.g.np != g.np || cd.g.KB != g.KB) {
+            coarse_direct_free();
+            TP_HIP(hipMalloc((void **)&cd.Lb, sizeof(double) * (size_t)g.nblk * (g.KB + 1) * CD_NB * CD_NB));
+            TP_HIP(hipMalloc((void **)&cd.Linv, sizeof(double) * (size_t)g.nblk * CD_NB * CD_NB));
+            TP_HIP(hipMalloc((void **)&cd.W, sizeof(double) * (size_t)g.np * g.np));
+            TP_HIP(hipMalloc((void **)&cd.Wt, sizeof(double) * (size_t)g.np * g.np));
+            TP_HIP(hipMalloc((void **)&cd.y, sizeof(double) * (size_t)g.np));
+            TP_HIP(hipMalloc((void **)&cd.ctl, sizeof(XcdRunCtrl)));
+            TP_HIP(hipMemsetAsync(cd.ctl, 0, sizeof(XcdRunCtrl), s));
+            cd.level = l;
+        }
+        cd.g = g;
+        TP_HIP(hipMemsetAsync(cd.Lb, 0, sizeof(double) * (size_t)g.nblk * (g.KB + 1) * CD_NB * CD_NB, s));
+        DiaOp<DOF> o{L.S, L.ndof(), L.g};
+        TP_LAUNCH((k_cd_fill<DOF>), dim3((g.np + CD_T - 1) / CD_T), dim3(CD_T), 0, s, o, g, cd.Lb);
+        const int P = g.KB + 1;
+        static const int stages = getenv("TP_CD_STAGES") ? atoi(getenv("TP_CD_STAGES")) : 3;  // (timing aid: 1 fill, 2 + factor, 3 all)
+        if (stages >= 2) TP_LAUNCH(k_cd_factor, dim3(8 * P), dim3(CD_T), 0, s, g, cd.Lb, cd.Linv, cd.ctl, P);
+        if (stages >= 3) TP_LAUNCH(k_cd_invert, dim3(g.nblk), dim3(CD_T), 0, s, g, cd.Lb, cd.Linv, cd.W, cd.Wt);
+        grid->launches += 3;
+        const double nb2 = (double)g.np * g.np;
+        grid->alg_bytes += 8.0 * (27.0 * DOF * DOF * L.g.nodes() + nb2);  // stencil in, W and W^T (lower halves) out
+        grid->flops += (double)g.np * g.KB * CD_NB * (g.KB * CD_NB + g.np);  // band Cholesky + triangular inverse
+        cd.factored = true;
+        return TP_OK;
+    }
+    // x = A^-1 b on level cd.level
+    int coarse_direct_apply(int l, const double *b) {
+        Level<DOF> &L = lv[l];
+        const int rows_per = CD_T / WAVE, nb = (cd.g.n + rows_per - 1) / rows_per;
+        TP_LAUNCH(k_cd_tri<false>, dim3(nb), dim3(CD_T), 0, grid->stream, cd.g, cd.W, b, cd.y);
+        TP_LAUNCH(k_cd_tri<true>, dim3(nb), dim3(CD_T), 0, grid->stream, cd.g, cd.Wt, cd.y, L.x);
+        grid->launches += 2;
+        grid->alg_bytes += 8.0 * ((double)cd.g.n * cd.g.n + 4.0 * cd.g.n);
+        grid->flops += 2.0 * (double)cd.g.n * cd.g.n;
+        return TP_OK;
+    }
     // ---- the coarsest level's run in one launch (coarse_run.h)
     unsigned long long *run_cnt = nullptr;  // [dev] arrival counter (monotone over the runs) + give-up flag
     XcdRunCtrl *run_ctl = nullptr;          // [dev] control block of the one-XCD run (zero between runs)
@@ -943,6 +1028,7 @@ struct MGSolver {
             return TP_OK;
         }
         Level<DOF> &L = lv[l];
+        if (cd.factored && l == cd.level && dot_slot < 0) return coarse_direct_apply(l, b);
         double theta, delta;
         cheb_window(l, &theta, &delta);
         if (!sg_capturing && dot_slot < 0 && k >= 8 && L.kind == LV_DIA && (L.no_comm || !grid->has_comm) && smooth_graphs_on())
@@ -1084,7 +1170,7 @@ struct MGSolver {
         // the restriction also takes the coarse level's first Chebyshev step from the zero guess (one launch less per
         // level and V-cycle); not when the coarse level is the replicated copy, whose right-hand side is gathered first
         static const bool no_fuse_first = getenv("TP_NO_FUSE_FIRST") != nullptr;
-        const bool fuse_first = !no_fuse_first && !(replicate && l + 1 == nlv - 1) &&
+        const bool fuse_first = !no_fuse_first && !(replicate && l + 1 == nlv - 1) && !(cd.factored && l + 1 == nlv - 1) &&
                                 (l + 1 == nlv - 1 ? opt.ncoarse : opt.nsmooth) >= 1;
         double th = 1.0, de = 1.0;
         if (fuse_first) cheb_window(l + 1, &th, &de);
@@ -1413,6 +1499,7 @@ struct MGSolver {
         }
         if (rc == TP_ERR_DIVERGED && run_ctl) TP_HIP(hipMemsetAsync(run_ctl, 0, sizeof(XcdRunCtrl), s));
         if (rc == TP_ERR_DIVERGED && lan_ctl) TP_HIP(hipMemsetAsync(lan_ctl, 0, sizeof(XcdRunCtrl), s));
+        if (rc == TP_ERR_DIVERGED && cd.ctl) TP_HIP(hipMemsetAsync(cd.ctl, 0, sizeof(XcdRunCtrl), s));
         if (its_out) *its_out = its;
         if (rnorm_out) *rnorm_out = rnorm;
         return rc;

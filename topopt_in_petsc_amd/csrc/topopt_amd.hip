@@ -414,6 +414,7 @@ extern "C" void tp_solver_default_opts(tp_solver_opts *o) {
     o->coarse_pc = 1;        // :731 PCSOR
     o->coarse_restart = 30;  // :632
     o->coarse_rtol = 1.0e-8; // :628
+    o->coarse_direct = 0;
 }
 
 struct tp_elasticity {
@@ -1031,6 +1032,7 @@ extern "C" int tp_elasticity_level_count(const tp_elasticity *e) { return e->mg.
 extern "C" long tp_elasticity_level_nodes(const tp_elasticity *e, int l) { return e->mg.lv[l].g.nodes(); }
 extern "C" double tp_elasticity_level_lambda(const tp_elasticity *e, int l) { return e->mg.lv[l].lam; }
 extern "C" double tp_elasticity_level_lambda_min(const tp_elasticity *e, int l) { return e->mg.lv[l].lam_min; }
+extern "C" int tp_elasticity_coarse_direct_active(const tp_elasticity *e) { return e->assembled && e->mg.cd.factored ? e->mg.cd.g.n : 0; }
 extern "C" int tp_elasticity_level_apply(tp_elasticity *e, int l, const double *u, double *y) {
     if (!e->assembled || l < 0 || l >= e->mg.nlv) return TP_ERR_STATE;
     return e->mg.apply(l, const_cast<double *>(u), y);

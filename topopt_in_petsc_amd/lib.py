@@ -34,7 +34,7 @@ class SolverOpts(C.Structure):
                 ("dtol", C.c_double), ("max_it", C.c_int), ("nsmooth", C.c_int), ("ncoarse", C.c_int),
                 ("cheb_lo", C.c_double), ("cheb_hi", C.c_double), ("nlanczos", C.c_int), ("fine_eig", C.c_int),
                 ("ksp_mode", C.c_int), ("restart", C.c_int), ("smooth_pc", C.c_int), ("coarse_pc", C.c_int),
-                ("coarse_restart", C.c_int), ("coarse_rtol", C.c_double)]
+                ("coarse_restart", C.c_int), ("coarse_rtol", C.c_double), ("coarse_direct", C.c_int)]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_long)
@@ -97,6 +97,7 @@ SYMBOLS = {
     "tp_elasticity_level_nodes": (_l, [_vp, _i]),
     "tp_elasticity_level_lambda": (_d, [_vp, _i]),
     "tp_elasticity_level_lambda_min": (_d, [_vp, _i]),
+    "tp_elasticity_coarse_direct_active": (_i, [_vp]),
     "tp_elasticity_level_apply": (_i, [_vp, _i, _vp, _vp]),
     "tp_elasticity_level_diag": (_i, [_vp, _i, _vp]),
     "tp_elasticity_set_cycles": (_i, [_vp, _vp, _i]),
