@@ -54,7 +54,7 @@ def parse():
     p.add_argument("--nlvls", type=int, default=0, help="override the multigrid depth of the workload")
     p.add_argument("--ncoarse", type=int, default=0, help="coarse-solve Chebyshev steps (0: the workload's)")
     p.add_argument("--nsmooth", type=int, default=0, help="Chebyshev steps per smoothing sweep (0: the workload's)")
-    p.add_argument("--coarse", default="cheb", choices=["direct", "cheb"],
+    p.add_argument("--coarse", default="direct", choices=["direct", "cheb"],
                    help="coarsest level: exact solve (banded Cholesky + explicit triangular inverse per assembly, where the level has <= 4096 rows; else falls back) or the Chebyshev run of --ncoarse steps")
     p.add_argument("--cycles", default="", help="cycles of the next coarser level per level, finest first, e.g. 1,2,2 (1 = V, 2 = W)")
     p.add_argument("--spmv-reps", type=int, default=50)

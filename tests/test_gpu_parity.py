@@ -572,12 +572,12 @@ def test_random_dirichlet_sets(tp, orc, seed, frac):
 
 
 @pytest.mark.parametrize("mesh,nlv,cycles", [((64, 32, 32), 4, (1, 2, 1)), ((48, 24, 24), 3, (1, 1)), ((64, 64, 64), 4, (1, 2, 2)),
-                                             ((40, 40, 24), 3, (2, 1)), ((32, 32, 32), 3, (1, 1))])
+                                             ((24, 40, 24), 3, (2, 1)), ((32, 32, 32), 3, (1, 1))])
 def test_coarsest_level_solved_exactly(tp, orc, mesh, nlv, cycles):
     """SolverOptions.coarse_direct (csrc/coarse_direct.h): the coarsest level's Chebyshev run replaced by
     x = W^T (W b), W the explicit inverse of the banded Cholesky factor computed per assembly.  The solve itself
     (residual against the level's operator), the V-/W-cycle and the whole CG history against the oracle's banded
-    Cholesky (oracle: chol_band_factor / chol_band_solve), for band widths of 6 .. 13 blocks and a padded last block."""
+    Cholesky (oracle: chol_band_factor / chol_band_solve), for band widths of 6 .. 10 blocks and a padded last block."""
     ex, ey, ez = mesh
     nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
     grid = tp.Grid(nx, ny, nz, h)
@@ -607,3 +607,19 @@ def test_coarsest_level_solved_exactly(tp, orc, mesh, nlv, cycles):
     assert np.abs(le.last_hist / hist_o - 1).max() <= 1e-6
     assert rel(host(le.U), Uo) <= 1e-9
     assert le.coarse_direct_active() == mg.size(lc)
+
+
+def test_coarsest_level_too_wide_for_the_exact_solve_falls_back(tp, orc):
+    """coarsest grid 11 x 11 x 7: half bandwidth 401 = 13 blocks, more than the factorisation keeps in LDS -> the Chebyshev
+    run, as if the option were off"""
+    ex, ey, ez = 40, 40, 24
+    grid = tp.Grid(ex + 1, ey + 1, ez + 1, 1.0 / ey)
+    res = []
+    for cd in (1, 0):
+        le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=3, nsmooth=2, ncoarse=20, coarse_direct=cd))
+        le.SetUpLoadAndBC()
+        le.AssembleStiffnessMatrix(grid.synth_density(3), 1e-9, 1.0, 3.0)
+        assert le.coarse_direct_active() == 0
+        its = le.KSPSolve()
+        res.append((host(le.U), its))
+    assert res[0][1] == res[1][1] and np.array_equal(res[0][0], res[1][0])

@@ -9,28 +9,35 @@
 // i.e. two triangular matrix-vector products per visit -- no dependent chain, 2 x 19 MB read by the whole device --
 // at the price of a factorisation per design iteration, which runs on a stream of its own beside the spectra estimates of
 // the other levels:
-//   k_cd_fill     stencil (DIA) rows -> block-band storage of the lower triangle;
-//   k_cd_factor   left-looking block Cholesky; the KB+1 tiles of a block column are computed by KB+1 workgroups that sit on
-//                 ONE XCD (join protocol and barrier of coarse_run.h; two barriers per block column); the workgroup of the
-//                 diagonal tile factors it and inverts the 32 x 32 factor, the others multiply with that inverse;
+//   k_cd_fill     stencil (DIA) rows -> block-band storage of the lower triangle (32 x 32 blocks, stored transposed);
+//   k_cd_factor   block Cholesky, left-looking per tile.  KB+1 workgroups on ONE XCD (join protocol and barrier of
+//                 coarse_run.h); a workgroup OWNS a row block (i -> workgroup i mod (KB+1)) and walks its tiles left to right
+//                 with the row block's finished tiles in LDS.  Per block column k: the owner of row block k finishes the
+//                 diagonal tile (one product of its own data) and factors it in one wave (registers + LDS, no workgroup
+//                 barrier inside); meanwhile the others pre-compute their NEXT tile's sum over the columns already
+//                 published (look-ahead: this is where the flops are, off the critical path); barrier; the others solve
+//                 their tile against the 32 x 32 factor (one wave, row per lane) and publish it; barrier.
+//   k_cd_diag_inv the 32 x 32 diagonal factors inverted (one wave per block);
 //   k_cd_invert   W = L^-1 by block forward substitution, one workgroup per block of 32 columns, no synchronisation
 //                 between workgroups (columns are independent); the last KB row blocks of the workgroup's columns live
 //                 in an LDS ring; also writes W^T;
-//   k_cd_lower / k_cd_upper   y = W b,  x = W^T y: one wave per row.
+//   k_cd_tri      y = W b,  x = W^T y: one wave per row.
+// The 32 x 32 x 32 products run one per WAVE on 4 x 4 register tiles (operands transposed in LDS, 16-byte reads: LDS
+// bandwidth is what bounds them), the terms of a sum are dealt to the four waves and added up in a fixed order.
 // Sums are formed in a fixed order: results are reproducible run to run; against the CPU restatement (oracle: banded
 // Cholesky, two substitutions) they differ by rounding only.  A non-positive pivot poisons the factor with NaN, which the
 // Krylov loop reports as divergence.
 #pragma once
 #include "coarse_run.h"
 
-constexpr int CD_NB = 32, CD_T = 256, CD_KBMAX = 16, CD_LD = CD_NB + 1;
+constexpr int CD_NB = 32, CD_T = 256, CD_KBMAX = 12, CD_LD = CD_NB + 1, CD_BLK = CD_NB * CD_NB;
 constexpr int CD_MAXROWS = 4096;
 
 struct CdGeom {
     int n, np, nblk, KB;  // rows, rows padded to whole blocks, blocks, band width in blocks (below the diagonal)
 };
-// block (i, j), i - KB <= j <= i, of the band storage: 32 x 32 doubles, row-major
-__host__ __device__ inline long cd_blk(const CdGeom &c, int i, int j) { return ((long)i * (c.KB + 1) + (j - (i - c.KB))) * (CD_NB * CD_NB); }
+// block (i, j), i - KB <= j <= i, of the band storage: 32 x 32 doubles, TRANSPOSED: element (r, m) at [m * 32 + r]
+__host__ __device__ inline long cd_blk(const CdGeom &c, int i, int j) { return ((long)i * (c.KB + 1) + (j - (i - c.KB))) * CD_BLK; }
 
 template <int DOF>
 __global__ __launch_bounds__(CD_T) void k_cd_fill(DiaOp<DOF> op, CdGeom c, double *__restrict__ Lb) {
@@ -54,21 +61,37 @@ __global__ __launch_bounds__(CD_T) void k_cd_fill(DiaOp<DOF> op, CdGeom c, doubl
                 for (int cc = 0; cc < DOF; cc++) {
                     const long col = nb * DOF + cc;
                     if (col > q) continue;
-                    Lb[cd_blk(c, bi, (int)(col / CD_NB)) + r * CD_NB + (int)(col % CD_NB)] = op.S[(long)(blk * DOF + cc) * op.nrows + q];
+                    Lb[cd_blk(c, bi, (int)(col / CD_NB)) + (int)(col % CD_NB) * CD_NB + r] = op.S[(long)(blk * DOF + cc) * op.nrows + q];
                 }
             }
 }
 
-// 32 bytes per thread of a 32 x 32 block, past the L1 (the block was written by another workgroup of this kernel); the
-// block address is uniform (a descriptor in SGPRs), the thread's place in it the offset
-__device__ inline void cd_load4(const double *block, int t, double v[4]) {
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    typedef unsigned u4 __attribute__((ext_vector_type(4)));
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(block), 0, CD_NB * CD_NB * 8, 0x00020000);
-    const u4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, t * 32, 0, 16 /* sc1 */);
-    const u4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, t * 32 + 16, 0, 16);
-    const d2 x = __builtin_bit_cast(d2, a), y = __builtin_bit_cast(d2, b);
-    v[0] = x[0], v[1] = x[1], v[2] = y[0], v[3] = y[1];
+typedef double cd_d2 __attribute__((ext_vector_type(2)));
+typedef unsigned cd_u4 __attribute__((ext_vector_type(4)));
+
+// one wave copies a published 32 x 32 block (8 KB) into LDS, past the L1: the block was written by another workgroup of
+// this kernel.  The block address is uniform (descriptor in SGPRs), the lane's place in it the offset.
+__device__ inline void cd_stage_block(const double *block, double *lds, int lane) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(block), 0, CD_BLK * 8, 0x00020000);
+    cd_u4 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) v[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (q * WAVE + lane) * 16, 0, 16 /* sc1 */);
+#pragma unroll
+    for (int q = 0; q < 8; q++) reinterpret_cast<cd_u4 *>(lds)[q * WAVE + lane] = v[q];
+}
+// one wave: acc[a][b] += sum_m At[m][4 tr + a] * Bt[m][4 tc + b], lane = 8 tr + tc  (both operands [m][32] in LDS)
+__device__ inline void cd_gemm_nt(double (&acc)[16], const double *At, const double *Bt, int lane) {
+    const int tr = lane >> 3, tc = lane & 7;
+#pragma unroll 4
+    for (int m = 0; m < CD_NB; m++) {
+        const cd_d2 a01 = *reinterpret_cast<const cd_d2 *>(At + m * CD_NB + 4 * tr), a23 = *reinterpret_cast<const cd_d2 *>(At + m * CD_NB + 4 * tr + 2);
+        const cd_d2 b01 = *reinterpret_cast<const cd_d2 *>(Bt + m * CD_NB + 4 * tc), b23 = *reinterpret_cast<const cd_d2 *>(Bt + m * CD_NB + 4 * tc + 2);
+        const double a[4] = {a01[0], a01[1], a23[0], a23[1]}, b[4] = {b01[0], b01[1], b23[0], b23[1]};
+#pragma unroll
+        for (int x = 0; x < 4; x++)
+#pragma unroll
+            for (int y = 0; y < 4; y++) acc[x * 4 + y] = fma(a[x], b[y], acc[x * 4 + y]);
+    }
 }
 
 // reciprocal square root to (almost) full precision without the division / square-root sequences of the compiler
@@ -78,10 +101,17 @@ __device__ inline double cd_rsqrt(double d) {
     y = y * fma(-0.5 * d * y, y, 1.5);
     return y;
 }
+__device__ inline double cd_readlane(double v, int l) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, l), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 
-__global__ __launch_bounds__(CD_T) void k_cd_factor(CdGeom c, double *Lb, double *__restrict__ Linv, XcdRunCtrl *ctl, int P) {
-    __shared__ double sA[CD_NB][CD_LD], sB[CD_NB][CD_LD], sT[CD_NB][CD_LD], sX[CD_NB][CD_LD];
-    __shared__ double s_invd[CD_NB], s_d;
+// Ld: per block column the 32 x 32 diagonal factor, row-major, with the RECIPROCALS of its diagonal on the diagonal
+__global__ __launch_bounds__(CD_T) void k_cd_factor(CdGeom c, double *Lb, double *__restrict__ Ld, XcdRunCtrl *ctl, int P, long long *prof) {
+    __shared__ double sOwn[CD_KBMAX * CD_BLK];  // finished tiles of my row block, transposed, slot j % KB
+    __shared__ double sStage[4 * CD_BLK];       // per wave: the other operand of a product / the wave's partial tile
+    __shared__ double sT[CD_NB * CD_LD], sTn[CD_NB * CD_LD], sD[CD_NB * CD_LD];  // this tile, the next one (look-ahead), diagonal factor
     __shared__ int s_rank, s_dead;
     if (threadIdx.x == 0) s_rank = xcd_join(ctl, P);
     __syncthreads();
@@ -90,169 +120,285 @@ __global__ __launch_bounds__(CD_T) void k_cd_factor(CdGeom c, double *Lb, double
         xcd_leave(ctl);
         return;
     }
-    const int t = threadIdx.x, r = t >> 3, sub = t & 7, c0 = sub * 4;
+    const int t = threadIdx.x, wave = t / WAVE, lane = t & (WAVE - 1);
+    const int tr = lane >> 3, tc = lane & 7;
+    int i = rank;  // my row block; its first tile is (i, max(i - KB, 0)) = (i, 0)
+    // thread's 4 elements of a transposed global block: column m_g, rows r_g .. r_g + 3
+    const int m_g = t >> 3, r_g = (t & 7) * 4;
+    auto load_matrix_tile = [&](int bi, int bj) {  // A tile (bi, bj) -> sTn (row-major, padded)
+        const double *p = Lb + cd_blk(c, bi, bj) + t * 4;
+#pragma unroll
+        for (int e = 0; e < 4; e++) sTn[(r_g + e) * CD_LD + m_g] = p[e];
+    };
+    if (i < c.nblk) load_matrix_tile(i, 0);
+    __syncthreads();
     int nbar = 0;
     bool dead = false;
-    for (int k = 0; k < c.nblk && !dead; k++) {
-        const int i = k + rank;
+    long long tp0 = prof ? wall_clock64() : 0;
+    auto mark = [&](int ph) {  // (timing aid, TP_CD_PROF=1: wall-clock ticks per phase and workgroup)
+        if (prof) {
+            const long long now = wall_clock64();
+            if (threadIdx.x == 0) prof[rank * 8 + ph] += now - tp0;
+            tp0 = now;
+        }
+    };
+    for (int k = 0; k < c.nblk; k++) {
         const bool act = i < c.nblk;
-        double acc[4] = {0, 0, 0, 0};
-        if (act) {
-            const double *At = Lb + cd_blk(c, i, k) + t * 4;  // still the matrix: nobody has written this tile yet
+        const bool diag = act && i == k;
+        mark(7);
+        // ---- (A) finish tile (i, k): the product with block column k - 1 is the one the look-ahead could not have
+        if (wave == 0 && act) {
+            double acc[16];
 #pragma unroll
-            for (int e = 0; e < 4; e++) acc[e] = At[e];
-            const int jlo = max(i - c.KB, 0), nj = k - jlo;
-            double vA[CD_KBMAX][4], vB[CD_KBMAX][4];
-#pragma unroll
-            for (int jj = 0; jj < CD_KBMAX; jj++)
-                if (jj < nj) {
-                    cd_load4(Lb + cd_blk(c, i, jlo + jj), t, vA[jj]);
-                    cd_load4(Lb + cd_blk(c, k, jlo + jj), t, vB[jj]);
+            for (int x = 0; x < 16; x++) acc[x] = 0.0;
+            if (k >= 1 && k - 1 >= i - c.KB) {
+                const double *At = sOwn + ((k - 1) % c.KB) * CD_BLK, *Bt = At;
+                if (!diag) {
+                    cd_stage_block(Lb + cd_blk(c, k, k - 1), sStage, lane);
+                    Bt = sStage;
                 }
+                cd_gemm_nt(acc, At, Bt, lane);
+            }
 #pragma unroll
-            for (int jj = 0; jj < CD_KBMAX; jj++)
-                if (jj < nj) {
-                    __syncthreads();
+            for (int x = 0; x < 4; x++)
 #pragma unroll
-                    for (int e = 0; e < 4; e++) sA[r][c0 + e] = vA[jj][e], sB[r][c0 + e] = vB[jj][e];
-                    __syncthreads();
-#pragma unroll 8
-                    for (int m = 0; m < CD_NB; m++) {
-                        const double a = sA[r][m];
+                for (int y = 0; y < 4; y++) sT[(4 * tr + x) * CD_LD + 4 * tc + y] = sTn[(4 * tr + x) * CD_LD + 4 * tc + y] - acc[x * 4 + y];
+        }
+        __syncthreads();
+        mark(0);
+        // ---- (B) diagonal owner: factor the tile (wave 0); the others: look-ahead, the sum of tile (i, k + 1) over the
+        // block columns published so far (j <= k - 1), terms dealt to the waves
+        const bool la = act && !diag && k + 1 <= i;
+        if (la) {
+            double acc[16];
 #pragma unroll
-                        for (int e = 0; e < 4; e++) acc[e] = fma(-a, sB[c0 + e][m], acc[e]);
+            for (int x = 0; x < 16; x++) acc[x] = 0.0;
+            const int jlo = max(i - c.KB, 0);
+            for (int j = jlo + wave; j <= k - 1; j += 4) {
+                const double *At = sOwn + (j % c.KB) * CD_BLK, *Bt = At;  // (i == k + 1: the next tile is my diagonal one)
+                if (i != k + 1) {
+                    cd_stage_block(Lb + cd_blk(c, k + 1, j), sStage + wave * CD_BLK, lane);
+                    Bt = sStage + wave * CD_BLK;
+                }
+                cd_gemm_nt(acc, At, Bt, lane);
+            }
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+#pragma unroll
+                for (int y = 0; y < 4; y++) sStage[wave * CD_BLK + (4 * tr + x) * CD_NB + 4 * tc + y] = acc[x * 4 + y];
+        }
+        if (diag && wave == 0) {
+            if (lane < CD_NB) {
+                // Right-looking, a row per lane in registers.  Column cc: pivot d = a[cc] of lane cc (readlane), y = 1/sqrt(d),
+                // l = a[cc] y.  The update of the NEXT column (the only one the next pivot waits for) takes its factor from a
+                // readlane; the updates of the columns behind it read the column through LDS (one row of the transposed
+                // factor, 16-byte broadcast reads) and are applied one column late, their latency behind the pivot arithmetic.
+                const int r = lane;
+                double a[CD_NB];
+#pragma unroll
+                for (int cc = 0; cc < CD_NB; cc++) a[cc] = sT[r * CD_LD + cc];
+                double lprev = 0.0;
+#pragma unroll
+                for (int cc = 0; cc < CD_NB; cc++) {
+                    if (cc >= 1) {  // deferred updates with column cc - 1: columns cc + 1 .. 31 (column cc was done by readlane)
+#pragma unroll
+                        for (int c2 = cc + 1; c2 < CD_NB; c2++) a[c2] = fma(-lprev, sStage[(cc - 1) * CD_NB + c2], a[c2]);
                     }
+                    const double d = cd_readlane(a[cc], cc);
+                    const double y = d > 0.0 ? cd_rsqrt(d) : __builtin_nan("");
+                    const double l = a[cc] * y;
+                    sStage[cc * CD_NB + r] = l;  // column cc of the factor, as a row
+                    if (cc + 1 < CD_NB) a[cc + 1] = fma(-l, cd_readlane(l, cc + 1), a[cc + 1]);
+                    sD[r * CD_LD + cc] = r == cc ? y : (r > cc ? l : 0.0);
+                    lprev = l;
                 }
-        }
-        if (rank == 0) {  // the diagonal tile: L_kk L_kk^T = T (lower), then its inverse
-            __syncthreads();
-#pragma unroll
-            for (int e = 0; e < 4; e++) sT[r][c0 + e] = acc[e];
-            __syncthreads();
-            for (int cc = 0; cc < CD_NB; cc++) {
-                double s = 0.0;
-                for (int m = sub; m < cc; m += 8) s = fma(sT[r][m], sT[cc][m], s);
-                s += __shfl_xor(s, 1);
-                s += __shfl_xor(s, 2);
-                s += __shfl_xor(s, 4);
-                const double a = sT[r][cc] - s;
-                if (r == cc && sub == 0) s_d = a;
-                __syncthreads();
-                const double d = s_d;
-                const double y = d > 0.0 ? cd_rsqrt(d) : __builtin_nan("");
-                if (sub == 0) {
-                    if (r == cc) sT[r][cc] = d * y, s_invd[cc] = y;
-                    else if (r > cc) sT[r][cc] = a * y;
-                    else sT[r][cc] = 0.0;
-                }
-                __syncthreads();
             }
-            // X = L_kk^-1, column e = r of this thread group (8 threads per column), rows in sequence
-            const int ecol = r;
-            for (int rr = 0; rr < CD_NB; rr++) {
-                double s = 0.0;
-                for (int m = ecol + sub; m < rr; m += 8) s = fma(sT[rr][m], sX[m][ecol], s);
-                s += __shfl_xor(s, 1);
-                s += __shfl_xor(s, 2);
-                s += __shfl_xor(s, 4);
-                if (sub == 0) sX[rr][ecol] = rr < ecol ? 0.0 : ((rr == ecol ? 1.0 : 0.0) - s) * s_invd[rr];
-                __syncthreads();
-            }
-            double *Lt = Lb + cd_blk(c, k, k) + t * 4, *Xt = Linv + (long)k * (CD_NB * CD_NB) + t * 4;
+            // publish (row-major)
 #pragma unroll
-            for (int e = 0; e < 4; e++) Lt[e] = sT[r][c0 + e], Xt[e] = sX[r][c0 + e];
+            for (int q = 0; q < CD_BLK / WAVE; q++) {
+                const int idx = q * WAVE + lane;
+                Ld[(long)k * CD_BLK + idx] = sD[(idx >> 5) * CD_LD + (idx & 31)];
+            }
         }
+        __syncthreads();
+        if (la) {  // tile (i, k + 1) so far = matrix tile - partial sums (fixed order)
+            const double *p = Lb + cd_blk(c, i, k + 1) + t * 4;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int idx = (r_g + e) * CD_NB + m_g;
+                const double sum = (sStage[idx] + sStage[CD_BLK + idx]) + (sStage[2 * CD_BLK + idx] + sStage[3 * CD_BLK + idx]);
+                sTn[(r_g + e) * CD_LD + m_g] = p[e] - sum;
+            }
+        }
+        mark(diag ? 1 : 2);
         if (xcd_barrier(ctl, nbar++, P, &s_dead)) {
             dead = true;
             break;
         }
-        if (act && rank > 0) {  // L_ik = T L_kk^-T
-            double vX[4];
-            cd_load4(Linv + (long)k * (CD_NB * CD_NB), t, vX);
-            __syncthreads();
+        mark(3);
+        // ---- (C) the others: L_ik = T L_kk^-T (row per lane), into my LDS and out; the owner of k: its next row block
+        if (act && !diag && wave == 0) {
+            double *sDt = sStage;  // (wave 0's staging area: free between the products of (A) and (B))
+            {   // the factor of block column k (row-major, reciprocal diagonal) -> transposed: sDt[m][c] = l_cm
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Ld + (long)k * CD_BLK, 0, CD_BLK * 8, 0x00020000);
+                cd_u4 v[8];
 #pragma unroll
-            for (int e = 0; e < 4; e++) sT[r][c0 + e] = acc[e], sB[r][c0 + e] = vX[e];
-            __syncthreads();
-            double o[4] = {0, 0, 0, 0};
-#pragma unroll 8
-            for (int m = 0; m < CD_NB; m++) {
-                const double a = sT[r][m];
+                for (int q = 0; q < 8; q++) v[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (q * WAVE + lane) * 16, 0, 16 /* sc1 */);
 #pragma unroll
-                for (int e = 0; e < 4; e++) o[e] = fma(a, sB[c0 + e][m], o[e]);
+                for (int q = 0; q < 8; q++) {
+                    const int idx = (q * WAVE + lane) * 2, rr = idx >> 5, cc = idx & 31;
+                    const cd_d2 d = __builtin_bit_cast(cd_d2, v[q]);
+                    sDt[cc * CD_NB + rr] = d[0];
+                    sDt[(cc + 1) * CD_NB + rr] = d[1];
+                }
             }
-            double *Lt = Lb + cd_blk(c, i, k) + t * 4;
+            if (lane < CD_NB) {
+                // x L^T = t, a row per lane: x_m = acc_m / l_mm, then acc_c -= x_m l_cm for c > m (independent updates; the
+                // factors l_cm, c = m + 1 .., are consecutive in the transposed copy: 16-byte broadcast reads)
+                const int r = lane;
+                double x[CD_NB];
 #pragma unroll
-            for (int e = 0; e < 4; e++) Lt[e] = o[e];
+                for (int cc = 0; cc < CD_NB; cc++) x[cc] = sT[r * CD_LD + cc];
+#pragma unroll
+                for (int m = 0; m < CD_NB; m++) {
+                    x[m] = x[m] * sDt[m * CD_NB + m];
+#pragma unroll
+                    for (int c2 = m + 1; c2 < CD_NB; c2++) x[c2] = fma(-x[m], sDt[m * CD_NB + c2], x[c2]);
+                }
+                double *own = sOwn + (k % c.KB) * CD_BLK, *out = Lb + cd_blk(c, i, k);
+#pragma unroll
+                for (int cc = 0; cc < CD_NB; cc++) own[cc * CD_NB + r] = x[cc], out[cc * CD_NB + r] = x[cc];
+            }
         }
+        if (diag) {
+            i = k + P;  // first tile of the new row block: (i, k + 1), no products yet
+            if (i < c.nblk) load_matrix_tile(i, k + 1);
+        }
+        mark(4);
         if (xcd_barrier(ctl, nbar++, P, &s_dead)) {
             dead = true;
             break;
         }
+        mark(5);
     }
-    if (dead && rank == 0 && threadIdx.x == 0) Linv[0] = __builtin_nan("");
+    if (dead && rank == 0 && threadIdx.x == 0) Ld[0] = __builtin_nan("");
     xcd_leave(ctl);
+}
+
+// Linv (stored transposed: element (r, m) at [m * 32 + r]) = inverse of the diagonal factor of block k; one wave per block
+__global__ __launch_bounds__(WAVE) void k_cd_diag_inv(const double *__restrict__ Ld, double *__restrict__ Linv) {
+    __shared__ double sD[CD_NB * CD_LD];
+    const int k = blockIdx.x, lane = threadIdx.x;
+    for (int idx = lane; idx < CD_BLK; idx += WAVE) sD[(idx >> 5) * CD_LD + (idx & 31)] = Ld[(long)k * CD_BLK + idx];
+    __syncthreads();
+    if (lane < CD_NB) {
+        const int e = lane;  // column e of the inverse
+        double x[CD_NB];
+#pragma unroll
+        for (int r = 0; r < CD_NB; r++) {
+            double a0 = r == e ? 1.0 : 0.0, a1 = 0.0;
+#pragma unroll
+            for (int m = 0; m + 1 < r; m += 2) {
+                a0 = fma(-sD[r * CD_LD + m], x[m], a0);
+                a1 = fma(-sD[r * CD_LD + m + 1], x[m + 1], a1);
+            }
+            if (r & 1) a0 = fma(-sD[r * CD_LD + r - 1], x[r - 1], a0);
+            x[r] = r < e ? 0.0 : (a0 + a1) * sD[r * CD_LD + r];  // (the diagonal holds reciprocals)
+        }
+#pragma unroll
+        for (int r = 0; r < CD_NB; r++) Linv[(long)k * CD_BLK + e * CD_NB + r] = x[r];
+    }
 }
 
 // W = L^-1 (and its transpose), block column `cb` per workgroup
 __global__ __launch_bounds__(CD_T) void k_cd_invert(CdGeom c, const double *__restrict__ Lb, const double *__restrict__ Linv,
                                                     double *__restrict__ W, double *__restrict__ Wt) {
-    __shared__ double sW[CD_KBMAX][CD_NB][CD_NB];  // ring: row blocks i - KB .. i - 1 of this block column
-    __shared__ double sA[CD_NB][CD_LD], sT[CD_NB][CD_LD], sI[CD_NB][CD_LD];
-    const int cb = blockIdx.x, t = threadIdx.x, r = t >> 3, sub = t & 7, c0 = sub * 4;
+    __shared__ double sW[CD_KBMAX * CD_BLK];  // ring: row blocks i - KB .. i - 1 of this block column, [m][col]
+    __shared__ double sStage[4 * CD_BLK];     // per wave: L_ij transposed / the wave's partial tile
+    __shared__ double sT[CD_BLK];             // the right-hand side tile [m][col]
+    __shared__ double sO[CD_NB * CD_LD];      // the new row block of W (padded: read by columns for W^T)
+    const int cb = blockIdx.x, t = threadIdx.x, wave = t / WAVE, lane = t & (WAVE - 1);
+    const int tr = lane >> 3, tc = lane & 7;
     const int ring = c.KB;
+    // the factor blocks this wave multiplies with are known in advance (they do not depend on W): the next one is
+    // requested before the current product starts, across the row-block steps as well
+    cd_u4 pre[8];
+    auto first_term = [&](int i) { return max(i - c.KB, cb) + wave; };
+    auto request = [&](int i, int j) {
+        const cd_u4 *src = reinterpret_cast<const cd_u4 *>(Lb + cd_blk(c, i, j));
+#pragma unroll
+        for (int q = 0; q < 8; q++) pre[q] = src[q * WAVE + lane];
+    };
+    {
+        int i0 = cb, j0 = first_term(cb);
+        while (i0 < c.nblk && j0 >= i0) {  // first (row block, term) of this wave
+            i0++;
+            if (i0 < c.nblk) j0 = first_term(i0);
+        }
+        if (i0 < c.nblk) request(i0, j0);
+    }
     for (int i = cb; i < c.nblk; i++) {
-        const int jlo = max(i - c.KB, cb), nj = i - jlo;
-        double vA[CD_KBMAX][4], vI[4];
+        cd_u4 li[8];  // wave 0: the inverse of this row block's diagonal factor, requested a step's work ahead of its use
+        if (wave == 0) {
+            const cd_u4 *src = reinterpret_cast<const cd_u4 *>(Linv + (long)i * CD_BLK);
 #pragma unroll
-        for (int jj = 0; jj < CD_KBMAX; jj++)
-            if (jj < nj) {
-                const double *p = Lb + cd_blk(c, i, jlo + jj) + t * 4;
-#pragma unroll
-                for (int e = 0; e < 4; e++) vA[jj][e] = p[e];
-            }
-        {
-            const double *p = Linv + (long)i * (CD_NB * CD_NB) + t * 4;
-#pragma unroll
-            for (int e = 0; e < 4; e++) vI[e] = p[e];
+            for (int q = 0; q < 8; q++) li[q] = src[q * WAVE + lane];
         }
-        double acc[4];
+        double acc[16];
 #pragma unroll
-        for (int e = 0; e < 4; e++) acc[e] = (i == cb && r == c0 + e) ? 1.0 : 0.0;
+        for (int x = 0; x < 16; x++) acc[x] = 0.0;
+        for (int j = first_term(i); j < i; j += 4) {
+            double *At = sStage + wave * CD_BLK;
 #pragma unroll
-        for (int jj = 0; jj < CD_KBMAX; jj++)
-            if (jj < nj) {
-                __syncthreads();
-#pragma unroll
-                for (int e = 0; e < 4; e++) sA[r][c0 + e] = vA[jj][e];
-                __syncthreads();
-                const double(*Wj)[CD_NB] = sW[(jlo + jj) % ring];
-#pragma unroll 8
-                for (int m = 0; m < CD_NB; m++) {
-                    const double a = sA[r][m];
-#pragma unroll
-                    for (int e = 0; e < 4; e++) acc[e] = fma(-a, Wj[m][c0 + e], acc[e]);
+            for (int q = 0; q < 8; q++) reinterpret_cast<cd_u4 *>(At)[q * WAVE + lane] = pre[q];
+            {   // the wave's next term: in this row block, or the first one of a later row block
+                int in = i, jn = j + 4;
+                while (in < c.nblk && jn >= in) {
+                    in++;
+                    if (in < c.nblk) jn = first_term(in);
                 }
+                if (in < c.nblk) request(in, jn);
             }
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 4; e++) sT[r][c0 + e] = acc[e], sI[r][c0 + e] = vI[e];
-        __syncthreads();
-        double o[4] = {0, 0, 0, 0};
-#pragma unroll 8
-        for (int m = 0; m < CD_NB; m++) {
-            const double a = sI[r][m];
-#pragma unroll
-            for (int e = 0; e < 4; e++) o[e] = fma(a, sT[m][c0 + e], o[e]);
+            cd_gemm_nt(acc, At, sW + (j % ring) * CD_BLK, lane);
         }
-        __syncthreads();  // every read of the slot that is overwritten now (block i - KB) and of sT is done
-        double(*Wi)[CD_NB] = sW[i % ring];
-        double *wp = W + (long)(i * CD_NB + r) * c.np + cb * CD_NB + c0;
 #pragma unroll
-        for (int e = 0; e < 4; e++) Wi[r][c0 + e] = o[e], sT[r][c0 + e] = o[e], wp[e] = o[e];
+        for (int x = 0; x < 4; x++)
+#pragma unroll
+            for (int y = 0; y < 4; y++) sStage[wave * CD_BLK + (4 * tr + x) * CD_NB + 4 * tc + y] = acc[x * 4 + y];
         __syncthreads();
-        double *tp = Wt + (long)(cb * CD_NB + r) * c.np + i * CD_NB + c0;  // row r of the transposed tile
 #pragma unroll
-        for (int e = 0; e < 4; e++) tp[e] = sT[c0 + e][r];
+        for (int e = 0; e < 4; e++) {
+            const int idx = t * 4 + e, r = idx >> 5, col = idx & 31;
+            const double sum = (sStage[idx] + sStage[CD_BLK + idx]) + (sStage[2 * CD_BLK + idx] + sStage[3 * CD_BLK + idx]);
+            sT[idx] = ((i == cb && r == col) ? 1.0 : 0.0) - sum;
+        }
+        __syncthreads();
+        if (wave == 0) {  // W_i = Linv_ii T
+            double *At = sStage;
+#pragma unroll
+            for (int q = 0; q < 8; q++) reinterpret_cast<cd_u4 *>(At)[q * WAVE + lane] = li[q];
+            double o[16];
+#pragma unroll
+            for (int x = 0; x < 16; x++) o[x] = 0.0;
+            cd_gemm_nt(o, At, sT, lane);
+            double *Wi = sW + (i % ring) * CD_BLK;  // (block i - KB: every product of this step is done)
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+#pragma unroll
+                for (int y = 0; y < 4; y++) {
+                    Wi[(4 * tr + x) * CD_NB + 4 * tc + y] = o[x * 4 + y];
+                    sO[(4 * tr + x) * CD_LD + 4 * tc + y] = o[x * 4 + y];
+                }
+        }
+        __syncthreads();
+        {
+            const int r = t >> 3, c0 = (t & 7) * 4;
+            double *wp = W + (long)(i * CD_NB + r) * c.np + cb * CD_NB + c0;
+            double *tp = Wt + (long)(cb * CD_NB + r) * c.np + i * CD_NB + c0;  // row r of the transposed tile
+#pragma unroll
+            for (int e = 0; e < 4; e++) wp[e] = sO[r * CD_LD + c0 + e], tp[e] = sO[(c0 + e) * CD_LD + r];
+        }
+        __syncthreads();
     }
 }
 

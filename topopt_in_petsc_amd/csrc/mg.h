@@ -846,7 +846,7 @@ struct MGSolver {
     // ---- the coarsest level solved exactly (coarse_direct.h): opt.coarse_direct, one rank or the replicated copy
     struct CoarseDirect {
         CdGeom g{};
-        double *Lb = nullptr, *Linv = nullptr, *W = nullptr, *Wt = nullptr, *y = nullptr;
+        double *Lb = nullptr, *Ld = nullptr, *Linv = nullptr, *W = nullptr, *Wt = nullptr, *y = nullptr;
         XcdRunCtrl *ctl = nullptr;
         int level = -1;       // the level the factor belongs to (nlv - 1, or nlv: the replicated copy)
         bool factored = false;
@@ -861,7 +861,7 @@ struct MGSolver {
         return KB >= 1 && KB <= CD_KBMAX && L.ndof() >= 4 * CD_NB;
     }
     void coarse_direct_free() {
-        for (double **p : {&cd.Lb, &cd.Linv, &cd.W, &cd.Wt, &cd.y}) {
+        for (double **p : {&cd.Lb, &cd.Ld, &cd.Linv, &cd.W, &cd.Wt, &cd.y}) {
             (void)hipFree(*p);
             *p = nullptr;
         }
@@ -883,6 +883,7 @@ struct MGSolver {
         if (cd.level != l || cd.g.np != g.np || cd.g.KB != g.KB) {
             coarse_direct_free();
             TP_HIP(hipMalloc((void **)&cd.Lb, sizeof(double) * (size_t)g.nblk * (g.KB + 1) * CD_NB * CD_NB));
+            TP_HIP(hipMalloc((void **)&cd.Ld, sizeof(double) * (size_t)g.nblk * CD_NB * CD_NB));
             TP_HIP(hipMalloc((void **)&cd.Linv, sizeof(double) * (size_t)g.nblk * CD_NB * CD_NB));
             TP_HIP(hipMalloc((void **)&cd.W, sizeof(double) * (size_t)g.np * g.np));
             TP_HIP(hipMalloc((void **)&cd.Wt, sizeof(double) * (size_t)g.np * g.np));
@@ -897,9 +898,30 @@ struct MGSolver {
         TP_LAUNCH((k_cd_fill<DOF>), dim3((g.np + CD_T - 1) / CD_T), dim3(CD_T), 0, s, o, g, cd.Lb);
         const int P = g.KB + 1;
         static const int stages = getenv("TP_CD_STAGES") ? atoi(getenv("TP_CD_STAGES")) : 3;  // (timing aid: 1 fill, 2 + factor, 3 all)
-        if (stages >= 2) TP_LAUNCH(k_cd_factor, dim3(8 * P), dim3(CD_T), 0, s, g, cd.Lb, cd.Linv, cd.ctl, P);
-        if (stages >= 3) TP_LAUNCH(k_cd_invert, dim3(g.nblk), dim3(CD_T), 0, s, g, cd.Lb, cd.Linv, cd.W, cd.Wt);
-        grid->launches += 3;
+        static const bool prof_on = getenv("TP_CD_PROF") != nullptr;  // (timing aid: ticks per phase, printed per factorisation)
+        long long *prof = nullptr;
+        if (prof_on) {
+            TP_HIP(hipMalloc((void **)&prof, sizeof(long long) * 8 * 32));
+            TP_HIP(hipMemsetAsync(prof, 0, sizeof(long long) * 8 * 32, s));
+        }
+        if (stages >= 2) TP_LAUNCH(k_cd_factor, dim3(8 * P), dim3(CD_T), 0, s, g, cd.Lb, cd.Ld, cd.ctl, P, prof);
+        if (prof_on) {
+            long long h[8 * 32];
+            TP_HIP(hipStreamSynchronize(s));
+            TP_HIP(hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost));
+            (void)hipFree(prof);
+            int rate = 100000;
+            (void)hipDeviceGetAttribute(&rate, hipDeviceAttributeWallClockRate, 0);
+            for (int r = 0; r < P; r += (P > 4 ? P / 3 : 1))
+                fprintf(stderr, "cd factor rank %2d us: A %.0f | B diag %.0f | B look-ahead %.0f | barrier1 %.0f | C %.0f | barrier2 %.0f | loop %.0f\n", r,
+                        h[r * 8 + 0] * 1e3 / rate, h[r * 8 + 1] * 1e3 / rate, h[r * 8 + 2] * 1e3 / rate, h[r * 8 + 3] * 1e3 / rate, h[r * 8 + 4] * 1e3 / rate,
+                        h[r * 8 + 5] * 1e3 / rate, h[r * 8 + 7] * 1e3 / rate);
+        }
+        if (stages >= 3) {
+            TP_LAUNCH(k_cd_diag_inv, dim3(g.nblk), dim3(WAVE), 0, s, cd.Ld, cd.Linv);
+            TP_LAUNCH(k_cd_invert, dim3(g.nblk), dim3(CD_T), 0, s, g, cd.Lb, cd.Linv, cd.W, cd.Wt);
+        }
+        grid->launches += 4;
         const double nb2 = (double)g.np * g.np;
         grid->alg_bytes += 8.0 * (27.0 * DOF * DOF * L.g.nodes() + nb2);  // stencil in, W and W^T (lower halves) out
         grid->flops += (double)g.np * g.KB * CD_NB * (g.KB * CD_NB + g.np);  // band Cholesky + triangular inverse
