@@ -384,3 +384,38 @@ def test_w_cycles_equal_petsc_pcmg_restated(orc, cycles):
     its_w = mg.solve(b, rtol=1e-8)[1]
     mg.set_cycles([1, 1, 1])
     assert its_w < mg.solve(b, rtol=1e-8)[1] or cycles == [3, 1, 1]
+
+
+@pytest.mark.parametrize("nlv,cycles", [(3, (1, 1)), (4, (1, 2, 1))])
+def test_exact_coarse_solve_equals_sparse_lu(orc, nlv, cycles):
+    """MG.set_coarse_direct: the coarsest level solved exactly (banded Cholesky of the oracle, chol_band_factor /
+    chol_band_solve; the reference's coarse KSP runs to rtol 1e-8, LinearElasticity.cc:628-632) -- the V-cycle restated in
+    numpy with scipy's sparse LU as coarse solver gives the same preconditioner to rounding, and the exact solve is never
+    worse than the 20-step Chebyshev run it replaces."""
+    nx, ny, nz, h, KE, N, b, x, E = _problem(orc, 32, 16, 16, "synth")
+    mg = orc.MG(nx, ny, nz, 3, nlv, 2, 20)
+    mg.set_coarse_direct(True)
+    mg.set_cycles(list(cycles))
+    mg.assemble(KE, E, N)
+    A = [mg.csr(l) for l in range(nlv)]
+    dinv = [1.0 / mg.diag(l) for l in range(nlv)]
+    lu = spla.splu(A[-1].tocsc())
+
+    def cycle(l, rhs):   # V-cycle
+        if l == nlv - 1:
+            return lu.solve(rhs)
+        lo, hi = 0.1 * mg.lam(l), 1.1 * mg.lam(l)
+        xl = _petsc_chebyshev(A[l], dinv[l], lo, hi, rhs, np.zeros_like(rhs), 2, True)
+        xl = xl + mg.prolong(l, cycle(l + 1, mg.restrict(l, rhs - A[l] @ xl)))
+        return _petsc_chebyshev(A[l], dinv[l], lo, hi, rhs, xl, 2, False)
+
+    r = np.random.default_rng(6).standard_normal(b.size) * N
+    if all(c == 1 for c in cycles):
+        z, zr = mg.precond(r), cycle(0, r)
+        assert np.abs(z - zr).max() <= 1e-10 * np.abs(zr).max()
+    U_d, its_d, hist_d = mg.solve(b, rtol=1e-6, maxit=300)
+    mg2 = orc.MG(nx, ny, nz, 3, nlv, 2, 20)
+    mg2.set_cycles(list(cycles))
+    mg2.assemble(KE, E, N)
+    U_c, its_c, hist_c = mg2.solve(b, rtol=1e-6, maxit=300)
+    assert its_d <= its_c + 1 and np.abs(U_d - U_c).max() <= 1e-4 * np.abs(U_c).max()

@@ -24,7 +24,7 @@
 //   k_cd_tri      y = W b,  x = W^T y: one wave per row.
 // The 32 x 32 x 32 products run one per WAVE on 4 x 4 register tiles (operands transposed in LDS, 16-byte reads: LDS
 // bandwidth is what bounds them), the terms of a sum are dealt to the four waves and added up in a fixed order.
-// Sums are formed in a fixed order: results are reproducible run to run; against the CPU restatement (oracle: banded
+// Sums are formed in a fixed order: results are reproducible run to run; against a CPU restatement (tests: banded
 // Cholesky, two substitutions) they differ by rounding only.  A non-positive pivot poisons the factor with NaN, which the
 // Krylov loop reports as divergence.
 #pragma once

@@ -399,7 +399,9 @@ __device__ inline void xcd_leave(XcdRunCtrl *ctl) {  // all threads; the last wo
         }
     }
 }
-// barrier number `k` (0, 1, 2 ..) of the run: the caller's stores are drained first; returns true if the run gave up
+// barrier number `k` (0, 1, 2 ..) of the run: the caller's stores are drained first; returns true if the run gave up.
+// (Every workgroup waits at every barrier: with ONE monotone counter a workgroup that only arrived and ran on would add
+// its next arrival to the count the others are still waiting on and release them one arrival early.)
 __device__ inline bool xcd_barrier(XcdRunCtrl *ctl, int k, int P, int *s_dead) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
