@@ -140,8 +140,9 @@ def cpu_baseline(sample, rtol, fine_eig, gpu_el, gpu_ndof, budget_s, nlv=4, nsmo
             "matrix_free": {"value": nd / t_mf, "unit": "DOF-updates/s", "seconds": t_mf,
                             "what": "the same step with the fine-level operator of the solve applied from KE and the moduli (OpenMP gather over "
                                     "the 8 elements of a node) instead of the assembled CSR; Galerkin operators as before"},
-            "sample": "1 step on %s, %d levels, Chebyshev(%d) / coarse Chebyshev(%d)%s as on the GPU line, CG its %d, %.2f s; assembled CSR + "
-                      "Galerkin SpGEMM (the reference's data path), OpenMP on %d threads" % (what, lv, nsmooth, ncoarse,
+            "sample": "1 step on %s, %d levels, Chebyshev(%d) / coarse %s%s as on the GPU line, CG its %d, %.2f s; assembled CSR + "
+                      "Galerkin SpGEMM (the reference's data path), OpenMP on %d threads" % (what, lv, nsmooth,
+                                                                                             "exact (banded Cholesky)" if coarse_direct else "Chebyshev(%d)" % ncoarse,
                                                                                              " / cycles per level " + cycles if cycles else "", its, t, cores)}
 
 

@@ -332,7 +332,8 @@ struct MGSolver {
             if (!lan_fork) TP_HIP(hipEventCreateWithFlags(&lan_fork, hipEventDisableTiming));
             TP_HIP(hipEventRecord(lan_fork, main));
             int rc = TP_OK;
-            for (int l = first_level; l < nlv && rc == TP_OK; l++) {
+            // coarsest level first: with the exact coarse solve its chain (factorisation) is the longest one
+            for (int l = nlv - 1; l >= first_level && rc == TP_OK; l--) {
                 if (!lan_stream[l]) TP_HIP(hipStreamCreateWithFlags(&lan_stream[l], hipStreamNonBlocking));
                 if (!lan_done[l]) TP_HIP(hipEventCreateWithFlags(&lan_done[l], hipEventDisableTiming));
                 TP_HIP(hipStreamWaitEvent(lan_stream[l], lan_fork, 0));
