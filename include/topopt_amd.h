@@ -178,7 +178,8 @@ typedef struct tp_solver_opts {
     /* ksp_mode 0, coarsest level: 0 = Chebyshev run of ncoarse steps on [smallest Ritz value, cheb_hi * largest];
      * 1 = exact solve (banded Cholesky + explicit triangular inverse, csrc/coarse_direct.h) where the level has at most
      * 4096 rows on one rank (or is replicated) -- closer to the reference's coarse KSP to rtol 1e-8 (:628-632) than a
-     * fixed polynomial; other levels / larger coarsest grids fall back to 0 */
+     * fixed polynomial; larger or distributed coarsest grids fall back to 0, and so do grids of <= 448 rows, whose
+     * Chebyshev run stays inside one workgroup (2 = exact also there) */
     int coarse_direct;
 } tp_solver_opts;
 void tp_solver_default_opts(tp_solver_opts *o);

@@ -62,7 +62,7 @@ class SolverOptions:
     coarse_restart: int = 30
     coarse_rtol: float = 1.0e-8
     # ksp_mode 0: coarsest level solved exactly (banded Cholesky + explicit triangular inverse, csrc/coarse_direct.h) where it
-    # has at most 4096 rows on one rank; 0: Chebyshev run of ncoarse steps
+    # has 449 .. 4096 rows on one rank (2: also below 449, where the Chebyshev run stays inside one workgroup); 0: Chebyshev run
     coarse_direct: int = 0
 
     @classmethod

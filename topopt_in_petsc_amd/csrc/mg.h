@@ -859,7 +859,10 @@ struct MGSolver {
         if (L.kind != LV_DIA || (grid->has_comm && !L.no_comm) || L.own_n() != L.ndof() || L.ndof() > CD_MAXROWS) return false;
         const long hb = (long)DOF * (L.g.plane() + L.g.nx + 1) + DOF - 1;
         const int KB = (int)((hb + CD_NB - 1) / CD_NB);
-        return KB >= 1 && KB <= CD_KBMAX && L.ndof() >= 4 * CD_NB;
+        if (!(KB >= 1 && KB <= CD_KBMAX && L.ndof() >= 4 * CD_NB)) return false;
+        // a level of <= 448 rows runs its Chebyshev steps inside ONE workgroup at 0.4 us each (coarse_run.h): a
+        // factorisation per assembly does not pay there -- coarse_direct = 2 asks for it anyway
+        return opt.coarse_direct >= 2 || L.ndof() > (long)RUN_RPB * 8;
     }
     void coarse_direct_free() {
         for (double **p : {&cd.Lb, &cd.Ld, &cd.Linv, &cd.W, &cd.Wt, &cd.y}) {
