@@ -333,15 +333,18 @@ struct MGSolver {
             TP_HIP(hipEventRecord(lan_fork, main));
             int rc = TP_OK;
             // coarsest level first: with the exact coarse solve its chain (factorisation) is the longest one
+            // (with the factorisation the other levels' chains share ONE stream: the device has four hardware queues, and
+            // streams that share a queue run one after the other -- the factorisation must not be the one that waits)
             for (int l = nlv - 1; l >= first_level && rc == TP_OK; l--) {
-                if (!lan_stream[l]) TP_HIP(hipStreamCreateWithFlags(&lan_stream[l], hipStreamNonBlocking));
+                const int sl = (direct && l != nlv - 1) ? first_level : l;  // stream slot of this level's chain
+                if (!lan_stream[sl]) TP_HIP(hipStreamCreateWithFlags(&lan_stream[sl], hipStreamNonBlocking));
                 if (!lan_done[l]) TP_HIP(hipEventCreateWithFlags(&lan_done[l], hipEventDisableTiming));
-                TP_HIP(hipStreamWaitEvent(lan_stream[l], lan_fork, 0));
+                TP_HIP(hipStreamWaitEvent(lan_stream[sl], lan_fork, 0));
                 const int steps = (l == nlv - 1 && l > 0) ? NLANCZOS_COARSE : opt.nlanczos;
-                grid->stream = lan_stream[l];  // everything the run launches goes to the level's stream
+                grid->stream = lan_stream[sl];  // everything the run launches goes to the level's stream
                 rc = (direct && l == nlv - 1) ? coarse_direct_factor() : lanczos_graph(l, steps);
                 grid->stream = main;
-                if (rc == TP_OK && hipEventRecord(lan_done[l], lan_stream[l]) != hipSuccess) rc = TP_ERR_HIP;
+                if (rc == TP_OK && hipEventRecord(lan_done[l], lan_stream[sl]) != hipSuccess) rc = TP_ERR_HIP;
             }
             for (int l = first_level; l < nlv; l++)
                 if (lan_done[l]) (void)hipStreamWaitEvent(main, lan_done[l], 0);
@@ -1224,6 +1227,7 @@ struct MGSolver {
     }
 
     // Jacobi diagonal + Chebyshev bound of a matrix-free level
+    double fine_bound = 0.0;
     int setup_matfree_level(int l, const double *h_KE) {
         Level<DOF> &L = lv[l];
         MatfreeOp<DOF> o{L.KE, L.E, L.mask, L.g};
@@ -1231,8 +1235,13 @@ struct MGSolver {
                            grid->stream, o, L.dinv);
         count_launch(grid, 8.0 * DOF * L.g.owned_nodes() + 8.0 * L.g.own_elems(), 16.0 * DOF * L.g.owned_nodes());
         if (l == 0) {
-            double lb = elem_lambda_bound(8 * DOF, h_KE);
-            L.lam = lb > 1.0 ? lb : 1.0;
+            // the element matrix of a solver never changes: the bound (a 24 x 24 Jacobi eigenvalue iteration on the host,
+            // ~90 us during which the device had nothing queued) is computed once
+            if (!(fine_bound > 0.0)) {
+                const double lb = elem_lambda_bound(8 * DOF, h_KE);
+                fine_bound = lb > 1.0 ? lb : 1.0;
+            }
+            L.lam = fine_bound;
         }
         return TP_OK;
     }

@@ -420,6 +420,8 @@ extern "C" void tp_solver_default_opts(tp_solver_opts *o) {
 struct tp_elasticity {
     tp_grid *grid;
     MGSolver<3> mg;
+    hipStream_t aux_stream = nullptr;            // level 2's Galerkin kernel beside level 1's (assemble)
+    hipEvent_t aux_fork = nullptr, aux_done = nullptr;
     double KE[576];
     double *d_KE, *d_M;      // element matrix, 8 child matrices (level 0 -> 1 fast path)
     double *d_E;             // SIMP moduli, own + ghost-above layer
@@ -596,6 +598,9 @@ extern "C" int tp_elasticity_destroy(tp_elasticity *e) {
     (void)hipStreamSynchronize(e->grid->stream);
     sym_slot_release(e->mg.lv[0].sym_slot);
     e->mg.free_levels();
+    if (e->aux_stream) (void)hipStreamDestroy(e->aux_stream);
+    if (e->aux_fork) (void)hipEventDestroy(e->aux_fork);
+    if (e->aux_done) (void)hipEventDestroy(e->aux_done);
     for (void *p : {(void *)e->d_KE, (void *)e->d_M, (void *)e->d_E, (void *)e->d_mask, (void *)e->d_bN, (void *)e->d_N,
                     (void *)e->d_flagged, (void *)e->d_colmask, (void *)e->d_flag_all, (void *)e->d_corr_nodes,
                     (void *)e->d_corr_adj, (void *)e->d_dK, (void *)e->d_corr, (void *)e->d_corr_tmp, (void *)e->d_KelF,
@@ -791,6 +796,27 @@ extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, dou
     TP_TRY(exchange_segments(g, e->d_E, nullptr, nullptr, e->d_E + nel, 2 * lay, 1, 2 * lay));
     TP_TRY(mg.setup_matfree_level(0, e->KE));
     const bool macro1 = mg.nlv > 1 && mg.lv[1].kind == LV_MACRO;  // level 1 applied from E: no element matrices there
+    // Level 2's element matrices come straight from the fine moduli (k_galerkin_l2_fast, ~0.3 ms at 128^3) and do not
+    // depend on level 1's kernels (flagged elements, corrections, diagonal: another ~0.4 ms): side by side on a second
+    // stream, joined where level 2 continues.  The chain to the coarsest level -- the critical path of the set-up since
+    // that level is factored (coarse_direct.h) -- starts that much earlier.
+    static const bool no_l2_aside = getenv("TP_NO_L2_ASIDE") != nullptr || getenv("TP_NO_L2_FAST") != nullptr || tp_debug_sync();
+    bool l2_aside = false;
+    if (macro1 && mg.nlv > 2 && !no_l2_aside) {
+        if (!e->aux_stream) TP_HIP(hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking));
+        if (!e->aux_fork) TP_HIP(hipEventCreateWithFlags(&e->aux_fork, hipEventDisableTiming));
+        if (!e->aux_done) TP_HIP(hipEventCreateWithFlags(&e->aux_done, hipEventDisableTiming));
+        Level<3> &C2 = mg.lv[2];
+        const long nEc2 = C2.g.own_elems();
+        static const long nb2_env = getenv("TP_L2_BLOCKS") ? atol(getenv("TP_L2_BLOCKS")) : 512;
+        const unsigned nb2 = (unsigned)(nEc2 < nb2_env ? nEc2 : nb2_env);
+        TP_HIP(hipEventRecord(e->aux_fork, s));
+        TP_HIP(hipStreamWaitEvent(e->aux_stream, e->aux_fork, 0));
+        TP_LAUNCH(k_galerkin_l2_fast, dim3(nb2), dim3(576), 0, e->aux_stream, mg.lv[0].g, C2.g, e->d_E, e->d_M2, C2.Kel, (int)nEc2);
+        count_launch(g, 8.0 * 64 * nEc2 + 8.0 * 576 * nEc2, 2.0 * 64 * 576 * nEc2);
+        TP_HIP(hipEventRecord(e->aux_done, e->aux_stream));
+        l2_aside = true;
+    }
     for (int l = 1; l < mg.nlv; l++) {
         Level<3> &F = mg.lv[l - 1], &C = mg.lv[l];
         const long nEc = C.g.own_elems();
@@ -832,9 +858,13 @@ extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, dou
             if (!no_fast2) {
                 static const long nb2_env = getenv("TP_L2_BLOCKS") ? atol(getenv("TP_L2_BLOCKS")) : 512;
                 const unsigned nb2 = (unsigned)(nEc < nb2_env ? nEc : nb2_env);
-                TP_LAUNCH(k_galerkin_l2_fast, dim3(nb2), dim3(576), 0, s, mg.lv[0].g, C.g, e->d_E, e->d_M2,
-                                   C.Kel, (int)nEc);
-                count_launch(g, 8.0 * 64 * nEc + 8.0 * 576 * nEc, 2.0 * 64 * 576 * nEc);
+                if (l2_aside) {
+                    TP_HIP(hipStreamWaitEvent(s, e->aux_done, 0));
+                } else {
+                    TP_LAUNCH(k_galerkin_l2_fast, dim3(nb2), dim3(576), 0, s, mg.lv[0].g, C.g, e->d_E, e->d_M2,
+                                       C.Kel, (int)nEc);
+                    count_launch(g, 8.0 * 64 * nEc + 8.0 * 576 * nEc, 2.0 * 64 * 576 * nEc);
+                }
                 if (e->nlist2) {
                     TP_LAUNCH((k_galerkin_coarse<true>), dim3((unsigned)e->nlist2), dim3(64), 0, s, F.g, C.g,
                                        e->d_KelF, C.Kel, mg.lv[0].g, e->d_E, e->d_M, e->d_fidx1, (long)e->nlist2, e->d_list2);
