@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 3, with the exact coarse solve: which cycle pattern now?
+export TMPDIR=/tmp
+run() { python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-cube256 --no-stated-cycle "$@" 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); c=d['config']; print('%-40s %.2f ms  its %s  launches %s  rel %.2e  %s' % (' '.join(sys.argv[1:]), d['ms_per_step'], c['cg_its'], c['kernel_launches_per_step'], c['rel_residual'], c['coarse_solve']))" "$@"; }
+run
+run --cycles 1,2,1,1
+run --cycles 1,1,2,1
+run --cycles 1,2,2,2
+run --cycles 1,3,1,1
+run --cycles 1,2,3,1
+run --nlvls 4 --cycles 1,2,2
+run --nlvls 4 --cycles 1,2,1
+run --nsmooth 3
