@@ -30,11 +30,13 @@ if ROOT not in sys.path:
 # level solvers, a far stronger -- and sequential -- smoother.  Scans: tools/sweep_solver_params.sh, DESIGN.md 4.5.
 WORKLOADS = {
     # BASELINE.json metric mesh, 6.44 M DOF; levels 2 and 3 cycled twice (PCMGSetCycleTypeOnLevel W): 19.7 -> 17.8 ms, 19 -> 13 its
-    "cantilever128": dict(el=(128, 128, 128), nlvls=5, nsmooth=2, ncoarse=20, cycles="1,2,2,1"),
+    # cycles: level 2 cycled three times per visit of level 1, V below (with the exact coarse solve: 14.4 ms / 11 its
+    # against 15.0 / 12 for round 2's 1,2,2,1 -- tools/cycle_scan5.sh, cycle_scan6.sh); ncoarse: only with --coarse cheb
+    "cantilever128": dict(el=(128, 128, 128), nlvls=5, nsmooth=2, ncoarse=20, cycles="1,3,1,1"),
     "c2": dict(el=(128, 64, 64), nlvls=3, nsmooth=2, ncoarse=45),               # configs[1] ("3-level GMG")
     "c1": dict(el=(48, 24, 24), nlvls=4, nsmooth=2, ncoarse=22),                # configs[0]
     "cube256": dict(el=(256, 256, 256), nlvls=6, nsmooth=2, ncoarse=45),        # north-star SpMV target mesh
-    "c3": dict(el=(256, 128, 128), nlvls=7, nsmooth=2, ncoarse=20, cycles="1,2,2,2,2,1"),  # configs[2] on ONE GPU (12.8 M DOF); with --gpus 8: 256x128x(128*8)
+    "c3": dict(el=(256, 128, 128), nlvls=6, nsmooth=2, ncoarse=20, cycles="1,3,1,1,1"),  # configs[2] on ONE GPU (12.8 M DOF); with --gpus 8: 256x128x(128*8)
     "c4": dict(el=(192, 64, 64), nlvls=6, nsmooth=2, ncoarse=45, ftype=2, bc="mbb"),  # configs[3]: MBB beam, Helmholtz (PDE) filter
     "c5": dict(el=(512, 256, 256), nlvls=4, nsmooth=2, ncoarse=60),             # configs[4] ("4-level GMG") on ONE GPU (101.7 M DOF, ~35 GB of the 288 GB); with --gpus 8 --scaling strong: its slabs
     # configs[1] with the reference's own absolute filter radius (TopOpt.cc:121 rmin = 0.08: ElemConn 5, 1331-tap cone)

@@ -99,8 +99,10 @@ CONFIGS = {
     "metric_128cubed": (128, 128, 128, 4, 1, "cantilever"),
     "C5_512x256x256_one_gpu": (512, 256, 256, 4, 1, "cantilever"),   # 101.6 M DOF, ~35 GB of the 288 GB
     # the parameterisation bench.py actually runs (WORKLOADS): depth, step counts, W-cycles on the middle levels
-    "metric_128cubed_bench_cycle": (128, 128, 128, 5, 1, "cantilever", dict(nsmooth=2, ncoarse=20), [1, 2, 2, 1]),
-    "C3_256x128x128_bench_cycle": (256, 128, 128, 7, 1, "cantilever", dict(nsmooth=2, ncoarse=20), [1, 2, 2, 2, 2, 1]),
+    "metric_128cubed_bench_cycle": (128, 128, 128, 5, 1, "cantilever", dict(nsmooth=2, ncoarse=20, coarse_direct=1), [1, 3, 1, 1]),
+    "C3_256x128x128_bench_cycle": (256, 128, 128, 6, 1, "cantilever", dict(nsmooth=2, ncoarse=20, coarse_direct=1), [1, 3, 1, 1, 1]),
+    # round 2's bench cycle (W on levels 2-3, Chebyshev coarse run)
+    "metric_128cubed_round2_cycle": (128, 128, 128, 5, 1, "cantilever", dict(nsmooth=2, ncoarse=20), [1, 2, 2, 1]),
 }
 
 

@@ -571,7 +571,7 @@ def test_random_dirichlet_sets(tp, orc, seed, frac):
     assert np.abs(le.last_hist[:k] / hist_o[:k] - 1).max() <= 1e-8
 
 
-@pytest.mark.parametrize("mesh,nlv,cycles", [((64, 32, 32), 4, (1, 2, 1)), ((48, 24, 24), 3, (1, 1)), ((64, 64, 64), 4, (1, 2, 2)),
+@pytest.mark.parametrize("mesh,nlv,cycles", [((64, 32, 32), 4, (1, 2, 1)), ((48, 24, 24), 3, (1, 1)), ((64, 64, 64), 4, (1, 3, 1)),
                                              ((24, 40, 24), 3, (2, 1)), ((32, 32, 32), 3, (1, 1))])
 def test_coarsest_level_solved_exactly(tp, orc, mesh, nlv, cycles):
     """SolverOptions.coarse_direct (csrc/coarse_direct.h): the coarsest level's Chebyshev run replaced by
