@@ -423,7 +423,9 @@ def main():
     gen3 = os.environ.get("TP_FINE_V", "0") in ("3",) or (os.environ.get("TP_FINE_V", "0") == "0" and ((nx + 30) // 31) * ((ny + 6) // 7) >= 160)
     kname = "k_fine_u4" if gen3 else "k_fine_tile"
     roofline = {"bound": "hbm", "kernel": "%s<EPI_CHEB> (fine-level matrix-free hex8 operator fused with "
-                                          "the Chebyshev-Jacobi update; the largest kernel of the step: profiles/r03_bench_step_shares.txt)" % kname,
+                                          "the Chebyshev-Jacobi update; the largest kernel of the Krylov loop and the largest bandwidth-bound kernel of the step: "
+                                          "profiles/r03b_bench_step_shares.txt -- only the once-per-step factorisation of the coarsest level, "
+                                          "k_cd_factor, a latency-bound chain of 69 block columns on a side stream, adds up to more time: DESIGN 4.5)" % kname,
                 "share_of_step": cheb_step_share,
                 "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                 "traffic": (traffic or {}).get("cheb_hbm_bytes_per_launch", None) and traffic["cheb_hbm_bytes_per_launch"] / 1e9,
