@@ -141,6 +141,11 @@ int tp_grid_drop_rccl(tp_grid *g);
 /* collective: rank-tagged buffers through the grid's CURRENT hooks (staged and in-place exchange, reductions,
  * all-gather); *ok = 1 if this rank received exactly its neighbours' data */
 int tp_grid_comm_selfcheck(tp_grid *g, int *ok);
+/* Stress test of the reductions that are finished inside the producing kernel (csrc/common.h, reduce_tail): `reps` dot
+ * products of two generated vectors of n doubles, back to back, each also computed by the two-launch form (partial sums,
+ * then k_reduce_final); *mismatches = how many differ in any bit.  (TP_NO_REDUCE_TAIL=1 switches the in-kernel form off
+ * library-wide; the test then compares the two-launch form with itself.) */
+int tp_grid_reduction_selftest(tp_grid *g, long n, int reps, int *mismatches);
 /* one-rank loop-back check of the RCCL call sequence (the rank is its own lower and upper neighbour):
  * returns TP_OK and the largest deviation in *max_err */
 int tp_rccl_selftest(int device, void *stream, long n, double *max_err);

@@ -623,3 +623,12 @@ def test_coarsest_level_too_wide_for_the_exact_solve_falls_back(tp, orc):
         its = le.KSPSolve()
         res.append((host(le.U), its))
     assert res[0][1] == res[1][1] and np.array_equal(res[0][0], res[1][0])
+
+
+def test_in_kernel_reduction_tail_stress(tp):
+    """csrc/common.h, reduce_tail: 600 dot products back to back over 4 M doubles (2048 workgroups each: the shape of the
+    CG loop's reductions), every one bitwise equal to the two-launch form (partial sums + k_reduce_final).  The tail rests on
+    relaxed agent-scope atomics and a drained store queue instead of a release fence; TP_NO_REDUCE_TAIL=1 is the way out."""
+    grid = tp.Grid(17, 9, 9, 0.125)
+    assert grid.reduction_selftest(4 * 1024 * 1024, 600) == 0
+    assert grid.reduction_selftest(1000, 50) == 0          # fewer workgroups than counter shards

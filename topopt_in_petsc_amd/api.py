@@ -114,6 +114,12 @@ class Grid:
         """number of halos that travelled on the second stream, overlapped with interior planes (0 = none)"""
         return int(self.L.tp_grid_overlapped_halos(self.handle))
 
+    def reduction_selftest(self, n, reps):
+        """`reps` back-to-back dot products over n doubles, in-kernel reduction tail against the two-launch form: mismatches"""
+        bad = C.c_int(0)
+        _chk(self.L.tp_grid_reduction_selftest(self.handle, int(n), int(reps), C.byref(bad)), "tp_grid_reduction_selftest")
+        return bad.value
+
     def kernel_timer(self, on):
         """bracket every launch of the fine level's fused Chebyshev step with a HIP event pair (bench.py's roofline)"""
         _chk(self.L.tp_grid_kernel_timer(self.handle, int(on)), "tp_grid_kernel_timer")

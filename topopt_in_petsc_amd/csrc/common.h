@@ -130,6 +130,13 @@ template <int NV>
 __device__ inline void reduce_tail(const double (&mine)[NV], double *__restrict__ partials, int nb, int b,
                                    unsigned *ticket, double *__restrict__ out) {
     __shared__ int s_last;
+    if (!ticket) {  // TP_NO_REDUCE_TAIL=1: partial sums only, the host launches k_reduce_final behind this kernel
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int v = 0; v < NV; v++) partials[(long)v * nb + b] = mine[v];
+        }
+        return;
+    }
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int v = 0; v < NV; v++)

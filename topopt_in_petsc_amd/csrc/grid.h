@@ -81,6 +81,26 @@ inline int finish_reduction(tp_grid *g, int slot) {
     return TP_OK;
 }
 
+// The reductions finished inside the producing kernel (reduce_tail, common.h) rely on relaxed agent-scope atomics and an
+// explicit vmcnt(0) instead of a release fence (measured: a fence per workgroup writes back the whole L2).  Should that
+// ever misbehave on another driver or firmware, TP_NO_REDUCE_TAIL=1 routes every such reduction through the former second
+// launch (k_reduce_final: same summation order, same bits): the kernels get no ticket and leave their partial sums only.
+inline unsigned *tail_ticket(tp_grid *g) {
+    static const bool off = getenv("TP_NO_REDUCE_TAIL") != nullptr;
+    return off ? nullptr : g->ticket;
+}
+template <int NV>
+inline int finish_reduction(tp_grid *g, int slot);
+// behind a kernel that ends in reduce_tail<NV> with nblocks workgroups: second launch if the tail is switched off, ranks
+template <int NV>
+inline int finish_tail(tp_grid *g, int nblocks, int slot) {
+    if (!tail_ticket(g)) {
+        TP_LAUNCH(k_reduce_final<NV>, dim3(1), dim3(BLK), 0, g->stream, g->partials, nblocks, g->scal + slot);
+        count_launch(g);
+    }
+    return finish_reduction<NV>(g, slot);
+}
+
 // the two-launch form for the once-per-call reductions (block partials in g->partials -> scal[slot..], then ranks)
 template <int NV>
 inline int reduce_partials(tp_grid *g, int nblocks, int slot) {
@@ -113,15 +133,15 @@ inline int read_scal_end(tp_grid *g, int n, double *out) {
 
 inline int dot_to_slot(tp_grid *g, const double *a, const double *b, long n, int slot) {
     int nb = grid_for(n, 2048);
-    TP_LAUNCH(k_dot, dim3(nb), dim3(BLK), 0, g->stream, a, b, n, g->partials, g->ticket, g->scal + slot);
+    TP_LAUNCH(k_dot, dim3(nb), dim3(BLK), 0, g->stream, a, b, n, g->partials, tail_ticket(g), g->scal + slot);
     count_launch(g, 16.0 * n, 2.0 * n);
-    return finish_reduction<1>(g, slot);
+    return finish_tail<1>(g, nb, slot);
 }
 inline int sum_to_slot(tp_grid *g, const double *a, long n, int slot) {
     int nb = grid_for(n, 2048);
-    TP_LAUNCH(k_sum, dim3(nb), dim3(BLK), 0, g->stream, a, n, g->partials, g->ticket, g->scal + slot);
+    TP_LAUNCH(k_sum, dim3(nb), dim3(BLK), 0, g->stream, a, n, g->partials, tail_ticket(g), g->scal + slot);
     count_launch(g, 8.0 * n, 1.0 * n);
-    return finish_reduction<1>(g, slot);
+    return finish_tail<1>(g, nb, slot);
 }
 
 // Generic neighbour exchange of `rows` segments of `seg` doubles each (pitch in

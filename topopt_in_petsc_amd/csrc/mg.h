@@ -1101,7 +1101,7 @@ struct MGSolver {
             TP_TRY(halo(l, L.x));
             if (dot_slot >= 0 && it == k - 1) {
                 a.partials = grid->partials;
-                a.ticket = grid->ticket;
+                a.ticket = tail_ticket(grid);
                 a.red_out = grid->scal + dot_slot;
                 TP_TRY(op<EPI_CHEB_DOT>(l, a));
             } else {
@@ -1480,7 +1480,7 @@ struct MGSolver {
                 double *z;
                 if (can_fuse_rz()) {  // r . z comes out of the V-cycle's last smoothing step
                     TP_TRY(precond(r, &z, rz_cur));
-                    TP_TRY(finish_reduction<1>(grid, rz_cur));
+                    TP_TRY(finish_tail<1>(grid, last_nblocks, rz_cur));
                 } else {
                     TP_TRY(precond(r, &z));
                     TP_TRY(dot_to_slot(grid, r + off, z + off, n, rz_cur));
@@ -1499,16 +1499,16 @@ struct MGSolver {
                     a.x = p;
                     a.out = w;
                     a.partials = grid->partials;
-                    a.ticket = grid->ticket;
+                    a.ticket = tail_ticket(grid);
                     a.red_out = grid->scal + S_PW;
                     TP_TRY(halo(0, p));
                     TP_TRY(op<EPI_APPLY_DOT>(0, a));
-                    TP_TRY(finish_reduction<1>(grid, S_PW));
+                    TP_TRY(finish_tail<1>(grid, last_nblocks, S_PW));
                 }
                 TP_LAUNCH(k_cg_update_xr, dim3(nb), dim3(BLK), 0, s, x, r, p, w, grid->scal, rz_cur, off, n,
-                                   grid->partials, grid->ticket, grid->scal + S_RR);
+                                   grid->partials, tail_ticket(grid), grid->scal + S_RR);
                 count_launch(grid, 48.0 * n, 6.0 * n);
-                TP_TRY(finish_reduction<1>(grid, S_RR));
+                TP_TRY(finish_tail<1>(grid, nb, S_RR));
                 double rr;
                 TP_TRY(read_scal_begin(grid, S_RR, 1));
                 if (spec_head && its < opt.max_it) TP_TRY(vcycle_head(r));  // next iteration's first kernels, then wait

@@ -86,6 +86,39 @@ extern "C" int tp_grid_drop_rccl(tp_grid *g) {
 }
 // Rank-tagged planes through the CURRENT hooks (staged and in-place exchange, all-reduce, all-gather) and a check
 // of what arrives: *ok = 1 if this rank saw exactly its neighbours' data.  Collective over the grid's ranks.
+__global__ __launch_bounds__(BLK) void k_selftest_fill(double *a, double *b, long n, uint64_t seed) {
+    for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
+        a[i] = hash_u01((uint64_t)i, seed) - 0.5;
+        b[i] = hash_u01((uint64_t)i, seed + 77) + 0.25;
+    }
+}
+extern "C" int tp_grid_reduction_selftest(tp_grid *g, long n, int reps, int *mismatches) {
+    if (!g || n < 1 || reps < 1 || reps > 4096 || !mismatches) return TP_ERR_ARG;
+    double *a = nullptr, *b = nullptr, *res = nullptr;
+    TP_HIP(hipMalloc((void **)&a, sizeof(double) * (size_t)n));
+    TP_HIP(hipMalloc((void **)&b, sizeof(double) * (size_t)n));
+    TP_HIP(hipMalloc((void **)&res, sizeof(double) * 2 * (size_t)reps));
+    const int nb = grid_for(n, 2048);
+    for (int r = 0; r < reps; r++) {
+        if (r % 16 == 0) TP_LAUNCH(k_selftest_fill, dim3(grid_for(n)), dim3(BLK), 0, g->stream, a, b, n, (uint64_t)(1000 + r));
+        // the in-kernel tail (or whatever TP_NO_REDUCE_TAIL leaves of it) ...
+        TP_LAUNCH(k_dot, dim3(nb), dim3(BLK), 0, g->stream, a, b, n, g->partials, tail_ticket(g), res + 2 * r);
+        if (!tail_ticket(g)) TP_LAUNCH(k_reduce_final<1>, dim3(1), dim3(BLK), 0, g->stream, g->partials, nb, res + 2 * r);
+        // ... and the two-launch form
+        TP_LAUNCH(k_dot, dim3(nb), dim3(BLK), 0, g->stream, a, b, n, g->partials, (unsigned *)nullptr, res + 2 * r + 1);
+        TP_LAUNCH(k_reduce_final<1>, dim3(1), dim3(BLK), 0, g->stream, g->partials, nb, res + 2 * r + 1);
+    }
+    std::vector<double> h(2 * (size_t)reps);
+    TP_HIP(hipMemcpyAsync(h.data(), res, sizeof(double) * h.size(), hipMemcpyDeviceToHost, g->stream));
+    TP_HIP(hipStreamSynchronize(g->stream));
+    int bad = 0;
+    for (int r = 0; r < reps; r++) bad += std::memcmp(&h[2 * r], &h[2 * r + 1], sizeof(double)) != 0 || !(h[2 * r] == h[2 * r]);
+    *mismatches = bad;
+    (void)hipFree(a);
+    (void)hipFree(b);
+    (void)hipFree(res);
+    return TP_OK;
+}
 extern "C" int tp_grid_comm_selfcheck(tp_grid *g, int *ok) {
     if (!g || !ok) return TP_ERR_ARG;
     *ok = 1;

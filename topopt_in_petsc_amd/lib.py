@@ -67,6 +67,7 @@ SYMBOLS = {
     "tp_grid_drop_rccl": (_i, [_vp]),
     "tp_grid_overlapped_halos": (_l, [_vp]),
     "tp_grid_comm_selfcheck": (_i, [_vp, C.POINTER(_i)]),
+    "tp_grid_reduction_selftest": (_i, [_vp, _l, _i, C.POINTER(_i)]),
     "tp_rccl_selftest": (_i, [_i, _vp, _l, C.POINTER(_d)]),
     "tp_grid_local_nodes": (_l, [_vp]),
     "tp_grid_local_elems": (_l, [_vp]),
