@@ -326,7 +326,9 @@ struct MGSolver {
         static const bool serial = getenv("TP_LANCZOS_SERIAL") != nullptr;
         // the coarsest level solved exactly needs no window: its factorisation takes the place of its Lanczos run
         const bool direct = coarse_direct_ok();
-        cd.factored = false;
+        const bool early = cd_early && direct;  // factorisation enqueued by the owner already (its event is recorded)
+        cd_early = false;
+        if (!early) cd.factored = false;
         if (!grid->has_comm && !serial && nlv - first_level >= 2) {
             hipStream_t main = grid->stream;
             if (!lan_fork) TP_HIP(hipEventCreateWithFlags(&lan_fork, hipEventDisableTiming));
@@ -336,20 +338,34 @@ struct MGSolver {
             // (with the factorisation the other levels' chains share ONE stream: the device has four hardware queues, and
             // streams that share a queue run one after the other -- the factorisation must not be the one that waits)
             for (int l = nlv - 1; l >= first_level && rc == TP_OK; l--) {
-                const int sl = (direct && l != nlv - 1) ? first_level : l;  // stream slot of this level's chain
-                if (!lan_stream[sl]) TP_HIP(hipStreamCreateWithFlags(&lan_stream[sl], hipStreamNonBlocking));
+                if (early && l == nlv - 1) continue;
+                // stream of this level's chain: with the factorisation, level `first_level` on one stream, the levels
+                // between it and the coarsest one on the owner's spare stream (or on the same one if there is none)
+                hipStream_t ls;
+                if (direct && l != nlv - 1) {
+                    if (l != first_level && side_stream) {
+                        ls = side_stream;
+                    } else {
+                        if (!lan_stream[first_level]) TP_HIP(hipStreamCreateWithFlags(&lan_stream[first_level], hipStreamNonBlocking));
+                        ls = lan_stream[first_level];
+                    }
+                } else {
+                    if (!lan_stream[l]) TP_HIP(hipStreamCreateWithFlags(&lan_stream[l], hipStreamNonBlocking));
+                    ls = lan_stream[l];
+                }
                 if (!lan_done[l]) TP_HIP(hipEventCreateWithFlags(&lan_done[l], hipEventDisableTiming));
-                TP_HIP(hipStreamWaitEvent(lan_stream[sl], lan_fork, 0));
+                TP_HIP(hipStreamWaitEvent(ls, lan_fork, 0));
                 const int steps = (l == nlv - 1 && l > 0) ? NLANCZOS_COARSE : opt.nlanczos;
-                grid->stream = lan_stream[sl];  // everything the run launches goes to the level's stream
+                grid->stream = ls;  // everything the run launches goes to the level's stream
                 rc = (direct && l == nlv - 1) ? coarse_direct_factor() : lanczos_graph(l, steps);
                 grid->stream = main;
-                if (rc == TP_OK && hipEventRecord(lan_done[l], lan_stream[sl]) != hipSuccess) rc = TP_ERR_HIP;
+                if (rc == TP_OK && hipEventRecord(lan_done[l], ls) != hipSuccess) rc = TP_ERR_HIP;
             }
             for (int l = first_level; l < nlv; l++)
                 if (lan_done[l]) (void)hipStreamWaitEvent(main, lan_done[l], 0);
             for (int l = first_level; l < nlv; l++)
                 if (lan_stream[l]) (void)hipStreamSynchronize(lan_stream[l]);
+            if (side_stream) (void)hipStreamSynchronize(side_stream);
             if (rc) return rc;
             for (int l = first_level; l < nlv; l++) {
                 if (direct && l == nlv - 1)
@@ -856,6 +872,31 @@ struct MGSolver {
         bool factored = false;
     } cd;
     int cd_level() const { return replicate ? nlv : nlv - 1; }
+    bool cd_early = false;              // this assembly's factorisation is already under way (coarse_direct_early)
+    hipStream_t side_stream = nullptr;  // owner's spare stream (idle during estimate_spectra): a second one for the chains
+    // Called by the owner as soon as the coarsest level's stencil is enqueued (before the other levels are finished): the
+    // factorisation goes to the coarsest level's stream right away.  One rank only (the replicated copy of a multi-rank
+    // run is built later, setup_replicated); estimate_spectra then leaves the level alone.
+    int coarse_direct_early(bool *started) {
+        *started = false;
+        static const bool serial = getenv("TP_LANCZOS_SERIAL") != nullptr;
+        if (grid->has_comm || serial || opt.ksp_mode != 0 || nlv < 3 || !coarse_direct_ok()) return TP_OK;
+        const int l = nlv - 1;
+        hipStream_t main = grid->stream;
+        if (!lan_fork) TP_HIP(hipEventCreateWithFlags(&lan_fork, hipEventDisableTiming));
+        if (!lan_stream[l]) TP_HIP(hipStreamCreateWithFlags(&lan_stream[l], hipStreamNonBlocking));
+        if (!lan_done[l]) TP_HIP(hipEventCreateWithFlags(&lan_done[l], hipEventDisableTiming));
+        TP_HIP(hipEventRecord(lan_fork, main));
+        TP_HIP(hipStreamWaitEvent(lan_stream[l], lan_fork, 0));
+        grid->stream = lan_stream[l];
+        const int rc = coarse_direct_factor();
+        grid->stream = main;
+        if (rc) return rc;
+        TP_HIP(hipEventRecord(lan_done[l], lan_stream[l]));
+        cd_early = true;
+        *started = true;
+        return TP_OK;
+    }
     bool coarse_direct_ok() const {
         if (!opt.coarse_direct || getenv("TP_NO_COARSE_DIRECT") || nlv < 2 || DOF != 3) return false;
         const Level<DOF> &L = lv[cd_level()];

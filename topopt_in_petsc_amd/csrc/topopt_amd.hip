@@ -827,13 +827,16 @@ extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, dou
     // two ghost layers above <- upper neighbour's first own layers (level 1 is applied
     // from the fine densities and reaches one coarse = two fine layers up)
     TP_TRY(exchange_segments(g, e->d_E, nullptr, nullptr, e->d_E + nel, 2 * lay, 1, 2 * lay));
-    TP_TRY(mg.setup_matfree_level(0, e->KE));
     const bool macro1 = mg.nlv > 1 && mg.lv[1].kind == LV_MACRO;  // level 1 applied from E: no element matrices there
+    // Order of the set-up (round 3): the chain fine moduli -> element matrices of level 2 -> ... -> stencil of the coarsest
+    // level is what the factorisation of that level waits for (coarse_direct.h: the longest chain of the set-up), so it
+    // runs first and bare (pass 1: the Galerkin kernels and their ghost exchanges only); everything that merely FINISHES a
+    // level -- stencils of the middle levels, level 1's corrections and diagonal, the fine diagonal -- follows (pass 2)
+    // while the factorisation is already under way on its own stream.  Same kernels, same data, same results.
     // Level 2's element matrices come straight from the fine moduli (k_galerkin_l2_fast, ~0.3 ms at 128^3) and do not
-    // depend on level 1's kernels (flagged elements, corrections, diagonal: another ~0.4 ms): side by side on a second
-    // stream, joined where level 2 continues.  The chain to the coarsest level -- the critical path of the set-up since
-    // that level is factored (coarse_direct.h) -- starts that much earlier.
+    // depend on level 1's kernels: side by side on a second stream, joined where level 2 continues.
     static const bool no_l2_aside = getenv("TP_NO_L2_ASIDE") != nullptr || getenv("TP_NO_L2_FAST") != nullptr || tp_debug_sync();
+    static const bool two_pass = getenv("TP_NO_SETUP_REORDER") == nullptr;
     bool l2_aside = false;
     if (macro1 && mg.nlv > 2 && !no_l2_aside) {
         if (!e->aux_stream) TP_HIP(hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking));
@@ -850,10 +853,10 @@ extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, dou
         TP_HIP(hipEventRecord(e->aux_done, e->aux_stream));
         l2_aside = true;
     }
-    for (int l = 1; l < mg.nlv; l++) {
+    // ---- pass 1 of level l: its Galerkin element matrices (and their ghost layer)
+    auto galerkin_level = [&](int l) -> int {
         Level<3> &F = mg.lv[l - 1], &C = mg.lv[l];
         const long nEc = C.g.own_elems();
-        const int gn = (int)((C.g.owned_nodes() + BLK - 1) / BLK);
         if (l == 1 && macro1) {
             // only the flagged elements get their (exact, masked) Galerkin matrix: compact rows, own ones first,
             // then the ghost layer's -- the upper neighbour's first-layer rows, which head ITS array
@@ -865,15 +868,7 @@ extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, dou
             if (g->has_comm && e->nx_first > 0)
                 TP_TRY(exchange_segments(g, e->d_KelF, nullptr, nullptr, e->d_KelF + 576 * (long)e->nflagged, 576,
                                          e->nx_first, 576));
-            if (e->nflag_all) {
-                TP_LAUNCH(k_macro_delta, dim3((int)(((long)e->nflag_all * 576 + BLK - 1) / BLK)), dim3(BLK), 0, s,
-                                   F.g, C.g, e->d_E, e->d_M, e->d_KelF, e->d_flag_all, e->nflag_all, e->d_dK);
-                count_launch(g);
-            }
-            TP_LAUNCH(k_macro_diag, dim3(gn), dim3(BLK), 0, s, F.g, C.g, e->d_E, e->d_M, e->d_KelF, e->d_fidx1,
-                               C.dinv);
-            count_launch(g, 8.0 * 8.0 * C.g.own_elems() + 24.0 * C.g.owned_nodes(), 8.0 * 64 * 3 * C.g.owned_nodes());
-            continue;
+            return TP_OK;
         }
         if (l == 1) {
             TP_LAUNCH(k_galerkin_fine_fast, dim3((unsigned)nEc), dim3(192), 0, s, F.g, C.g, e->d_E, e->d_M,
@@ -918,6 +913,23 @@ extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, dou
         const long clay = (long)C.g.ex * C.g.ey;
         // (one contiguous block of 576*clay doubles, cut into rows of `clay` so that it fits the staging buffers)
         TP_TRY(exchange_segments(g, C.Kel, nullptr, nullptr, C.Kel + 576 * clay * C.g.ez_own, clay, 576, clay));
+        return TP_OK;
+    };
+    // ---- pass 2 of level l: what the level's own operator needs (stencil by diagonals / corrections, Jacobi diagonal)
+    auto finish_level = [&](int l) -> int {
+        Level<3> &F = mg.lv[l - 1], &C = mg.lv[l];
+        const int gn = (int)((C.g.owned_nodes() + BLK - 1) / BLK);
+        if (l == 1 && macro1) {
+            if (e->nflag_all) {
+                TP_LAUNCH(k_macro_delta, dim3((int)(((long)e->nflag_all * 576 + BLK - 1) / BLK)), dim3(BLK), 0, s,
+                                   F.g, C.g, e->d_E, e->d_M, e->d_KelF, e->d_flag_all, e->nflag_all, e->d_dK);
+                count_launch(g);
+            }
+            TP_LAUNCH(k_macro_diag, dim3(gn), dim3(BLK), 0, s, F.g, C.g, e->d_E, e->d_M, e->d_KelF, e->d_fidx1,
+                               C.dinv);
+            count_launch(g, 8.0 * 8.0 * C.g.own_elems() + 24.0 * C.g.owned_nodes(), 8.0 * 64 * 3 * C.g.owned_nodes());
+            return TP_OK;
+        }
         if (C.kind == LV_MACRO) {  // (not reached: handled above)
             TP_LAUNCH(k_elem_diag, dim3(gn), dim3(BLK), 0, s, C.g, C.Kel, C.dinv);
             count_launch(g, 8.0 * (24.0 + 3.0) * C.g.owned_nodes(), 24.0 * C.g.owned_nodes());
@@ -925,7 +937,25 @@ extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, dou
             TP_LAUNCH(k_elem_to_dia, dim3(gn, 27), dim3(BLK), 0, s, C.g, C.Kel, C.S, C.dinv);
             count_launch(g, 8.0 * (576.0 * C.g.elems_stored() + 243.0 * C.g.owned_nodes()), 9.0 * 64 * C.g.owned_nodes());
         }
+        return TP_OK;
+    };
+    if (two_pass) {
+        for (int l = 1; l < mg.nlv; l++) TP_TRY(galerkin_level(l));
+        bool early = false;
+        if (mg.nlv > 2) {  // the coarsest level's stencil first; its factorisation starts at once (one rank)
+            TP_TRY(finish_level(mg.nlv - 1));
+            TP_TRY(mg.coarse_direct_early(&early));
+        }
+        TP_TRY(mg.setup_matfree_level(0, e->KE));
+        for (int l = 1; l < mg.nlv - (mg.nlv > 2 ? 1 : 0); l++) TP_TRY(finish_level(l));
+    } else {
+        TP_TRY(mg.setup_matfree_level(0, e->KE));
+        for (int l = 1; l < mg.nlv; l++) {
+            TP_TRY(galerkin_level(l));
+            TP_TRY(finish_level(l));
+        }
     }
+    mg.side_stream = e->aux_stream;  // (idle from here on: a second stream for the spectra chains, mg.h)
     mg.ready = true;
     TP_TRY(mg.setup_replicated());
     if (mg.opt.ksp_mode == 0) TP_TRY(mg.estimate_spectra(mg.opt.fine_eig ? 0 : 1));  // Chebyshev windows
