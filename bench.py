@@ -71,24 +71,137 @@ def parse():
                    help="weak: the workload mesh per GPU (default); strong: the workload mesh split over the GPUs")
     p.add_argument("--no-cube256", action="store_true", help="skip the 256^3 fine-kernel roofline entry")
     p.add_argument("--no-other-scaling", action="store_true", help="N > 1: do not also time the complementary scaling case (strong beside weak)")
+    p.add_argument("--budget-s", type=float, default=1500.0,
+                   help="wall-clock budget of the whole run: N > 1 skips the complementary scaling case when the main case took over "
+                        "half of it, and a self-spawned run (python bench.py --gpus N) kills its ranks at this limit")
+    p.add_argument("--no-parity", action="store_true", help="skip the comparison of the GPU step with the CPU baseline's numbers")
     return p.parse_args()
 
 
-def respawn_under_torchrun(n):
-    """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run ... bench.py --gpus N`."""
+def spawn_ranks(n, limit_s):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* as torch.distributed.run would set them, rendezvous on 127.0.0.1), each in a process group of its own, and
+    ALWAYS come back: a rank that fails takes the others down, ranks that outlive rank 0's JSON line by 30 s are killed
+    (the line is complete by then: teardown is all that is left), and nothing outlives `limit_s` seconds."""
+    import signal
     import socket
+    import subprocess
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    os.execv(sys.executable, cmd)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TP_BENCH_SPAWNED="1")
+        env.setdefault("OMP_NUM_THREADS", "1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, start_new_session=True))
+
+    def kill_all():
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except Exception:
+                pass
+
+    t0 = time.time()
+    rank0_done = None
+    rc = 0
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                rc = bad[0] if bad[0] > 0 else 128 - bad[0]
+                sys.stderr.write("bench.py: a rank exited with %s; stopping the others\n" % bad[0])
+                break
+            if all(c == 0 for c in codes):
+                break
+            if codes[0] == 0 and rank0_done is None:
+                rank0_done = time.time()
+            if rank0_done is not None and time.time() - rank0_done > 30.0:
+                sys.stderr.write("bench.py: ranks %s still alive 30 s after rank 0 finished (teardown): killed\n" %
+                                 [i for i, c in enumerate(codes) if c is None])
+                break
+            if time.time() - t0 > limit_s:
+                sys.stderr.write("bench.py: %d ranks did not finish within %.0f s: killed\n" % (n, limit_s))
+                if codes[0] is None:   # no line yet: say so on stdout, in the contract's shape
+                    print(json.dumps({"metric": METRIC, "value": None, "unit": "DOF-updates/s", "n_gpus": n,
+                                      "error": "ranks did not finish within %.0f s" % limit_s}), flush=True)
+                    rc = 4
+                break
+            time.sleep(0.2)
+    finally:
+        kill_all()
+    sys.exit(rc)
+
+
+METRIC = "DOF-updates/s per design iter (assembly+PCG+filter)"
+
+
+class Watchdog:
+    """A wall-clock limit per phase of the run.  When a phase overruns, every thread's Python stack goes to stderr
+    (faulthandler), rank 0 prints the line it has so far with an "error" key -- unless the complete line is already out
+    -- and the process ends through os._exit: non-zero before the line, zero after it (only teardown was left).  Runs on
+    a daemon thread: library calls release the GIL, so a rank stuck inside a collective or a kernel is still caught."""
+
+    def __init__(self, json_fd, rank):
+        import threading
+        self.json_fd, self.rank = json_fd, rank
+        self.name, self.deadline, self.partial, self.line_out = "start", None, {}, False
+        self.t = threading.Thread(target=self._run, daemon=True)
+        self.t.start()
+
+    def phase(self, name, seconds):
+        if os.environ.get("TP_BENCH_TEST_OVERRUN") == name:     # tests/test_bench_line.py: this phase hangs
+            self.name, self.deadline = name, time.time() + 1.0
+            time.sleep(3600)
+        self.name, self.deadline = name, time.time() + seconds
+        if os.environ.get("TP_BENCH_TRACE"):
+            sys.stderr.write("[bench r%d %.2f] %s (limit %.0f s)\n" % (self.rank, time.time() % 1000, name, seconds))
+            sys.stderr.flush()
+
+    def _run(self):
+        import faulthandler
+        while True:
+            time.sleep(0.5)
+            d = self.deadline
+            if d is not None and time.time() > d:
+                sys.stderr.write("bench.py[rank %d]: phase '%s' exceeded its wall-clock limit\n" % (self.rank, self.name))
+                try:
+                    faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+                    sys.stderr.flush()
+                    if self.rank == 0 and not self.line_out:
+                        out = dict(self.partial)
+                        out.setdefault("metric", METRIC)
+                        out.setdefault("value", None)
+                        out["error"] = "phase '%s' exceeded its wall-clock limit" % self.name
+                        os.write(self.json_fd, (json.dumps(out) + "\n").encode())
+                finally:
+                    os._exit(0 if self.line_out else 3)
+
+
+def cpu_baseline_worker(argv):
+    """`bench.py --cpu-baseline-worker out.json sample rtol fine_eig ex ey ez ndof budget nlv nsmooth ncoarse cycles direct`:
+    the oracle's design iteration in a process of its own (all host cores, nothing of torch or the GPU library loaded)."""
+    out, sample, rtol, fine_eig, ex, ey, ez, ndof, budget, nlv, nsmooth, ncoarse, cycles, direct = argv
+    res = cpu_baseline(sample, float(rtol), int(fine_eig), (int(ex), int(ey), int(ez)), int(ndof), float(budget), int(nlv),
+                       int(nsmooth), int(ncoarse), "" if cycles == "-" else cycles, bool(int(direct)))
+    with open(out + ".tmp", "w") as f:
+        json.dump(res, f)
+    os.replace(out + ".tmp", out)
 
 
 def cpu_step(orc, el, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, matfree_too, coarse_direct=False):
     """One design iteration of the oracle (the reference's data path: assembled CSR + Galerkin SpGEMM) on `el` elements;
-    with matfree_too the solve is repeated with the fine-level operator applied matrix-free (OpenMP gather).  Returns
-    (n_dof, its, seconds assembled, seconds matrix-free or None, levels)."""
+    with matfree_too the solve is repeated with the fine-level operator applied matrix-free (OpenMP gather).  Returns a
+    dict: n_dof, its, seconds (assembled), seconds_mf (matrix-free or None), levels, and the numbers the GPU step is
+    compared with at the same mesh: fx, gx, rel_residual, hist (||r_k||, k = 0 .. its), phase seconds."""
     ex, ey, ez = el
     while nlv > 1 and (ex % (1 << (nlv - 1)) or ey % (1 << (nlv - 1)) or ez % (1 << (nlv - 1))):
         nlv -= 1
@@ -103,6 +216,7 @@ def cpu_step(orc, el, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, matfree_too
         mg.set_cycles([int(v) for v in cycles.split(",")][: max(nlv - 1, 0)])
     t0 = time.perf_counter()
     xt, xp = flt.project(1, x)
+    tf = time.perf_counter()
     mg.assemble(KE, orc.simp(xp), N)
     t1 = time.perf_counter()
     U, its, hist = mg.solve(R * N, rtol=rtol)
@@ -118,34 +232,66 @@ def cpu_step(orc, el, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, matfree_too
         U2, its2, _ = mg.solve(R * N, rtol=rtol)
         t_mf = (t1 - t0) + (time.perf_counter() - t4) + (t3 - t2)
         mg.fine_matfree(False)
-    return 3 * nx * ny * nz, its, t3 - t0, t_mf, nlv
+    import numpy as np
+    hist = np.asarray(hist, dtype=float)
+    return {"n_dof": 3 * nx * ny * nz, "its": int(its), "seconds": t3 - t0, "seconds_mf": t_mf, "levels": nlv,
+            "fx": float(fx), "gx": float(gx), "rel_residual": float(hist[min(its, len(hist) - 1)] / hist[0]) if len(hist) else None,
+            "hist": [float(v) for v in hist[:64]], "df_abs_sum": float(np.abs(df).sum()),
+            "phase_seconds": {"filter": tf - t0, "assemble": t1 - tf, "solve": t2 - t1, "sensitivities+filter": t3 - t2}}
+
+
+def host_description():
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return {"cpu_model": model, "os_cpu_count": os.cpu_count(), "usable_cpus": usable}
 
 
 def cpu_baseline(sample, rtol, fine_eig, gpu_el, gpu_ndof, budget_s, nlv=4, nsmooth=4, ncoarse=30, cycles="", coarse_direct=False):
     """the oracle timed on the host cores beside the GPU line -- on the SAME mesh when the budget
-    (--cpu-budget seconds, default 240) allows it, judged from a first run on the bounded sample mesh; both data paths:
-    assembled CSR (the reference's) and matrix-free fine level."""
+    (--cpu-budget seconds) allows it, judged from a first run on the bounded sample mesh; both data paths: assembled
+    CSR (the reference's) and matrix-free fine level.  OpenMP over ALL usable host cores (sched_getaffinity; an
+    OMP_NUM_THREADS in the environment wins), count and CPU model stated."""
+    host = host_description()
+    if "TP_CPU_THREADS" in os.environ:
+        os.environ["OMP_NUM_THREADS"] = os.environ["TP_CPU_THREADS"]
+    elif os.environ.get("OMP_NUM_THREADS", "1") == "1":   # "1" is what launchers set for their ranks, not a choice made for this leg
+        os.environ["OMP_NUM_THREADS"] = str(host["usable_cpus"])
     from oracle import oracle as orc
-    cores = int(os.environ.get("OMP_NUM_THREADS", min(os.cpu_count() or 1, 16)))
+    cores = int(os.environ["OMP_NUM_THREADS"])
     sel = tuple(int(v) for v in sample.split("x"))
-    nd, its, t, t_mf, lv = cpu_step(orc, sel, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, True, coarse_direct)
-    est = (t + t_mf) * gpu_ndof / nd  # work per DOF and iteration count are close to mesh independent
+    r = cpu_step(orc, sel, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, True, coarse_direct)
+    est = (r["seconds"] + r["seconds_mf"]) * gpu_ndof / r["n_dof"]  # work per DOF and iteration count are close to mesh independent
     what = "%dx%dx%d elements (%d DOF -- NOT the GPU line's %d-DOF mesh: the same mesh was estimated at %.0f s, over the --cpu-budget of %.0f s)" % (
-        sel + (nd, gpu_ndof, est, budget_s))
-    same = False
-    if est <= budget_s and tuple(gpu_el) != sel:
-        nd, its, t, t_mf, lv = cpu_step(orc, tuple(gpu_el), rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, True, coarse_direct)
-        what = "%dx%dx%d elements (%d DOF: the GPU line's mesh)" % (tuple(gpu_el) + (nd,))
+        sel + (r["n_dof"], gpu_ndof, est, budget_s))
+    same = tuple(gpu_el) == sel
+    if est <= budget_s and not same:
+        r = cpu_step(orc, tuple(gpu_el), rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, True, coarse_direct)
         same = True
+    if same:
+        what = "%dx%dx%d elements (%d DOF: the GPU line's mesh)" % (tuple(gpu_el) + (r["n_dof"],))
+    nd, t, t_mf = r["n_dof"], r["seconds"], r["seconds_mf"]
     return {"value": nd / t, "unit": "DOF-updates/s", "cores": cores, "kind": "port", "same_mesh": same,
-            "sample_n_dof": nd, "gpu_line_n_dof": gpu_ndof,
+            "omp_num_threads": cores, "host": host,
+            "sample_n_dof": nd, "gpu_line_n_dof": gpu_ndof, "seconds": t, "phase_seconds": r["phase_seconds"],
+            "fx": r["fx"], "gx": r["gx"], "cg_its": r["its"], "rel_residual": r["rel_residual"], "hist": r["hist"],
             "matrix_free": {"value": nd / t_mf, "unit": "DOF-updates/s", "seconds": t_mf,
                             "what": "the same step with the fine-level operator of the solve applied from KE and the moduli (OpenMP gather over "
                                     "the 8 elements of a node) instead of the assembled CSR; Galerkin operators as before"},
             "sample": "1 step on %s, %d levels, Chebyshev(%d) / coarse %s%s as on the GPU line, CG its %d, %.2f s; assembled CSR + "
-                      "Galerkin SpGEMM (the reference's data path), OpenMP on %d threads" % (what, lv, nsmooth,
-                                                                                             "exact (banded Cholesky)" if coarse_direct else "Chebyshev(%d)" % ncoarse,
-                                                                                             " / cycles per level " + cycles if cycles else "", its, t, cores)}
+                      "Galerkin SpGEMM (the reference's data path), OpenMP on %d threads (%s, os.cpu_count %s)" % (
+                          what, r["levels"], nsmooth, "exact (banded Cholesky)" if coarse_direct else "Chebyshev(%d)" % ncoarse,
+                          " / cycles per level " + cycles if cycles else "", r["its"], t, cores, host["cpu_model"], host["os_cpu_count"])}
 
 
 def fine_kernel_times(tp, torch, ex, ey, ez, reps):
@@ -179,15 +325,65 @@ def fine_kernel_times(tp, torch, ex, ey, ez, reps):
     spmv = timed(lambda: le.MatMult(u, y), reps)
     cheb = (timed(lambda: le.smooth(0, u, y, k, False), max(reps // 4, 2)) -
             timed(lambda: le.smooth(0, u, y, 0, False), max(reps // 4, 2))) / k
+    torch.cuda.synchronize()
+    grid.close()
     return spmv, cheb, (ex + 1) * (ey + 1) * (ez + 1), ex * ey * ez
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-worker":
+        return cpu_baseline_worker(sys.argv[2:])
     a = parse()
+    t_start = time.time()
     # multi-process GPU work on this driver stack needs dmabuf IPC (RCCL / tensor sharing fail with the legacy mode)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        respawn_under_torchrun(a.gpus)
+        spawn_ranks(a.gpus, a.budget_s)
+    if os.environ.get("TP_BENCH_TEST_SLEEPER") and os.environ.get("TP_BENCH_SPAWNED"):   # tests/test_bench_line.py: a rank that hangs
+        time.sleep(3600)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, a.gpus))
+
+    W = WORKLOADS[a.workload]
+    nlv = a.nlvls or W["nlvls"]
+    a.nsmooth = a.nsmooth or W["nsmooth"]
+    a.ncoarse = a.ncoarse or W["ncoarse"]
+    if not a.cycles and not a.nlvls:
+        a.cycles = W.get("cycles", "")     # (--cycles 1 forces plain V-cycles; an overridden depth takes no pattern along)
+
+    # ---- the CPU baseline runs FIRST and in a process of its own (all host cores): the GPU phases follow
+    # it, so the device work is the last thing the run does, and none of the oracle's threads or memory is around when
+    # the GPU step is timed.  It solves the same mesh with the same cycle; its fx / iteration count / residual history are
+    # what the GPU step is checked against further down ("parity" in the line).
+    cpu_res, cpu_err = None, None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        import subprocess
+        import tempfile
+        ex0, ey0, ez0 = W["el"]
+        direct_guess = int(a.coarse == "direct")
+        fd, cpu_json = tempfile.mkstemp(suffix=".json", prefix="tp_cpu_baseline_")
+        os.close(fd)
+        os.unlink(cpu_json)
+        env = dict(os.environ)
+        env.pop("OMP_NUM_THREADS", None) if env.get("OMP_NUM_THREADS") == "1" else None
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", cpu_json, a.cpu_sample, repr(a.rtol), str(a.fine_eig),
+               str(ex0), str(ey0), str(ez0), str(3 * (ex0 + 1) * (ey0 + 1) * (ez0 + 1)), repr(a.cpu_budget), str(nlv), str(a.nsmooth),
+               str(a.ncoarse), a.cycles or "-", str(direct_guess)]
+        try:
+            p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=a.cpu_budget * 1.5 + 120, start_new_session=True)
+            if p.returncode == 0 and os.path.exists(cpu_json):
+                cpu_res = json.load(open(cpu_json))
+            else:
+                cpu_err = "oracle process exited with %d: %s" % (p.returncode, p.stderr[-400:])
+        except subprocess.TimeoutExpired:
+            cpu_err = "oracle process exceeded %.0f s" % (a.cpu_budget * 1.5 + 120)
+        finally:
+            if os.path.exists(cpu_json):
+                os.unlink(cpu_json)
+
     import torch
     import torch.distributed as dist
     import topopt_in_petsc_amd as tp
@@ -197,56 +393,66 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, a.gpus))
+    wd = Watchdog(json_fd, rank)
+    wd.partial.update({"n_gpus": world, "steps": a.steps, "warmup": a.warmup, "unit": "DOF-updates/s"})
+    wd.phase("device + process group", 180)
     dev = 0 if a.same_device else local_rank
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
         if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev), timeout=datetime.timedelta(seconds=300))
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
 
-    W = WORKLOADS[a.workload]
     ex, ey, ezg = W["el"]
     ftype, bc = W.get("ftype", 1), W.get("bc", "cantilever")
-    nlv = a.nlvls or W["nlvls"]
-    a.nsmooth = a.nsmooth or W["nsmooth"]
-    a.ncoarse = a.ncoarse or W["ncoarse"]
-    if not a.cycles and not a.nlvls:
-        a.cycles = W.get("cycles", "")     # (--cycles 1 forces plain V-cycles; an overridden depth takes no pattern along)
     if a.scaling == "strong" and (ezg % world or (ezg // world) % (1 << (nlv - 1))):
         raise SystemExit("strong scaling: %d element layers do not split into %d slabs of whole coarse layers of a %d-level "
                          "hierarchy (try --nlvls %d)" % (ezg, world, nlv, max(1, (ezg // max(world, 1)).bit_length() - 1)))
     ez = ezg * world if a.scaling == "weak" else ezg  # weak: fixed slab per GPU; strong: fixed mesh
     nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
     ndof = 3 * nx * ny * nz
-    grid = tp.Grid(nx, ny, nz, h, rank=rank, nranks=world)
-    le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=nlv, rtol=a.rtol, fine_eig=a.fine_eig, ncoarse=a.ncoarse, nsmooth=a.nsmooth,
-                                                    coarse_direct=int(a.coarse == "direct")))
-    if a.cycles:
-        le.set_cycles([int(v) for v in a.cycles.split(",")])
-    rmin = W.get("rmin", 2.56 * h)
-    flt = tp.Filter(grid, ftype, rmin)
-    le.SetUpLoadAndBC_MBB() if bc == "mbb" else le.SetUpLoadAndBC()
-    x = grid.synth_density(12345)
-    xt, xp, df, dg = grid.elem_vec(), grid.elem_vec(), grid.elem_vec(), grid.elem_vec()
     Emin, Emax, penal, volfrac = 1e-9, 1.0, 3.0, 0.12
-    info = {}
 
-    def step(le=le):
-        flt.FilterProject(x, xt, xp)                       # main.cc:98
-        le.U.zero_()                                       # cold start: every step does the full solve
-        fx, gx = le.ComputeObjectiveConstraintsSensitivities(df, dg, xp, Emin, Emax, penal, volfrac)  # main.cc:62
-        df.mul_(10.0 / fx)                                 # main.cc:68-73 (fscale)
-        flt.Gradients(x, xt, df, [dg])                     # main.cc:76
-        info.update(its=le.last_its, fx=fx, gx=gx, rel_res=le.last_rnorm / le.last_bnorm)
-        info["solve_s"] = info.get("solve_s", 0.0) + le.last_solve_s
-        info["solve_its"] = info.get("solve_its", 0) + le.last_its
+    class Case:
+        """grid + solver + filter + design vectors of one mesh; step() is one design-iteration pass of the hot path.
+        Nothing here is captured by a closure or a default argument: close() really releases the library objects."""
+
+        def __init__(self, nz_nodes, rmin, nlv_, ncoarse_, nsmooth_, direct, cycles):
+            self.grid = tp.Grid(nx, ny, nz_nodes, h, rank=rank, nranks=world)
+            self.le = self.solver(nlv_, ncoarse_, nsmooth_, direct, cycles)
+            self.flt = tp.Filter(self.grid, ftype, rmin)
+            g = self.grid
+            self.x = g.synth_density(12345)
+            self.xt, self.xp, self.df, self.dg = g.elem_vec(), g.elem_vec(), g.elem_vec(), g.elem_vec()
+            self.info = {}
+
+        def solver(self, nlv_, ncoarse_, nsmooth_, direct, cycles):
+            le_ = tp.LinearElasticity(self.grid, tp.SolverOptions(nlvls=nlv_, rtol=a.rtol, fine_eig=a.fine_eig, ncoarse=ncoarse_,
+                                                                  nsmooth=nsmooth_, coarse_direct=int(direct)))
+            if cycles:
+                le_.set_cycles([int(v) for v in cycles.split(",")])
+            le_.SetUpLoadAndBC_MBB() if bc == "mbb" else le_.SetUpLoadAndBC()
+            return le_
+
+        def step(self, le_=None, hist_cap=0):
+            le_ = le_ or self.le
+            info = self.info
+            self.flt.FilterProject(self.x, self.xt, self.xp)                 # main.cc:98
+            le_.U.zero_()                                                     # cold start: every step does the full solve
+            fx, gx = le_.ComputeObjectiveConstraintsSensitivities(self.df, self.dg, self.xp, Emin, Emax, penal, volfrac,
+                                                                  hist_cap=hist_cap)                                   # main.cc:62
+            self.df.mul_(10.0 / fx)                                           # main.cc:68-73 (fscale)
+            self.flt.Gradients(self.x, self.xt, self.df, [self.dg])           # main.cc:76
+            info.update(its=le_.last_its, fx=fx, gx=gx, rel_res=le_.last_rnorm / le_.last_bnorm)
+            info["solve_s"] = info.get("solve_s", 0.0) + le_.last_solve_s
+            info["solve_its"] = info.get("solve_its", 0) + le_.last_its
+
+        def close(self):
+            torch.cuda.synchronize()
+            self.grid.close()     # solver(s), filter, optimiser first, then the grid and its communicators
 
     def barrier():
         torch.cuda.synchronize()
@@ -254,16 +460,35 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(v):
+        if world > 1:
+            tt = torch.tensor([v], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            v = float(tt[0])
+        return v
+
+    wd.phase("set-up of the %s case" % a.scaling, 300)
+    rmin = W.get("rmin", 2.56 * h)
+    case = Case(nz, rmin, nlv, a.ncoarse, a.nsmooth, a.coarse == "direct", a.cycles)
+    grid, le, flt, info = case.grid, case.le, case.flt, case.info
+    x, df, dg = case.x, case.df, case.dg
+    step = case.step
+    wd.phase("warm-up", 300 + 60 * a.warmup)
     for _ in range(a.warmup):
         step()
     info.clear()
     le.pop_stats()
     barrier()
+    wd.phase("timed region", 120 + 60 * a.steps)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
+    wd.phase("after the timed region", 300)
+    dt = max_over_ranks(dt)
+    t_step = dt / max(a.steps, 1)
+    wd.partial.update({"value": ndof / t_step, "ms_per_step": 1e3 * t_step, "note": "partial line: only the timed region finished"})
     alg_bytes, flops, launches = le.pop_stats()
     coarse_is_direct = bool(le.coarse_direct_active())  # (falls back to the Chebyshev run where the level is too large / distributed)
     # MMA::Update on the same design vectors (MMA.cc:522-946 on the device), reported separately
@@ -278,14 +503,15 @@ def main():
         torch.cuda.synchronize()
         t_m.append(time.perf_counter() - tm0)
     mma_ms = 1e3 * min(t_m)
-    del mma
+    mma.close()
+    mma = None
     # ---- the cycle SURVEY 8(d) / BASELINE.md state for this metric (the reference's counts: 4 levels, 4 smoothing steps,
     # 30 coarse steps, V-cycles; LinearElasticity.cc:621-635) in the same run, beside the tuned cycle of `value`
     stated = None
     if world == 1 and not a.no_stated_cycle and a.workload == "cantilever128":
+        wd.phase("stated cycle", 300)
         keep = dict(info)
-        le4 = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=4, rtol=a.rtol, fine_eig=a.fine_eig, ncoarse=30, nsmooth=4))
-        le4.SetUpLoadAndBC()
+        le4 = case.solver(4, 30, 4, False, "")
         step(le4)
         barrier()
         ts0 = time.perf_counter()
@@ -295,14 +521,29 @@ def main():
         stated = {"ms_per_step": 1e3 * (time.perf_counter() - ts0) / 3, "cg_its": le4.last_its, "rel_residual": le4.last_rnorm / le4.last_bnorm,
                   "value": ndof / ((time.perf_counter() - ts0) / 3),
                   "cycle": "4 levels, Chebyshev(4)-Jacobi smoothing, coarse Chebyshev(30), V-cycles (the counts of LinearElasticity.cc:621-635)"}
-        del le4
+        le4.close()
+        le4 = None
         info.clear()
         info.update(keep)
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt[0])
-    t_step = dt / max(a.steps, 1)
+
+    # ---- parity at the line's own mesh: the CPU baseline solved the same problem with the same cycle; one more GPU
+    # step (outside the timed region, residual history recorded) is compared with its numbers
+    parity = None
+    if cpu_res is not None and cpu_res.get("same_mesh") and not a.no_parity:
+        wd.phase("parity step", 300)
+        keep = dict(info)
+        step(hist_cap=64)
+        hg = [float(v) for v in le.last_hist]
+        ho = cpu_res["hist"]
+        k = min(len(hg), len(ho), 10)
+        parity = {"against": "cpu_baseline (oracle, same mesh, same cycle)", "its_gpu": le.last_its, "its_cpu": cpu_res["cg_its"],
+                  "its_equal": le.last_its == cpu_res["cg_its"], "fx_gpu": info["fx"], "fx_cpu": cpu_res["fx"],
+                  "fx_rel_err": abs(info["fx"] / cpu_res["fx"] - 1.0), "gx_abs_err": abs(info["gx"] - cpu_res["gx"]),
+                  "hist_max_rel_err_first10": max(abs(hg[i] / ho[i] - 1.0) for i in range(k)) if k else None,
+                  "hist_max_rel_err_all": max(abs(hg[i] / ho[i] - 1.0) for i in range(min(len(hg), len(ho)))) if k else None,
+                  "hist_compared": k}
+        info.clear()
+        info.update(keep)
 
     # ---- roofline ---------------------------------------------------------------------------------
     # Dominant kernel of the step (rocprofv3: profiles/): k_matfree_tile<EPI_CHEB,0>, the fine-level matrix-free
@@ -335,45 +576,37 @@ def main():
     if world > 1 and not a.no_other_scaling:
         o_scal = "strong" if a.scaling == "weak" else "weak"
         ok = not (o_scal == "strong" and (ezg % world or (ezg // world) % (1 << (nlv - 1))))
-        if ok:
+        used = max_over_ranks(time.time() - t_start)      # (the same decision on every rank)
+        if ok and used > 0.5 * a.budget_s:
+            other = {"scaling": o_scal, "skipped": "the %s case used %.0f s, over half of --budget-s %.0f" % (a.scaling, used, a.budget_s)}
+        elif ok:
+            wd.phase("set-up of the %s case" % o_scal, 300)
             ez2 = ezg if o_scal == "strong" else ezg * world
-            grid2 = tp.Grid(nx, ny, ez2 + 1, h, rank=rank, nranks=world)
-            le2 = tp.LinearElasticity(grid2, tp.SolverOptions(nlvls=nlv, rtol=a.rtol, fine_eig=a.fine_eig, ncoarse=a.ncoarse, nsmooth=a.nsmooth,
-                                                              coarse_direct=int(a.coarse == "direct")))
-            if a.cycles:
-                le2.set_cycles([int(v) for v in a.cycles.split(",")])
-            flt2 = tp.Filter(grid2, ftype, 2.56 * h)
-            le2.SetUpLoadAndBC_MBB() if bc == "mbb" else le2.SetUpLoadAndBC()
-            x2 = grid2.synth_density(12345)
-            xt2, xp2, df2, dg2 = grid2.elem_vec(), grid2.elem_vec(), grid2.elem_vec(), grid2.elem_vec()
-
-            def step2():
-                flt2.FilterProject(x2, xt2, xp2)
-                le2.U.zero_()
-                fx2, _ = le2.ComputeObjectiveConstraintsSensitivities(df2, dg2, xp2, Emin, Emax, penal, volfrac)
-                df2.mul_(10.0 / fx2)
-                flt2.Gradients(x2, xt2, df2, [dg2])
-
+            case2 = Case(ez2 + 1, 2.56 * h, nlv, a.ncoarse, a.nsmooth, a.coarse == "direct", a.cycles)
+            wd.phase("%s case" % o_scal, 300 + 60 * (a.warmup + a.steps))
             for _ in range(a.warmup):
-                step2()
+                case2.step()
             barrier()
             t2 = time.perf_counter()
             for _ in range(a.steps):
-                step2()
+                case2.step()
             barrier()
-            dt2 = time.perf_counter() - t2
-            if world > 1:
-                tt2 = torch.tensor([dt2], dtype=torch.float64, device="cuda")
-                dist.all_reduce(tt2, op=dist.ReduceOp.MAX)
-                dt2 = float(tt2[0])
+            dt2 = max_over_ranks(time.perf_counter() - t2)
             ndof2 = 3 * nx * ny * (ez2 + 1)
+            le2, grid2 = case2.le, case2.grid
             other = {"scaling": o_scal, "value": ndof2 / (dt2 / a.steps), "unit": "DOF-updates/s", "ms_per_step": 1e3 * dt2 / a.steps,
                      "n_dof": ndof2, "mesh": "%dx%dx%d elements over %d GPUs" % (ex, ey, ez2, world), "cg_its": le2.last_its,
                      "rel_residual": le2.last_rnorm / le2.last_bnorm, "halo_overlap": grid2.halo_overlap, "comm": grid2.comm_kind,
                      "coarse_solve": "direct" if le2.coarse_direct_active() else "chebyshev(%d)" % a.ncoarse}
-            del le2, flt2, grid2
+            le2 = grid2 = None
+            wd.phase("teardown of the %s case" % o_scal, 120)
+            barrier()
+            case2.close()     # every rank, between barriers: the case's communicators go together
+            case2 = None
+            barrier()
         else:
             other = {"scaling": o_scal, "skipped": "%d element layers do not split into %d slabs of whole coarse layers of a %d-level hierarchy" % (ezg, world, nlv)}
+    wd.phase("roofline measurements", 300)
 
     # ---- the roofline kernel where it runs: two more steps (outside the timed region, so that the 126 event pairs per
     # step do not touch `value`) with a HIP event pair around every launch of the fine level's fused Chebyshev step, on
@@ -442,6 +675,7 @@ def main():
     # Infinity Cache), measured in this run on rank 0 of a 1-GPU job
     if world == 1 and not a.no_cube256 and a.workload == "cantilever128":
         u = y = None
+        wd.phase("256^3 fine-level kernels", 300)
         s256, c256, nn, ne = fine_kernel_times(tp, torch, 256, 256, 256, 40)
         rec = json.load(open(tj)).get("256x256x256") if os.path.exists(tj) else None
         roofline["spmv256"] = {
@@ -472,7 +706,9 @@ def main():
                    "solver_dof_its_per_s": ndof * info.get("solve_its", 0) / max(info.get("solve_s", 0.0), 1e-30),
                    "solve_ms_per_step": 1e3 * info.get("solve_s", 0.0) / max(a.steps, 1),
                    "mma_ms_per_update": mma_ms,
-                   "parallelism": "zslab%d" % world, "comm": grid.comm_kind, "halo_overlap": grid.halo_overlap,
+                   "parallelism": "zslab%d" % world, "comm": grid.comm_kind, "comm_ranks": world,
+                   "comm_calls": dict(zip(("halo_exchanges", "all_reduces"), grid.comm_stats())) if grid.comm_kind.startswith("rccl") else None,
+                   "backend": (a.backend if world > 1 else None), "halo_overlap": grid.halo_overlap,
                    "scaling_note": "weak: %dx%dx%d elements per GPU" % (ex, ey, ezg) if a.scaling == "weak" else "strong: fixed %dx%dx%d mesh" % (ex, ey, ezg), "kernel_launches_per_step": launches / max(a.steps, 1),
                    "stated_cycle": stated,
                    "alg_GB_per_step": alg_bytes / max(a.steps, 1) / 1e9,
@@ -481,21 +717,42 @@ def main():
     }
     if other is not None:
         out["other_scaling"] = other
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.cpu_sample, a.rtol, a.fine_eig, (ex, ey, ezg), ndof, a.cpu_budget, nlv, a.nsmooth, a.ncoarse, a.cycles, coarse_is_direct)
+    if parity is not None:
+        if bool(coarse_is_direct) != (a.coarse == "direct"):
+            parity["note"] = "the GPU fell back to the Chebyshev coarse run while the CPU baseline solved the coarsest level exactly: cycles differ"
+        out["parity"] = parity
+    if cpu_res is not None:
+        cpu_res.pop("hist", None)
+        out["cpu_baseline"] = cpu_res
+    elif cpu_err is not None:
+        out["cpu_baseline"] = {"value": None, "unit": "DOF-updates/s", "cores": 0, "kind": "port", "sample": "failed", "error": cpu_err}
+    wd.phase("teardown", 60)
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+    wd.line_out = True        # from here on an overrun ends the process with exit code 0: the measurement is complete
+    u = y = x = df = dg = step = grid = le = flt = info = None
     if world > 1:
-        # orderly teardown: solver objects (and the library's own RCCL communicator) go before the process group,
-        # on all ranks together
+        # orderly teardown on all ranks together: the library objects (solvers, filters, grid, the library's own RCCL
+        # communicators) are destroyed explicitly between two barriers, then the process group.  Nothing is left to
+        # destructors that would run after the process group is gone.
+        barrier()
+        case.close()
+        case = None
         import gc
-        torch.cuda.synchronize()
-        dist.barrier()
-        le = flt = grid = None
         gc.collect()
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
+        # ranks of a multi-process job end here, without the interpreter's finalisation (which has hung once on a
+        # driver box after the line was out, GPUTEST_r03): exit hooks are still run, streams flushed
+        import atexit
+        sys.stdout.flush()
+        sys.stderr.flush()
+        try:
+            atexit._run_exitfuncs()
+        finally:
+            os._exit(0)
+    case.close()
 
 
 if __name__ == "__main__":

@@ -4,6 +4,7 @@ import json
 import os
 import subprocess
 import sys
+import time
 
 import pytest
 
@@ -13,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_with_the_contract_keys():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-cube256",
-                        "--cpu-sample", "16x8x8"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--cpu-sample", "16x8x8"], capture_output=True, text=True, timeout=150, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [ln for ln in r.stdout.split("\n") if ln.strip()]
     assert len(lines) == 1, r.stdout
@@ -36,22 +37,21 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert 0 < rf["back_to_back"]["frac"] < 1 and rf["back_to_back"]["avg_launch_ms"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and isinstance(cb["sample"], str)
+    assert cb["cores"] == cb["omp_num_threads"] and cb["host"]["usable_cpus"] >= 1 and cb["same_mesh"] is True
+    # the CPU baseline solved the line's own mesh with the line's own cycle: the GPU step is checked against it in the line
+    p = d["parity"]
+    assert p["its_equal"] and p["its_gpu"] == cb["cg_its"], p
+    assert p["fx_rel_err"] <= 1e-9 and p["hist_max_rel_err_first10"] <= 1e-8 and p["gx_abs_err"] <= 1e-13, p
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("scaling", ["weak", "strong"])
-def test_bench_spawns_its_own_ranks(scaling):
-    """`python bench.py --gpus 2` without a launcher re-executes itself under torch.distributed.run (what the driver's
-    scaling run does); here both slabs share the one GPU of the box (--same-device, host-staged gloo hooks)"""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-device", "--backend", "gloo",
-                        "--workload", "tiny", "--steps", "2", "--warmup", "1", "--scaling", scaling],
-                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+def _check_two_rank_line(r, scaling):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.split("\n") if ln.strip()]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
+    assert "error" not in d, d
     assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["value"] > 0
-    assert d["config"]["parallelism"] == "zslab2" and d["config"]["halo_overlap"] > 0
+    assert d["config"]["parallelism"] == "zslab2" and d["config"]["halo_overlap"] > 0 and d["config"]["comm_ranks"] == 2
     ez = 32 if scaling == "weak" else 16
     assert "32x16x%d elements" % ez in d["config"]["workload"]
     assert "cpu_baseline" not in d          # rank 0 of a 1-GPU job only
@@ -59,6 +59,56 @@ def test_bench_spawns_its_own_ranks(scaling):
     o = d["other_scaling"]
     assert o["scaling"] == ("strong" if scaling == "weak" else "weak") and o["value"] > 0 and o["cg_its"] > 0
     assert "32x16x%d elements" % (16 if scaling == "weak" else 32) in o["mesh"]
+
+
+TWO_RANKS = ["--gpus", "2", "--same-device", "--backend", "gloo", "--workload", "tiny", "--steps", "2", "--warmup", "1"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_spawns_its_own_ranks(scaling):
+    """`python bench.py --gpus 2` without a launcher starts its two ranks itself (bench.py: spawn_ranks -- one process
+    group per rank, a deadline, no rank left behind); here both slabs share the one GPU of the box (--same-device,
+    host-staged gloo hooks).  The whole run takes seconds: the limit is what guards the suite against a hang."""
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + TWO_RANKS + ["--scaling", scaling, "--budget-s", "120"],
+                       capture_output=True, text=True, timeout=150, cwd=ROOT)
+    _check_two_rank_line(r, scaling)
+    assert time.time() - t0 < 140
+
+
+@pytest.mark.gpu
+def test_bench_under_torch_distributed_run():
+    """the driver's form for N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py")] + TWO_RANKS,
+                       capture_output=True, text=True, timeout=150, cwd=ROOT)
+    _check_two_rank_line(r, "weak")
+
+
+@pytest.mark.gpu
+def test_bench_ends_with_an_error_line_when_a_phase_overruns():
+    """the wall-clock watchdog: a phase over its limit -> stacks on stderr, ONE line with an "error" key, exit code 3"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-cube256",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=150, cwd=ROOT, env=dict(os.environ, TP_BENCH_TEST_OVERRUN="warm-up"))
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    lines = [ln for ln in r.stdout.split("\n") if ln.strip()]
+    assert len(lines) == 1 and "warm-up" in json.loads(lines[0])["error"] and "exceeded its wall-clock limit" in r.stderr
+
+
+def test_spawner_kills_ranks_that_never_finish():
+    """CPU: bench.py's own launcher comes back when its ranks hang (here: two sleepers), kills their process groups and
+    reports it in the contract's shape"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--budget-s", "3"], capture_output=True, text=True,
+                       timeout=60, cwd=ROOT, env=dict(os.environ, TP_BENCH_TEST_SLEEPER="1"))
+    assert r.returncode == 4, (r.returncode, r.stderr[-1000:])
+    d = json.loads([ln for ln in r.stdout.split("\n") if ln.strip()][-1])
+    assert d["value"] is None and "did not finish" in d["error"] and d["n_gpus"] == 2
+    assert "killed" in r.stderr
 
 
 def test_bench_workloads_are_consistent():

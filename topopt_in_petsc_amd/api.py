@@ -104,6 +104,7 @@ class Grid:
         self._opts = _lib.GridOpts(nx, ny, nz, self.h[0], self.h[1], self.h[2], rank, nranks, self.device.index,
                                    self.stream.cuda_stream, comm_p)
         self.handle = C.c_void_p()
+        self._children = []   # weak references to the solvers / filters / optimisers built on this grid (close() order)
         _chk(self.L.tp_grid_create(C.byref(self.handle), C.byref(self._opts)), "tp_grid_create")
         self.comm_kind = "none" if nranks == 1 else "torch.distributed hooks"
         if nranks > 1 and self.comm.backend == "nccl" and os.environ.get("TP_COMM", "rccl") != "torch":
@@ -113,6 +114,12 @@ class Grid:
     def halo_overlap(self):
         """number of halos that travelled on the second stream, overlapped with interior planes (0 = none)"""
         return int(self.L.tp_grid_overlapped_halos(self.handle))
+
+    def comm_stats(self):
+        """(halo exchanges, all-reduces) the in-library RCCL path has issued so far; (0, 0) on the hooks / one rank"""
+        ex, red = C.c_long(0), C.c_long(0)
+        self.L.tp_grid_comm_stats(self.handle, C.byref(ex), C.byref(red))
+        return ex.value, red.value
 
     def reduction_selftest(self, n, reps):
         """`reps` back-to-back dot products over n doubles, in-kernel reduction tail against the two-launch form: mismatches"""
@@ -153,10 +160,14 @@ class Grid:
         src = 0 if group is None else dist.get_global_rank(group, 0)
         dist.broadcast_object_list(obj, src=src, group=group)
         idb, idb2 = C.create_string_buffer(obj[0][:128], 128), C.create_string_buffer(obj[0][128:], 128)
-        if os.environ.get("TP_RCCL_ONE_COMM"):
-            rc = self.L.tp_grid_use_rccl(self.handle, idb)
-        else:
+        # one communicator by default: halo exchanges and all-reduces share it (stream order decides).  A second
+        # communicator for the exchanges (TP_RCCL_TWO_COMM=1) lets them run beside the reductions, but two communicators
+        # are only guaranteed to make progress concurrently if their kernels can co-reside -- opt-in until a run on two or
+        # more GPUs has passed the self-check and a full solve with it
+        if os.environ.get("TP_RCCL_TWO_COMM"):
             rc = self.L.tp_grid_use_rccl2(self.handle, idb, idb2)
+        else:
+            rc = self.L.tp_grid_use_rccl(self.handle, idb)
         flag = torch.tensor([1 if rc == 0 else 0], device=self.device, dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
         if int(flag[0]) == 0:   # some rank could not create its communicator: every rank goes back to the hooks
@@ -174,10 +185,33 @@ class Grid:
             return
         self.comm_kind = "rccl (in-library)"
 
-    def __del__(self):
+    def _adopt(self, child):
+        import weakref
+        self._children.append(weakref.ref(child))
+
+    def close(self):
+        """Destroy the library objects NOW, dependents first (solvers, filters, optimisers built on this grid), after a
+        device synchronisation -- the explicit, ordered counterpart of XxxDestroy in the reference (main.cc:126-134).
+        Multi-rank programs call this on every rank before the process group goes (bench.py); idempotent."""
+        for ref in list(getattr(self, "_children", ())):
+            obj = ref()
+            if obj is not None:
+                obj.close()
+        self._children = []
         if getattr(self, "handle", None):
+            try:
+                torch.cuda.synchronize(self.device)
+            except Exception:
+                pass
             self.L.tp_grid_destroy(self.handle)
             self.handle = None
+        self.comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # sizes of the local arrays
     @property
@@ -212,15 +246,22 @@ class LinearElasticity:
         self.handle = C.c_void_p()
         self._o = self.opts.c_struct()
         _chk(self.L.tp_elasticity_create(C.byref(self.handle), grid.handle, C.byref(self._o)), "tp_elasticity_create")
+        grid._adopt(self)
         self.U = grid.node_vec(3)       # state, persists across design iterations (warm start, :647)
         self.RHS = grid.node_vec(3)
         self.N = grid.node_vec(3)
         self.last_its, self.last_rnorm, self.last_bnorm, self.last_hist = 0, 0.0, 0.0, None
 
-    def __del__(self):
+    def close(self):
         if getattr(self, "handle", None):
             self.L.tp_elasticity_destroy(self.handle)
             self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     @property
     def KE(self):
@@ -388,11 +429,18 @@ class Filter:
         po = pde_opts.c_struct() if pde_opts else None
         _chk(self.L.tp_filter_create(C.byref(self.handle), grid.handle, filterType, rmin,
                                      C.byref(po) if po else None), "tp_filter_create")
+        grid._adopt(self)
 
-    def __del__(self):
+    def close(self):
         if getattr(self, "handle", None):
             self.L.tp_filter_destroy(self.handle)
             self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     @property
     def ElemConn(self):
@@ -441,12 +489,19 @@ class MMA:
         n_loc = x.numel()
         n_glob = n_global if n_global is not None else grid.part.ex * grid.part.ey * grid.part.ez
         _chk(self.L.tp_mma_create(C.byref(self.handle), grid.handle, n_loc, n_glob, m, _ptr(x)), "tp_mma_create")
+        grid._adopt(self)
         self.last_inner = 0
 
-    def __del__(self):
+    def close(self):
         if getattr(self, "handle", None):
             self.L.tp_mma_destroy(self.handle)
             self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def SetOuterMovelimit(self, Xmin, Xmax, movlim, x, xmin, xmax):
         _chk(self.L.tp_mma_set_outer_movelimit(self.handle, Xmin, Xmax, movlim, _ptr(x), _ptr(xmin), _ptr(xmax)),
