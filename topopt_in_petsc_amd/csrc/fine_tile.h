@@ -137,10 +137,15 @@ __device__ __forceinline__ void fine_tile_run(const TileArgs &t, const NodeArgs 
 #pragma unroll
         for (int c = 0; c < 3; c++) bo[c] = FT_ABL == 6 ? 1.0 : bp[c];
     };
-    // 3-term Chebyshev: the previous iterate lives in the output buffer (c1 = 0 / zero guess: not read).  The two
-    // variants of the loop differ in this one load, so the choice is made once, outside the loop.
+    // 3-term Chebyshev: the previous iterate lives in the output buffer.  With c1 = 0 / a zero guess it is not needed --
+    // but the loop is ONE piece of code for both cases (round 4): as two instantiations the compiler scheduled the one
+    // without this load far worse (its four scalar loads of the block coefficients serialised through one SGPR range,
+    // 21 waits per step: 72 us against 49-51 us back to back at 128^3, tools/cheb_variants.py).  A sweep's first step
+    // therefore repeats the load of `b` here (same addresses as load_epi: served by the L1, no HBM bytes) and a
+    // uniform select drops the value.
+    const double *prev_base = read_prev ? a.out : a.b;
     auto load_prev = [&](int pl) {
-        const double *pp = a.out + 3 * plane * min(max(pl, 0), t.nzl - 1) + ncq;
+        const double *pp = prev_base + 3 * plane * min(max(pl, 0), t.nzl - 1) + ncq;
 #pragma unroll
         for (int c = 0; c < 3; c++) dd[c] = FT_ABL == 6 ? 1.0 : pp[c];
     };
@@ -161,7 +166,7 @@ __device__ __forceinline__ void fine_tile_run(const TileArgs &t, const NodeArgs 
         }
         Enext = load_E(kz0 - 1);
         if (HAS_B) load_epi(kz0 - 1);
-        if (read_prev) load_prev(kz0 - 1);
+        if (IS_CHEB) load_prev(kz0 - 1);
         store_plane(0, kz0 - 1, p0);
         store_plane(1, kz0, p1);
         if (MASKED) {
@@ -180,8 +185,8 @@ __device__ __forceinline__ void fine_tile_run(const TileArgs &t, const NodeArgs 
     double pdot = 0.0;
     double Elow = 0.0;
 
-    auto step = [&](int s, auto with_prev) {
-        constexpr bool PREV = decltype(with_prev)::value;
+    auto step = [&](int s) {
+        constexpr bool PREV = IS_CHEB;
         const int el = kz0 - 1 + s;  // element layer; bottom node plane el (ring slot s & 3), top el + 1
         if (FT_ABL == 9) {  // timing skeleton: same loads / stores, same pipeline distance, nothing else
             const double acc = (pre[0] + pre[1]) + (pre[2] + pre[3]) + Enext;
@@ -280,7 +285,7 @@ __device__ __forceinline__ void fine_tile_run(const TileArgs &t, const NodeArgs 
             } else if (EPI == EPI_RESID) {
                 o[c] = bo[c] - y;
             } else if (IS_CHEB) {
-                const double dprev = PREV ? xo - dd[c] : (a.c1 != 0.0 ? xo : 0.0);  // zero guess: u- = 0
+                const double dprev = read_prev ? xo - dd[c] : (a.c1 != 0.0 ? xo : 0.0);  // zero guess: u- = 0
                 o[c] = xo + (a.c1 * dprev + a.c2 * (di[c] * (bo[c] - y)));
                 if (EPI == EPI_CHEB_DOT) pdot = (s >= 1 && node_ok) ? fma(bo[c], o[c], pdot) : pdot;
             } else {
@@ -310,11 +315,7 @@ __device__ __forceinline__ void fine_tile_run(const TileArgs &t, const NodeArgs 
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, o01), rs, voff_out, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, o[2]), rs, voff_out + 16u, 0, 0);
     };
-    if (read_prev) {
-        for (int s = 0; s < nsteps; s++) step(s, std::true_type{});
-    } else {
-        for (int s = 0; s < nsteps; s++) step(s, std::false_type{});
-    }
+    for (int s = 0; s < nsteps; s++) step(s);
     if (EPI == EPI_APPLY_DOT || EPI == EPI_CHEB_DOT) {
         const double v[1] = {block_sum(pdot)};
         reduce_tail<1>(v, a.partials, gridDim.x * gridDim.y * gridDim.z, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z),
