@@ -86,39 +86,87 @@ inline void host_grandchild_matrices(const double *M, double *M2) {
 }
 
 // ---- level 0 -> 2 in one step for level-2 elements without flagged children: thread = matrix entry (576 per
-// workgroup), its 64 constants M2[.][entry] live in registers, the 64 moduli are workgroup-uniform (scalar loads):
-// 64 fma per entry, no LDS, no intermediate level-1 matrices.
-__global__ __launch_bounds__(576) void k_galerkin_l2_fast(Geom g0, Geom g2, const double *__restrict__ E,
-                                                          const double *__restrict__ M2, double *__restrict__ Kc,
-                                                          int nel) {
-    const int t = threadIdx.x;
+// workgroup), its 64 constants M2[.][entry] live in registers: 64 fma per entry, no intermediate level-1 matrices.
+// The 64 moduli of an element are workgroup-uniform.  Round 3 read them with scalar loads: 128 SGPRs per element do not
+// fit, the compiler split them into 8 groups with a wait behind each -- eight dependent scalar round trips per element,
+// 551 us at 128^3 for 1.2 G fma (the kernel heads the longest chain of the set-up: -> level 3 -> level 4 -> factorisation).
+// Round 4: the moduli of EIGHT elements are gathered by 512 threads (one value each), parked in registers while the
+// previous batch is computed, and passed through a double-buffered LDS table that every thread reads as broadcasts.
+// Same products in the same order as before: same bits.
+// A workgroup serves ONE THIRD of the 576 entries (192 threads = 3 waves; blockIdx.y = third): several small workgroups
+// share a CU and hide each other's barrier and LDS latency, and a thread may use up to 256 registers.
+constexpr int L2F_B = 6, L2F_T = 192;
+__global__ __launch_bounds__(L2F_T, 2) void k_galerkin_l2_fast(Geom g0, Geom g2, const double *__restrict__ E,
+                                                               const double *__restrict__ M2, double *__restrict__ Kc,
+                                                               int nel) {
+    __shared__ double sE[2][L2F_B][64];
+    const int t = threadIdx.x + L2F_T * blockIdx.y;  // matrix entry
     double m2[64];
 #pragma unroll
     for (int q = 0; q < 64; q++) m2[q] = M2[(size_t)q * 576 + t];
     const long sx = g0.ex, sxy = (long)g0.ex * g0.ey;  // row / layer pitch of the fine moduli
     // every own element is written here; the few with a flagged level-1 child are overwritten afterwards by the
     // generic construction (stream order), which spares a per-element flag load in this loop
-    for (int el = blockIdx.x; el < nel; el += gridDim.x) {
-        const int I2 = el % g2.ex, J2 = (el / g2.ex) % g2.ey, K2 = el / (g2.ex * g2.ey);
-        // the 4 x 4 x 4 block of fine moduli: 16 rows of 4 contiguous values, walked with pointer increments (the
-        // addresses are workgroup-uniform: scalar loads, little scalar arithmetic)
-        const double *__restrict__ pz = E + (long)(4 * I2) + sx * (4 * J2) + sxy * (4 * K2);
-        double sacc = 0.0;
+    const int niter = ((int)blockIdx.x < nel) ? (nel - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;  // elements of this workgroup
+    if (niter == 0) return;
+    // loader role: thread -> two values of the batch (6 elements x 64 moduli = 384 = 2 x 192); modulus q = x + 4 y + 16 z
+    int lb[2], lq[2];
+    long qoff[2];
 #pragma unroll
-        for (int z = 0; z < 4; z++) {
-            const double *__restrict__ py = pz;
+    for (int r = 0; r < 2; r++) {
+        const int f = (int)threadIdx.x + L2F_T * r;
+        lb[r] = f >> 6;
+        lq[r] = f & 63;
+        qoff[r] = (lq[r] & 3) + sx * ((lq[r] >> 2) & 3) + sxy * (lq[r] >> 4);
+    }
+    auto fetch = [&](int i0, double v[2]) {  // (always valid addresses: beyond the end the last element is read again)
 #pragma unroll
-            for (int y = 0; y < 4; y++) {
-#pragma unroll
-                for (int x = 0; x < 4; x++) {
-                    const int c2 = (x >> 1) + 2 * (y >> 1) + 4 * (z >> 1), g = (x & 1) + 2 * (y & 1) + 4 * (z & 1);
-                    sacc = fma(py[x], m2[c2 * 8 + g], sacc);
-                }
-                py += sx;
-            }
-            pz += sxy;
+        for (int r = 0; r < 2; r++) {
+            const int el = (int)blockIdx.x + min(i0 + lb[r], niter - 1) * (int)gridDim.x;
+            const int I2 = el % g2.ex, J2 = (el / g2.ex) % g2.ey, K2 = el / (g2.ex * g2.ey);
+            v[r] = E[(long)(4 * I2) + sx * (4 * J2) + sxy * (4 * K2) + qoff[r]];
         }
-        Kc[(long)el * 576 + t] = sacc;
+    };
+    double pre[2];
+    fetch(0, pre);
+#pragma unroll
+    for (int r = 0; r < 2; r++) sE[0][lb[r]][lq[r]] = pre[r];
+    fetch(L2F_B, pre);
+    __syncthreads();
+    int cur = 0;
+    for (int b0 = 0; b0 < niter; b0 += L2F_B, cur ^= 1) {
+        const int nb = min(L2F_B, niter - b0);
+        for (int j = 0; j < nb; j++) {
+            // the 64 broadcast reads of an element in four groups of 16, group z + 1 requested before group z is consumed
+            // (left to itself the compiler issues one read, waits, multiplies: 32 serial LDS round trips per element)
+            typedef double l2f_d2 __attribute__((ext_vector_type(2)));
+            const l2f_d2 *__restrict__ se = reinterpret_cast<const l2f_d2 *>(sE[cur][j]);
+            l2f_d2 ev[2][8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) ev[0][u] = se[u];
+            double sacc = 0.0;
+#pragma unroll
+            for (int z = 0; z < 4; z++) {
+                if (z < 3) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++) ev[(z + 1) & 1][u] = se[8 * (z + 1) + u];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int y = 0; y < 4; y++)
+#pragma unroll
+                    for (int x = 0; x < 4; x++) {
+                        const int c2 = (x >> 1) + 2 * (y >> 1) + 4 * (z >> 1), g = (x & 1) + 2 * (y & 1) + 4 * (z & 1);
+                        sacc = fma(ev[z & 1][(x + 4 * y) >> 1][x & 1], m2[c2 * 8 + g], sacc);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            Kc[(long)((int)blockIdx.x + (b0 + j) * (int)gridDim.x) * 576 + t] = sacc;
+        }
+#pragma unroll
+        for (int r = 0; r < 2; r++) sE[cur ^ 1][lb[r]][lq[r]] = pre[r];   // batch b0 + B (in flight since the previous trip)
+        fetch(b0 + 2 * L2F_B, pre);                                       // batch b0 + 2 B
+        __syncthreads();
     }
 }
 

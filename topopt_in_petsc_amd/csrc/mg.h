@@ -4,6 +4,9 @@
 // KSPCHEBYSHEV/PCJACOBI smoothers the reference reaches through PETSc
 // (LinearElasticity.cc:617-746, PDEFilter.cc:269-417).
 #pragma once
+#include <algorithm>
+#include <thread>
+
 #include "galerkin.h"
 #include "grid.h"
 #include "operators.h"
@@ -334,6 +337,12 @@ struct MGSolver {
             if (!lan_fork) TP_HIP(hipEventCreateWithFlags(&lan_fork, hipEventDisableTiming));
             TP_HIP(hipEventRecord(lan_fork, main));
             int rc = TP_OK;
+            static const bool serial_host = getenv("TP_LANCZOS_ONE_THREAD") != nullptr;
+            struct Replay {
+                hipStream_t s;
+                int l;
+            };
+            std::vector<Replay> replay;
             // coarsest level first: with the exact coarse solve its chain (factorisation) is the longest one
             // (with the factorisation the other levels' chains share ONE stream: the device has four hardware queues, and
             // streams that share a queue run one after the other -- the factorisation must not be the one that waits)
@@ -356,10 +365,53 @@ struct MGSolver {
                 if (!lan_done[l]) TP_HIP(hipEventCreateWithFlags(&lan_done[l], hipEventDisableTiming));
                 TP_HIP(hipStreamWaitEvent(ls, lan_fork, 0));
                 const int steps = (l == nlv - 1 && l > 0) ? NLANCZOS_COARSE : opt.nlanczos;
+                // A captured chain is replayed from a helper thread (round 4): hipGraphLaunch of a ~100-node chain keeps
+                // the calling thread for 0.6-1.3 ms (rocprofv3 --hip-trace), so three replays issued one after the other
+                // made the LAST level's chain start 1-2 ms late whatever stream it was on -- the set-up was bound by
+                // the host.  Chains that share a stream share a thread (order on the stream = order of the calls).
+                if (!(direct && l == nlv - 1) && !serial_host && lanczos_graph_replayable(l)) {
+                    lan[l].m = steps;
+                    replay.push_back({ls, l});
+                    continue;
+                }
                 grid->stream = ls;  // everything the run launches goes to the level's stream
                 rc = (direct && l == nlv - 1) ? coarse_direct_factor() : lanczos_graph(l, steps);
                 grid->stream = main;
                 if (rc == TP_OK && hipEventRecord(lan_done[l], ls) != hipSuccess) rc = TP_ERR_HIP;
+            }
+            if (!replay.empty()) {
+                int dev = 0;
+                (void)hipGetDevice(&dev);
+                std::vector<hipStream_t> streams;
+                for (const Replay &r : replay)
+                    if (std::find(streams.begin(), streams.end(), r.s) == streams.end()) streams.push_back(r.s);
+                std::vector<int> trc(streams.size(), TP_OK);
+                std::vector<std::thread> th;
+                for (size_t q = 0; q < streams.size(); q++)
+                    th.emplace_back([&, q, dev]() {
+                        if (hipSetDevice(dev) != hipSuccess) {
+                            trc[q] = TP_ERR_HIP;
+                            return;
+                        }
+                        for (const Replay &r : replay) {
+                            if (r.s != streams[q]) continue;
+                            if (hipGraphLaunch(lan_graph[r.l], r.s) != hipSuccess || hipEventRecord(lan_done[r.l], r.s) != hipSuccess) trc[q] = TP_ERR_HIP;
+                        }
+                    });
+                for (std::thread &t : th) t.join();
+                for (size_t q = 0; q < streams.size(); q++)
+                    if (trc[q] != TP_OK) {   // a failed replay: drop the graphs, enqueue the chains the plain way
+                        (void)hipGetLastError();
+                        for (const Replay &r : replay) {
+                            if (r.s != streams[q]) continue;
+                            lan_graph_state[r.l] = -1;
+                            grid->stream = r.s;
+                            const int rc2 = lanczos_enqueue(r.l, lan[r.l].m);
+                            grid->stream = main;
+                            if (rc2 == TP_OK && hipEventRecord(lan_done[r.l], r.s) != hipSuccess) rc = TP_ERR_HIP;
+                            if (rc2) rc = rc2;
+                        }
+                    }
             }
             for (int l = first_level; l < nlv; l++)
                 if (lan_done[l]) (void)hipStreamWaitEvent(main, lan_done[l], 0);
@@ -1403,6 +1455,13 @@ struct MGSolver {
         B.m = steps;
         TP_HIP(hipMemcpyAsync(B.hc, B.coef, sizeof(double) * 520, hipMemcpyDeviceToHost, s));
         return TP_OK;
+    }
+    // is the captured chain of level l valid for the vectors it would run on now?
+    bool lanczos_graph_replayable(int l) const {
+        const Level<DOF> &L = lv[l];
+        const void *key[5] = {L.r, L.b, L.d, L.corr, (const void *)(intptr_t)topology_epoch};
+        return lan_graph_state[l] == 1 && memcmp(key, lan_graph_key[l], sizeof(key)) == 0 && !lanczos_xcd_ok(l, opt.nlanczos) &&
+               getenv("TP_NO_GRAPH") == nullptr && !tp_debug_sync();
     }
     // replay (or capture, or plain enqueue) of the run of level l on grid->stream
     int lanczos_graph(int l, int steps) {

@@ -848,7 +848,7 @@ extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, dou
         const unsigned nb2 = (unsigned)(nEc2 < nb2_env ? nEc2 : nb2_env);
         TP_HIP(hipEventRecord(e->aux_fork, s));
         TP_HIP(hipStreamWaitEvent(e->aux_stream, e->aux_fork, 0));
-        TP_LAUNCH(k_galerkin_l2_fast, dim3(nb2), dim3(576), 0, e->aux_stream, mg.lv[0].g, C2.g, e->d_E, e->d_M2, C2.Kel, (int)nEc2);
+        TP_LAUNCH(k_galerkin_l2_fast, dim3(nb2, 3), dim3(L2F_T), 0, e->aux_stream, mg.lv[0].g, C2.g, e->d_E, e->d_M2, C2.Kel, (int)nEc2);
         count_launch(g, 8.0 * 64 * nEc2 + 8.0 * 576 * nEc2, 2.0 * 64 * 576 * nEc2);
         TP_HIP(hipEventRecord(e->aux_done, e->aux_stream));
         l2_aside = true;
@@ -889,7 +889,7 @@ extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, dou
                 if (l2_aside) {
                     TP_HIP(hipStreamWaitEvent(s, e->aux_done, 0));
                 } else {
-                    TP_LAUNCH(k_galerkin_l2_fast, dim3(nb2), dim3(576), 0, s, mg.lv[0].g, C.g, e->d_E, e->d_M2,
+                    TP_LAUNCH(k_galerkin_l2_fast, dim3(nb2, 3), dim3(L2F_T), 0, s, mg.lv[0].g, C.g, e->d_E, e->d_M2,
                                        C.Kel, (int)nEc);
                     count_launch(g, 8.0 * 64 * nEc + 8.0 * 576 * nEc, 2.0 * 64 * 576 * nEc);
                 }
