@@ -71,6 +71,9 @@ ORC_API double orc_hash_u01(uint64_t idx, uint64_t seed) { return hash_u01(idx, 
 
 /* deterministic (thread-count independent) blocked reductions */
 #define RED_CHUNK 4096
+/* element-wise loops over long vectors: OpenMP where the vector is long enough to pay for the fork (every thread
+ * computes whole entries: results do not depend on the thread count) */
+#define PFOR_MIN 100000
 static double vdot(long n, const double *a, const double *b) {
     long nch = (n + RED_CHUNK - 1) / RED_CHUNK;
     double *part = (double *)xmalloc(sizeof(double) * (size_t)nch);
@@ -402,7 +405,9 @@ static void csr_spmv(const csr_t *A, const double *x, double *y) {
         y[r] = s;
     }
 }
-/* y = A^T x (serial scatter; used for restriction and T^T) */
+/* y = A^T x (serial scatter; used for T^T and where no transpose is stored.  The multigrid restriction uses the stored
+ * transpose -- csr_transpose keeps the rows of a column in ascending order, so the gather adds the same terms in the
+ * same order as this scatter: same bits, any number of threads) */
 static void csr_spmv_t(const csr_t *A, const double *x, double *y) {
     for (long c = 0; c < A->ncol; c++) y[c] = 0.0;
     for (long r = 0; r < A->nrow; r++)
@@ -437,64 +442,83 @@ typedef struct {
 } cv_t;
 static int cv_cmp(const void *a, const void *b) { return ((const cv_t *)a)->c - ((const cv_t *)b)->c; }
 
-/* C = A * B, generic Gustavson SpGEMM with a dense accumulator; columns sorted. */
+/* C = A * B, Gustavson SpGEMM with a dense accumulator per thread; columns sorted.  Two passes over the rows (count,
+ * then fill), both OpenMP-parallel over rows: a row of C is computed by one thread with the same accumulation order as
+ * the serial form, so the result does not depend on the thread count. */
 static csr_t *csr_matmul(const csr_t *A, const csr_t *B) {
     csr_t *C = (csr_t *)xcalloc(1, sizeof(csr_t));
     C->nrow  = A->nrow;
     C->ncol  = B->ncol;
     C->rp    = (long *)xcalloc((size_t)C->nrow + 1, sizeof(long));
-    long cap = A->rp[A->nrow] * 2 + 16;
-    C->ci    = (int *)xmalloc(sizeof(int) * (size_t)cap);
-    C->v     = (double *)xmalloc(sizeof(double) * (size_t)cap);
-    double *acc = (double *)xcalloc((size_t)B->ncol, sizeof(double));
-    long *mark  = (long *)xmalloc(sizeof(long) * (size_t)B->ncol);
-    for (long c = 0; c < B->ncol; c++) mark[c] = -1;
-    int *cols   = (int *)xmalloc(sizeof(int) * (size_t)B->ncol);
-    cv_t *tmp   = NULL;
-    long tmpcap = 0;
-    long nnz    = 0;
-    for (long r = 0; r < A->nrow; r++) {
-        long cnt = 0;
-        for (long p = A->rp[r]; p < A->rp[r + 1]; p++) {
-            int k     = A->ci[p];
-            double av = A->v[p];
-            for (long q = B->rp[k]; q < B->rp[k + 1]; q++) {
-                int c = B->ci[q];
-                if (mark[c] != r) {
-                    mark[c]     = r;
-                    acc[c]      = 0.0;
-                    cols[cnt++] = c;
+    const int par = A->nrow > 20000;
+    /* pass 1: row lengths */
+#pragma omp parallel if (par)
+    {
+        long *mark = (long *)xmalloc(sizeof(long) * (size_t)B->ncol);
+        for (long c = 0; c < B->ncol; c++) mark[c] = -1;
+#pragma omp for schedule(dynamic, 512)
+        for (long r = 0; r < A->nrow; r++) {
+            long cnt = 0;
+            for (long p = A->rp[r]; p < A->rp[r + 1]; p++) {
+                int k = A->ci[p];
+                for (long q = B->rp[k]; q < B->rp[k + 1]; q++) {
+                    int c = B->ci[q];
+                    if (mark[c] != r) {
+                        mark[c] = r;
+                        cnt++;
+                    }
                 }
-                acc[c] += av * B->v[q];
+            }
+            C->rp[r + 1] = cnt;
+        }
+        free(mark);
+    }
+    for (long r = 0; r < C->nrow; r++) C->rp[r + 1] += C->rp[r];
+    long nnz = C->rp[C->nrow];
+    C->ci    = (int *)xmalloc(sizeof(int) * (size_t)(nnz + 1));
+    C->v     = (double *)xmalloc(sizeof(double) * (size_t)(nnz + 1));
+    /* pass 2: values */
+#pragma omp parallel if (par)
+    {
+        double *acc = (double *)xcalloc((size_t)B->ncol, sizeof(double));
+        long *mark  = (long *)xmalloc(sizeof(long) * (size_t)B->ncol);
+        for (long c = 0; c < B->ncol; c++) mark[c] = -1;
+        cv_t *tmp   = NULL;
+        long tmpcap = 0;
+#pragma omp for schedule(dynamic, 512)
+        for (long r = 0; r < A->nrow; r++) {
+            const long cnt_r = C->rp[r + 1] - C->rp[r];
+            if (cnt_r > tmpcap) {
+                tmpcap = cnt_r * 2;
+                tmp    = (cv_t *)realloc(tmp, sizeof(cv_t) * (size_t)tmpcap);
+                if (!tmp) abort();
+            }
+            long cnt = 0;
+            for (long p = A->rp[r]; p < A->rp[r + 1]; p++) {
+                int k     = A->ci[p];
+                double av = A->v[p];
+                for (long q = B->rp[k]; q < B->rp[k + 1]; q++) {
+                    int c = B->ci[q];
+                    if (mark[c] != r) {
+                        mark[c]      = r;
+                        acc[c]       = 0.0;
+                        tmp[cnt++].c = c;
+                    }
+                    acc[c] += av * B->v[q];
+                }
+            }
+            for (long t = 0; t < cnt; t++) tmp[t].v = acc[tmp[t].c];
+            qsort(tmp, (size_t)cnt, sizeof(cv_t), cv_cmp);
+            long o = C->rp[r];
+            for (long t = 0; t < cnt; t++) {
+                C->ci[o + t] = tmp[t].c;
+                C->v[o + t]  = tmp[t].v;
             }
         }
-        if (nnz + cnt > cap) {
-            cap   = (nnz + cnt) * 2;
-            C->ci = (int *)realloc(C->ci, sizeof(int) * (size_t)cap);
-            C->v  = (double *)realloc(C->v, sizeof(double) * (size_t)cap);
-            if (!C->ci || !C->v) abort();
-        }
-        if (cnt > tmpcap) {
-            tmpcap = cnt * 2;
-            tmp    = (cv_t *)realloc(tmp, sizeof(cv_t) * (size_t)tmpcap);
-            if (!tmp) abort();
-        }
-        for (long t = 0; t < cnt; t++) {
-            tmp[t].c = cols[t];
-            tmp[t].v = acc[cols[t]];
-        }
-        qsort(tmp, (size_t)cnt, sizeof(cv_t), cv_cmp);
-        for (long t = 0; t < cnt; t++) {
-            C->ci[nnz] = tmp[t].c;
-            C->v[nnz]  = tmp[t].v;
-            nnz++;
-        }
-        C->rp[r + 1] = nnz;
+        free(acc);
+        free(mark);
+        free(tmp);
     }
-    free(acc);
-    free(mark);
-    free(cols);
-    free(tmp);
     return C;
 }
 
@@ -521,6 +545,7 @@ static csr_t *assemble_csr(int nx, int ny, int nz, int dof, const double *KE, co
     A->ci    = (int *)xmalloc(sizeof(int) * (size_t)nnz);
     A->v     = (double *)xcalloc((size_t)nnz, sizeof(double));
     /* column pattern, ascending */
+#pragma omp parallel for schedule(static) if (nn > 20000)
     for (int k = 0; k < nz; k++)
         for (int j = 0; j < ny; j++)
             for (int i = 0; i < nx; i++) {
@@ -540,30 +565,40 @@ static csr_t *assemble_csr(int nx, int ny, int nz, int dof, const double *KE, co
                     }
                 }
             }
-    /* values */
-    long nd[8];
-    for (int k = 0; k < ez; k++)
-        for (int j = 0; j < ey; j++)
-            for (int i = 0; i < ex; i++) {
-                long e   = (long)i + (long)ex * (j + (long)ey * k);
-                double s = E ? E[e] : 1.0;
-                elem_nodes(nx, ny, i, j, k, nd);
-                for (int a = 0; a < 8; a++) {
-                    int ia = i + LX[a], ja = j + LY[a], ka = k + LZ[a];
-                    int cx = 1 + (ia > 0) + (ia < nx - 1), cy = 1 + (ja > 0) + (ja < ny - 1);
-                    for (int b = 0; b < 8; b++) {
-                        int di = LX[b] - LX[a], dj = LY[b] - LY[a], dk = LZ[b] - LZ[a];
-                        /* slot of neighbour (di,dj,dk) in node a's sorted neighbour list */
-                        int sx = di + (ia > 0), sy = dj + (ja > 0), sz = dk + (ka > 0);
-                        long slot = ((long)sz * cy + sy) * cx + sx;
-                        for (int c = 0; c < dof; c++) {
-                            long p = A->rp[dof * nd[a] + c] + slot * dof;
-                            for (int cc = 0; cc < dof; cc++) A->v[p + cc] += KE[(dof * a + c) * ed + dof * b + cc] * s;
+    /* values, gathered per NODE (OpenMP over nodes, no write conflicts): node n collects, from each of its up to 8
+     * elements in ASCENDING element order, the rows of the element matrix that belong to it.  The reference's element
+     * loop (LinearElasticity.cc:503-528) adds to an entry once per element in ascending order too, so every entry sees
+     * the same additions in the same order: bit-identical to the serial element loop, for any thread count. */
+#pragma omp parallel for collapse(2) schedule(static) if (nn > 20000)
+    for (int k = 0; k < nz; k++)
+        for (int j = 0; j < ny; j++)
+            for (int i = 0; i < nx; i++) {
+                const long n = (long)i + (long)nx * (j + (long)ny * k);
+                const int cx = 1 + (i > 0) + (i < nx - 1), cy = 1 + (j > 0) + (j < ny - 1);
+                for (int dk = -1; dk <= 0; dk++)
+                    for (int dj = -1; dj <= 0; dj++)
+                        for (int di = -1; di <= 0; di++) { /* element (i + di, j + dj, k + dk): ascending e */
+                            const int ei = i + di, ej = j + dj, ek = k + dk;
+                            if (ei < 0 || ei >= ex || ej < 0 || ej >= ey || ek < 0 || ek >= ez) continue;
+                            const long e   = (long)ei + (long)ex * (ej + (long)ey * ek);
+                            const double s = E ? E[e] : 1.0;
+                            int a = -1; /* local number of node n in that element */
+                            for (int q = 0; q < 8; q++)
+                                if (LX[q] == -di && LY[q] == -dj && LZ[q] == -dk) a = q;
+                            for (int b = 0; b < 8; b++) {
+                                const int ddi = LX[b] - LX[a], ddj = LY[b] - LY[a], ddk = LZ[b] - LZ[a];
+                                /* slot of neighbour (ddi,ddj,ddk) in node n's sorted neighbour list */
+                                const int sx = ddi + (i > 0), sy = ddj + (j > 0), sz = ddk + (k > 0);
+                                const long slot = ((long)sz * cy + sy) * cx + sx;
+                                for (int c = 0; c < dof; c++) {
+                                    const long p = A->rp[dof * n + c] + slot * dof;
+                                    for (int cc = 0; cc < dof; cc++) A->v[p + cc] += KE[(dof * a + c) * ed + dof * b + cc] * s;
+                                }
+                            }
                         }
-                    }
-                }
             }
     if (N) {
+#pragma omp parallel for schedule(static) if (A->nrow > PFOR_MIN)
         for (long r = 0; r < A->nrow; r++)
             for (long p = A->rp[r]; p < A->rp[r + 1]; p++) {
                 A->v[p] = N[r] * A->v[p] * N[A->ci[p]];
@@ -626,6 +661,7 @@ typedef struct {
     int nx[MAXLV], ny[MAXLV], nz[MAXLV];
     csr_t *A[MAXLV];
     csr_t *P[MAXLV]; /* P[l]: level l+1 (coarse) -> level l (fine) */
+    csr_t *PT[MAXLV]; /* its transpose, stored: restriction as a gather, Galerkin products */
     double *dinv[MAXLV];
     double lam[MAXLV];
     double lam_min[MAXLV]; /* coarsest level only: smallest Ritz value (coarse-solve window) */
@@ -705,17 +741,21 @@ static double lanczos_lmax(const csr_t *A, const double *dinv, int nsteps, doubl
     double *V = (double *)xmalloc(sizeof(double) * (size_t)n * (size_t)(nsteps + 1));
     double al[128] = {0}, be[128] = {0}, h[129];
     double *v0 = V;
+#pragma omp parallel for schedule(static) if (n > PFOR_MIN)
     for (long i = 0; i < n; i++) {
         dis[i] = sqrt(dinv[i]);
         v0[i]  = hash_u01((uint64_t)i, 0x5eedULL) - 0.5;
     }
     double nv = vnorm(n, v0);
+#pragma omp parallel for schedule(static) if (n > PFOR_MIN)
     for (long i = 0; i < n; i++) v0[i] /= nv;
     int m = 0;
     for (int j = 0; j < nsteps; j++) {
         const double *vj = V + (size_t)j * n;
+        #pragma omp parallel for schedule(static) if (n > PFOR_MIN)
         for (long i = 0; i < n; i++) t[i] = dis[i] * vj[i];
         csr_spmv(A, t, w);
+        #pragma omp parallel for schedule(static) if (n > PFOR_MIN)
         for (long i = 0; i < n; i++) w[i] = dis[i] * w[i];
         double alpha = 0.0;
         for (int pass = 0; pass < 2; pass++) {
@@ -723,6 +763,7 @@ static double lanczos_lmax(const csr_t *A, const double *dinv, int nsteps, doubl
             for (int q = 0; q <= j; q++) {
                 const double *vq = V + (size_t)q * n;
                 const double hq  = h[q];
+#pragma omp parallel for schedule(static) if (n > PFOR_MIN)
                 for (long i = 0; i < n; i++) w[i] -= hq * vq[i];
             }
             alpha += h[j];
@@ -733,6 +774,7 @@ static double lanczos_lmax(const csr_t *A, const double *dinv, int nsteps, doubl
         m++;
         if (!(beta > 1e-14 * fabs(alpha))) break;
         double *vn = V + (size_t)(j + 1) * n;
+#pragma omp parallel for schedule(static) if (n > PFOR_MIN)
         for (long i = 0; i < n; i++) vn[i] = w[i] / beta;
     }
     double l = tridiag_lmax(m, al, be);
@@ -812,7 +854,10 @@ ORC_API orc_mg_t *orc_mg_create(int nx, int ny, int nz, int dof, int nlv, int ns
         s->r[l] = (double *)xcalloc((size_t)n, sizeof(double));
         s->d[l] = (double *)xcalloc((size_t)n, sizeof(double));
     }
-    for (int l = 0; l + 1 < nlv; l++) s->P[l] = interp_csr(s->nx[l + 1], s->ny[l + 1], s->nz[l + 1], dof);
+    for (int l = 0; l + 1 < nlv; l++) {
+        s->P[l]  = interp_csr(s->nx[l + 1], s->ny[l + 1], s->nz[l + 1], dof);
+        s->PT[l] = csr_transpose(s->P[l]);
+    }
     return s;
 }
 
@@ -889,6 +934,7 @@ ORC_API void orc_mg_destroy(orc_mg_t *s) {
     for (int l = 0; l < s->nlv; l++) {
         csr_free(s->A[l]);
         csr_free(s->P[l]);
+        csr_free(s->PT[l]);
         free(s->dinv[l]);
         free(s->b[l]);
         free(s->x[l]);
@@ -911,14 +957,13 @@ ORC_API void orc_mg_assemble(orc_mg_t *s, const double *KE, const double *E, con
     s->A[0] = assemble_csr(s->nx[0], s->ny[0], s->nz[0], s->dof, KE, E, N);
     for (int l = 0; l + 1 < s->nlv; l++) {
         csr_t *AP = csr_matmul(s->A[l], s->P[l]);
-        csr_t *Pt = csr_transpose(s->P[l]);
-        s->A[l + 1] = csr_matmul(Pt, AP);
+        s->A[l + 1] = csr_matmul(s->PT[l], AP);
         csr_free(AP);
-        csr_free(Pt);
     }
     for (int l = 0; l < s->nlv; l++) {
         csr_t *A   = s->A[l];
         s->dinv[l] = (double *)xmalloc(sizeof(double) * (size_t)A->nrow);
+#pragma omp parallel for schedule(static) if (A->nrow > PFOR_MIN)
         for (long r = 0; r < A->nrow; r++) {
             double dg = 0.0;
             for (long p = A->rp[r]; p < A->rp[r + 1]; p++)
@@ -949,12 +994,14 @@ static void cheb_smooth(const csr_t *A, const double *dinv, const double *b, dou
     long n       = A->nrow;
     double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta, rho = 1.0 / sigma;
     if (zero_guess) {
+#pragma omp parallel for schedule(static) if (n > PFOR_MIN)
         for (long i = 0; i < n; i++) {
             d[i] = dinv[i] * b[i] / theta;
             x[i] = d[i];
         }
     } else {
         csr_spmv(A, x, r);
+#pragma omp parallel for schedule(static) if (n > PFOR_MIN)
         for (long i = 0; i < n; i++) {
             d[i] = dinv[i] * (b[i] - r[i]) / theta;
             x[i] += d[i];
@@ -964,6 +1011,7 @@ static void cheb_smooth(const csr_t *A, const double *dinv, const double *b, dou
         double rn = 1.0 / (2.0 * sigma - rho);
         double c1 = rn * rho, c2 = 2.0 * rn / delta;
         csr_spmv(A, x, r);
+#pragma omp parallel for schedule(static) if (n > PFOR_MIN)
         for (long i = 0; i < n; i++) {
             d[i] = c1 * d[i] + c2 * (dinv[i] * (b[i] - r[i]));
             x[i] += d[i];
@@ -991,11 +1039,13 @@ static void mcycle(orc_mg_t *s, int l, int zero_guess) {
     }
     cheb_smooth(A, s->dinv[l], s->b[l], s->x[l], s->r[l], s->d[l], s->nsmooth, lmin, lmax, zero_guess);
     csr_spmv(A, s->x[l], s->r[l]);
+#pragma omp parallel for schedule(static) if (n > PFOR_MIN)
     for (long i = 0; i < n; i++) s->r[l][i] = s->b[l][i] - s->r[l][i];
-    csr_spmv_t(s->P[l], s->r[l], s->b[l + 1]); /* restriction = P^T */
+    csr_spmv(s->PT[l], s->r[l], s->b[l + 1]); /* restriction = P^T (stored transpose: same sums in the same order as the scatter) */
     const int cyc = (l + 1 == s->nlv - 1) ? 1 : s->cycles[l];
     for (int c = 0; c < cyc; c++) mcycle(s, l + 1, c == 0);
     csr_spmv(s->P[l], s->x[l + 1], s->r[l]);
+#pragma omp parallel for schedule(static) if (n > PFOR_MIN)
     for (long i = 0; i < n; i++) s->x[l][i] += s->r[l][i];
     cheb_smooth(A, s->dinv[l], s->b[l], s->x[l], s->r[l], s->d[l], s->nsmooth, lmin, lmax, 0);
 }
@@ -1020,6 +1070,7 @@ ORC_API int orc_mg_solve(orc_mg_t *s, const double *b, double *x, double rtol, d
     double *r = (double *)xmalloc(sizeof(double) * (size_t)n), *z = (double *)xmalloc(sizeof(double) * (size_t)n),
            *p = (double *)xmalloc(sizeof(double) * (size_t)n), *w = (double *)xmalloc(sizeof(double) * (size_t)n);
     csr_spmv(A, x, r);
+#pragma omp parallel for schedule(static) if (n > PFOR_MIN)
     for (long i = 0; i < n; i++) r[i] = b[i] - r[i];
     double bnorm = vnorm(n, b);
     double ttol  = fmax(rtol * bnorm, atol);
@@ -1034,6 +1085,7 @@ ORC_API int orc_mg_solve(orc_mg_t *s, const double *b, double *x, double rtol, d
         for (its = 1; its <= maxit; its++) {
             csr_spmv(A, p, w);
             double alpha = rz / vdot(n, p, w);
+#pragma omp parallel for schedule(static) if (n > PFOR_MIN)
             for (long i = 0; i < n; i++) {
                 x[i] += alpha * p[i];
                 r[i] -= alpha * w[i];
@@ -1050,6 +1102,7 @@ ORC_API int orc_mg_solve(orc_mg_t *s, const double *b, double *x, double rtol, d
             else memcpy(z, r, sizeof(double) * (size_t)n);
             double rzn  = vdot(n, r, z);
             double beta = rzn / rz;
+#pragma omp parallel for schedule(static) if (n > PFOR_MIN)
             for (long i = 0; i < n; i++) p[i] = z[i] + beta * p[i];
             rz = rzn;
         }
@@ -1094,11 +1147,15 @@ ORC_API void orc_compliance_sens(int nx, int ny, int nz, const double *KE, const
                                  double *dfdx, double *dgdx) {
     int ex = nx - 1, ey = ny - 1, ez = nz - 1;
     long nel = (long)ex * ey * ez;
-    long nd[8];
     double f = 0.0;
+    /* element contributions in parallel, added up afterwards in the reference's element order (LinearElasticity.cc:421):
+     * the same sum, bit for bit, as the serial loop */
+    double *fe = (double *)xmalloc(sizeof(double) * (size_t)nel);
+#pragma omp parallel for collapse(2) schedule(static) if (nel > 20000)
     for (int k = 0; k < ez; k++)
         for (int j = 0; j < ey; j++)
             for (int i = 0; i < ex; i++) {
+                long nd[8];
                 long e = (long)i + (long)ex * (j + (long)ey * k);
                 elem_nodes(nx, ny, i, j, k, nd);
                 double ue[24];
@@ -1107,9 +1164,11 @@ ORC_API void orc_compliance_sens(int nx, int ny, int nz, const double *KE, const
                 double uKu = 0.0;
                 for (int kk = 0; kk < 24; kk++)
                     for (int hh = 0; hh < 24; hh++) uKu += ue[kk] * KE[kk * 24 + hh] * ue[hh];
-                f += (Emin + pow(xPhys[e], penal) * (Emax - Emin)) * uKu;
+                fe[e] = (Emin + pow(xPhys[e], penal) * (Emax - Emin)) * uKu;
                 if (dfdx) dfdx[e] = -1.0 * penal * pow(xPhys[e], penal - 1) * (Emax - Emin) * uKu;
             }
+    for (long e = 0; e < nel; e++) f += fe[e];
+    free(fe);
     *fx = f;
     if (gx) *gx = vsum(nel, xPhys) / ((double)nel) - volfrac;
     if (dgdx)
