@@ -632,3 +632,47 @@ def test_in_kernel_reduction_tail_stress(tp):
     grid = tp.Grid(17, 9, 9, 0.125)
     assert grid.reduction_selftest(4 * 1024 * 1024, 600) == 0
     assert grid.reduction_selftest(1000, 50) == 0          # fewer workgroups than counter shards
+
+
+@pytest.mark.parametrize("where", [1, 2])
+def test_one_xcd_kernels_give_up_path(tmp_path, where):
+    """A one-XCD persistent kernel (Chebyshev run, Lanczos run, factorisation of the coarsest level) that gives up -- its
+    workgroups not co-resident on a shared device -- must cost a retry, not the solve: the library redoes the set-up with
+    the launch-per-step forms, keeps the one-XCD forms off for the rest of the process and solves again.  The hook
+    TP_TEST_FORCE_GIVEUP takes the recovery branch without a real give-up (1: found by the solve, 2: found by the
+    set-up); the result must be the one of a process that never used those kernels (TP_NO_COARSE_XCD, TP_NO_COARSE_DIRECT)
+    up to the cold start of the retry."""
+    import subprocess, sys
+    worker = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import topopt_in_petsc_amd as tp\n"
+        "tp.load_library()\n"
+        "grid = tp.Grid(65, 65, 65, 1.0 / 64)\n"
+        "le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=4, nsmooth=2, ncoarse=20, rtol=1e-5, coarse_direct=1))\n"
+        "le.SetUpLoadAndBC()\n"
+        "x = grid.synth_density(12345)\n"
+        "res = []\n"
+        "for it in range(2):\n"
+        "    le.U.zero_()\n"
+        "    le.SolveState(x, 1e-9, 1.0, 3.0, hist_cap=64)\n"
+        "    res.append((le.last_its, le.last_rnorm / le.last_bnorm, le.coarse_direct_active()))\n"
+        "np.savez(sys.argv[1], U=le.U.cpu().numpy(), its=[r[0] for r in res], rel=[r[1] for r in res], cd=[r[2] for r in res])\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env in (("forced", {"TP_TEST_FORCE_GIVEUP": str(where)}), ("never", {"TP_NO_COARSE_XCD": "1", "TP_NO_COARSE_DIRECT": "1", "TP_NO_LANCZOS_XCD": "1"})):
+        e = dict(os.environ)
+        for k in ("TP_TEST_FORCE_GIVEUP", "TP_NO_COARSE_XCD", "TP_NO_COARSE_DIRECT", "TP_NO_LANCZOS_XCD"):
+            e.pop(k, None)
+        e.update(env)
+        out = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", worker, out], env=e, capture_output=True, text=True, timeout=200)
+        assert r.returncode == 0, r.stderr[-2000:]
+        if tag == "forced":
+            assert "gave up" in r.stderr and r.stderr.count("gave up") == 1      # one retry, then the forms stay off
+        res[tag] = np.load(out)
+    f, n = res["forced"], res["never"]
+    assert list(f["cd"]) == [0, 0] and list(n["cd"]) == [0, 0]                   # no factorisation after the give-up
+    # every solve of both processes is a cold start on the same hierarchy built by the same kernels
+    assert list(f["its"]) == list(n["its"]) and max(f["its"]) < 200 and max(f["rel"]) <= 1e-5
+    assert np.abs(f["U"] - n["U"]).max() <= 1e-12 * np.abs(n["U"]).max()

@@ -26,6 +26,14 @@
 // after a tuning change, bad grid) must not pass silently with stale output and a plausible timing.
 // TP_DEBUG_SYNC=1 additionally synchronises the device after every launch, so that an asynchronous fault is
 // reported at the launch that caused it (implies no graph capture).
+// The one-XCD persistent kernels (coarse_run.h: Chebyshev run, Lanczos run; coarse_direct.h: factorisation) rely on their
+// workgroups being co-resident.  When one of them gives up (its peers did not show up within ~1 s: a device shared with
+// another process' persistent kernels) the library redoes the work with the launch-per-step forms and keeps the
+// one-XCD forms OFF for the rest of the process (topopt_amd.hip: redo_without_xcd).
+inline bool &tp_xcd_disabled() {
+    static bool off = false;
+    return off;
+}
 inline bool tp_debug_sync() {
     static const bool v = getenv("TP_DEBUG_SYNC") != nullptr && atoi(getenv("TP_DEBUG_SYNC")) != 0;
     return v;

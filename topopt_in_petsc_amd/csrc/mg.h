@@ -950,7 +950,7 @@ struct MGSolver {
         return TP_OK;
     }
     bool coarse_direct_ok() const {
-        if (!opt.coarse_direct || getenv("TP_NO_COARSE_DIRECT") || nlv < 2 || DOF != 3) return false;
+        if (!opt.coarse_direct || getenv("TP_NO_COARSE_DIRECT") || tp_xcd_disabled() || nlv < 2 || DOF != 3) return false;
         const Level<DOF> &L = lv[cd_level()];
         if (L.kind != LV_DIA || (grid->has_comm && !L.no_comm) || L.own_n() != L.ndof() || L.ndof() > CD_MAXROWS) return false;
         const long hb = (long)DOF * (L.g.plane() + L.g.nx + 1) + DOF - 1;
@@ -1042,6 +1042,29 @@ struct MGSolver {
     // ---- the coarsest level's run in one launch (coarse_run.h)
     unsigned long long *run_cnt = nullptr;  // [dev] arrival counter (monotone over the runs) + give-up flag
     XcdRunCtrl *run_ctl = nullptr;          // [dev] control block of the one-XCD run (zero between runs)
+    bool gaveup_seen = false;               // the last diverged solve found a give-up flag raised by a one-XCD kernel
+    // did a one-XCD kernel (Chebyshev run, Lanczos run, factorisation) give up?  Blocking read of the sticky flags.
+    bool xcd_gaveup() {
+        unsigned long long f[3] = {0ull, 0ull, 0ull};
+        XcdRunCtrl *blocks[3] = {run_ctl, lan_ctl, cd.ctl};
+        for (int q = 0; q < 3; q++)
+            if (blocks[q]) (void)hipMemcpyAsync(&f[q], &blocks[q]->gaveup[0], sizeof(unsigned long long), hipMemcpyDeviceToHost, grid->stream);
+        (void)hipStreamSynchronize(grid->stream);
+        return (f[0] | f[1] | f[2]) != 0ull;
+    }
+    void xcd_reset_controls() {
+        for (XcdRunCtrl *b : {run_ctl, lan_ctl, cd.ctl})
+            if (b) (void)hipMemsetAsync(b, 0, sizeof(XcdRunCtrl), grid->stream);
+        cd_early = false;
+        cd.factored = false;
+    }
+    // after an assembly that failed half way: no chain of a side stream may still be running when the next one starts
+    void join_side_streams() {
+        for (int i = 0; i <= TP_MAX_LEVELS; i++)
+            if (lan_stream[i]) (void)hipStreamSynchronize(lan_stream[i]);
+        if (side_stream) (void)hipStreamSynchronize(side_stream);
+        cd_early = false;
+    }
     unsigned long long run_base = 0;        // arrivals of all runs so far
     long coarse_runs = 0;
     // rows per thread: the fewest that bring the run down to `want` workgroups (barrier cost grows with their number)
@@ -1076,7 +1099,7 @@ struct MGSolver {
         const char *sw = getenv("TP_COARSE_RUN");  // read per call: the tests switch it within a process
         if (sw && atoi(sw) == 1) return wgs <= RUN_MAX_WGS && run_stage_doubles(L.g, DOF, R) <= RUN_XS ? 2 : 0;
         // 3: the run on one XCD (coarse_run.h): one rank, at most 32 workgroups (one per CU of an XCD), R <= 2
-        if (getenv("TP_NO_COARSE_RUN") || getenv("TP_NO_COARSE_XCD")) return 0;
+        if (getenv("TP_NO_COARSE_RUN") || getenv("TP_NO_COARSE_XCD") || tp_xcd_disabled()) return 0;
         return xcd_eligible(l, RUN_XS, 8) ? 3 : 0;
     }
     // the level fits a run on one XCD: all its rows on this rank (one rank, or the replicated copy of the coarsest
@@ -1429,7 +1452,7 @@ struct MGSolver {
     // level qualifies for the one-XCD form; TP_NO_LANCZOS_XCD=1 keeps the chain of launches.
     XcdRunCtrl *lan_ctl = nullptr;
     bool lanczos_xcd_ok(int l, int steps) const {
-        if (getenv("TP_NO_LANCZOS_XCD") || steps > LAN_MAXS || steps < 2) return false;
+        if (getenv("TP_NO_LANCZOS_XCD") || tp_xcd_disabled() || steps > LAN_MAXS || steps < 2) return false;
         if (!(replicate ? l == nlv : (l == nlv - 1 && l > 0))) return false;
         return xcd_eligible(l, LAN_XS, 4);  // (8 rows per thread: the basis no longer fits the LDS)
     }
@@ -1626,6 +1649,8 @@ struct MGSolver {
         }
         head_for = nullptr;
         TP_TRY(drain_halos());
+        gaveup_seen = false;
+        if (rc == TP_ERR_DIVERGED) gaveup_seen = xcd_gaveup();  // (before the control blocks are cleared below)
         if (rc == TP_ERR_DIVERGED && run_cnt) {
             // a multi-workgroup coarse run that gave up leaves its give-up flag set and fewer arrivals than run_base
             // assumes: every later run would time out as well.  Start the counters over.

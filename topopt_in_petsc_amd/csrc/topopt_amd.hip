@@ -815,6 +815,18 @@ extern "C" int tp_elasticity_cantilever(tp_elasticity *e, double *N, double *RHS
     return tp_elasticity_set_bc(e, N);
 }
 
+static int elasticity_setup_from_E(tp_elasticity *e);
+// A one-XCD persistent kernel gave up (common.h: tp_xcd_disabled): switch those forms off for the rest of the process,
+// hand their control blocks back zeroed and build the hierarchy again from the moduli with the launch-per-step forms.
+static int redo_without_xcd(tp_elasticity *e, const char *where) {
+    fprintf(stderr, "topopt_amd: a one-XCD persistent kernel gave up during %s (workgroups not co-resident: shared device?); "
+                    "redoing it with separate launches, one-XCD forms off for the rest of this process\n", where);
+    tp_xcd_disabled() = true;
+    e->mg.join_side_streams();
+    e->mg.xcd_reset_controls();
+    TP_HIP(hipStreamSynchronize(e->grid->stream));
+    return elasticity_setup_from_E(e);
+}
 extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, double Emin, double Emax, double penal) {
     if (!e->have_bc) return TP_ERR_STATE;
     tp_grid *g = e->grid;
@@ -827,6 +839,32 @@ extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, dou
     // two ghost layers above <- upper neighbour's first own layers (level 1 is applied
     // from the fine densities and reaches one coarse = two fine layers up)
     TP_TRY(exchange_segments(g, e->d_E, nullptr, nullptr, e->d_E + nel, 2 * lay, 1, 2 * lay));
+    // a previous assembly that failed half way must not leave its state behind (a stale "factorisation under way" event,
+    // a sticky give-up flag)
+    mg.cd_early = false;
+    e->assembled = false;
+    int rc = elasticity_setup_from_E(e);
+    if (rc == TP_OK && mg.opt.ksp_mode == 0 && !tp_xcd_disabled()) {
+        // a Lanczos run on one XCD that gave up poisons its Ritz values with NaN (a factorisation that gave up shows in
+        // the solve: tp_elasticity_solve)
+        bool bad = false;
+        for (int l = 0; l <= mg.nlv; l++) bad = bad || mg.lv[l].lam != mg.lv[l].lam || mg.lv[l].lam_min != mg.lv[l].lam_min;
+        static const bool force = getenv("TP_TEST_FORCE_GIVEUP") != nullptr && atoi(getenv("TP_TEST_FORCE_GIVEUP")) == 2;
+        if ((bad && mg.xcd_gaveup()) || (force && !tp_xcd_disabled())) rc = redo_without_xcd(e, "the set-up");
+    }
+    if (rc != TP_OK) {  // join what the failed set-up left running on the side streams
+        if (e->aux_stream) (void)hipStreamSynchronize(e->aux_stream);
+        mg.join_side_streams();
+        (void)hipStreamSynchronize(s);
+    }
+    return rc;
+}
+static int elasticity_setup_from_E(tp_elasticity *e) {
+    tp_grid *g = e->grid;
+    MGSolver<3> &mg = e->mg;
+    hipStream_t s = g->stream;
+    Geom q0 = mg.lv[0].g;
+    const long nel = q0.own_elems();
     const bool macro1 = mg.nlv > 1 && mg.lv[1].kind == LV_MACRO;  // level 1 applied from E: no element matrices there
     // Order of the set-up (round 3): the chain fine moduli -> element matrices of level 2 -> ... -> stencil of the coarsest
     // level is what the factorisation of that level waits for (coarse_direct.h: the longest chain of the set-up), so it
@@ -981,7 +1019,16 @@ extern "C" int tp_elasticity_solve(tp_elasticity *e, const double *RHS, double *
     // RHS <- RHS .* N (LinearElasticity.cc:542), on a scratch copy
     TP_LAUNCH(k_mul, dim3(grid_for(n)), dim3(BLK), 0, g->stream, e->d_bN, RHS, e->d_N, n);
     count_launch(g, 24.0 * n, 1.0 * n);
-    return e->mg.solve(e->d_bN, U, its, rnorm, bnorm, hist, hist_cap);
+    int rc = e->mg.solve(e->d_bN, U, its, rnorm, bnorm, hist, hist_cap);
+    // A solve that "diverged" because a one-XCD kernel gave up (its result is poisoned with NaN on purpose): build the
+    // hierarchy again without those kernels and solve once more, from a zero guess (U holds NaN by now).
+    static const bool force = getenv("TP_TEST_FORCE_GIVEUP") != nullptr && atoi(getenv("TP_TEST_FORCE_GIVEUP")) == 1;
+    if (!tp_xcd_disabled() && ((rc == TP_ERR_DIVERGED && e->mg.gaveup_seen) || (force && rc == TP_OK))) {
+        TP_TRY(redo_without_xcd(e, "the solve"));
+        TP_HIP(hipMemsetAsync(U, 0, sizeof(double) * (size_t)n, g->stream));
+        rc = e->mg.solve(e->d_bN, U, its, rnorm, bnorm, hist, hist_cap);
+    }
+    return rc;
 }
 
 // fx = sum_e E_e u_e^T KE u_e, dfdx_e = -p x^(p-1) (Emax-Emin) u_e^T KE u_e, partial sum x
