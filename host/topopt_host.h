@@ -67,6 +67,10 @@ class LinearElasticity {
     // -mg_coarse_ksp_max_it; the defaults are the reference's 4 and 30, DESIGN 4.5 has the measured optimum)
     LinearElasticity(tp_grid *grid, PetscInt nlvls_, PetscScalar nu_, PetscInt smooth_its = 0, PetscInt coarse_its = 0) : g(grid) {
         tp_solver_opts o;
+        if (tp_abi_version() != TP_ABI_VERSION || tp_solver_opts_size() != sizeof(tp_solver_opts)) {  // header / library mismatch
+            err = TP_ERR_STATE;
+            return;
+        }
         tp_solver_default_opts(&o);
         o.nlvls = nlvls_;
         o.nu = nu_;

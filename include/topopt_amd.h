@@ -188,6 +188,12 @@ typedef struct tp_solver_opts {
     int coarse_direct;
 } tp_solver_opts;
 void tp_solver_default_opts(tp_solver_opts *o);
+/* The option structs grow at their END from round to round.  A host built against an older header would have the library
+ * read past its struct: hosts compare these two numbers with their own header at load time (the Python host in lib.py,
+ * the C++ hosts in host/topopt_host.h) and refuse to run on a mismatch. */
+#define TP_ABI_VERSION 4
+int tp_abi_version(void);                 /* the library's TP_ABI_VERSION */
+unsigned long tp_solver_opts_size(void);  /* the library's sizeof(tp_solver_opts) */
 
 typedef struct tp_elasticity tp_elasticity;
 /* LinearElasticity::LinearElasticity + SetUpLoadAndBC (LinearElasticity.cc:12-180):

@@ -95,6 +95,16 @@ __global__ __launch_bounds__(BLK) void k_selftest_fill(double *a, double *b, lon
 extern "C" int tp_grid_reduction_selftest(tp_grid *g, long n, int reps, int *mismatches) {
     if (!g || n < 1 || reps < 1 || reps > 4096 || !mismatches) return TP_ERR_ARG;
     double *a = nullptr, *b = nullptr, *res = nullptr;
+    struct Guard {  // the early returns of TP_HIP / TP_LAUNCH free the buffers too
+        double *&a, *&b, *&r;
+        hipStream_t s;
+        ~Guard() {
+            (void)hipStreamSynchronize(s);
+            (void)hipFree(a);
+            (void)hipFree(b);
+            (void)hipFree(r);
+        }
+    } guard{a, b, res, g->stream};
     TP_HIP(hipMalloc((void **)&a, sizeof(double) * (size_t)n));
     TP_HIP(hipMalloc((void **)&b, sizeof(double) * (size_t)n));
     TP_HIP(hipMalloc((void **)&res, sizeof(double) * 2 * (size_t)reps));
@@ -114,9 +124,6 @@ extern "C" int tp_grid_reduction_selftest(tp_grid *g, long n, int reps, int *mis
     int bad = 0;
     for (int r = 0; r < reps; r++) bad += std::memcmp(&h[2 * r], &h[2 * r + 1], sizeof(double)) != 0 || !(h[2 * r] == h[2 * r]);
     *mismatches = bad;
-    (void)hipFree(a);
-    (void)hipFree(b);
-    (void)hipFree(res);
     return TP_OK;
 }
 extern "C" int tp_grid_comm_selfcheck(tp_grid *g, int *ok) {
@@ -428,6 +435,8 @@ extern "C" int tp_synth_density(tp_grid *g, double *x, uint64_t seed) {
 // ===========================================================================
 // linear elasticity
 // ===========================================================================
+extern "C" int tp_abi_version(void) { return TP_ABI_VERSION; }
+extern "C" unsigned long tp_solver_opts_size(void) { return (unsigned long)sizeof(tp_solver_opts); }
 extern "C" void tp_solver_default_opts(tp_solver_opts *o) {
     o->nlvls = 4;       // LinearElasticity.cc:23
     o->nu = 0.3;        // :22

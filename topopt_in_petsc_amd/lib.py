@@ -83,6 +83,8 @@ SYMBOLS = {
     "tp_memcpy_d2h": (_i, [_vp, _vp, C.c_size_t]),
     "tp_sync": (_i, [_vp]),
     "tp_solver_default_opts": (None, [C.POINTER(SolverOpts)]),
+    "tp_abi_version": (_i, []),
+    "tp_solver_opts_size": (C.c_ulong, []),
     "tp_elasticity_create": (_i, [C.POINTER(_vp), _vp, C.POINTER(SolverOpts)]),
     "tp_elasticity_create_ke": (_i, [C.POINTER(_vp), _vp, C.POINTER(SolverOpts), _vp]),
     "tp_elasticity_destroy": (_i, [_vp]),
@@ -141,6 +143,9 @@ SYMBOLS = {
 }
 
 
+ABI_VERSION = 4   # TP_ABI_VERSION of include/topopt_amd.h
+
+
 def load_library():
     global _LIB
     if _LIB is None:
@@ -153,5 +158,9 @@ def load_library():
             fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
+        # include/topopt_amd.h: the option structs grow at their end; a stale binding must not reach the library
+        if lib.tp_abi_version() != ABI_VERSION or lib.tp_solver_opts_size() != C.sizeof(SolverOpts):
+            raise LibraryMissing("libtopopt_amd.so (ABI %d, tp_solver_opts of %d bytes) does not match this binding (ABI %d, %d bytes): rebuild"
+                                 % (lib.tp_abi_version(), lib.tp_solver_opts_size(), ABI_VERSION, C.sizeof(SolverOpts)))
         _LIB = lib
     return _LIB
