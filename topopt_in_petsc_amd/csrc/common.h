@@ -136,7 +136,7 @@ constexpr int TICKET_STRIDE = 1024;              // unsigned words between two c
 constexpr int TICKET_WORDS = 9 * TICKET_STRIDE;  // allocation: 8 shards + top
 template <int NV>
 __device__ inline void reduce_tail(const double (&mine)[NV], double *__restrict__ partials, int nb, int b,
-                                   unsigned *ticket, double *__restrict__ out) {
+                                   unsigned *ticket, double *__restrict__ out, double *__restrict__ out_host = nullptr) {
     __shared__ int s_last;
     if (!ticket) {  // TP_NO_REDUCE_TAIL=1: partial sums only, the host launches k_reduce_final behind this kernel
         if (threadIdx.x == 0) {
@@ -180,7 +180,10 @@ __device__ inline void reduce_tail(const double (&mine)[NV], double *__restrict_
                 if (i0 + k * BLK < nb) s += w[k];
         }
         s = block_sum(s);
-        if (threadIdx.x == 0) out[v] = s;
+        if (threadIdx.x == 0) {
+            out[v] = s;
+            if (out_host) out_host[v] = s;  // pinned host memory: the host reads it behind an event, no copy in the stream
+        }
     }
     if (threadIdx.x == 0) __hip_atomic_store(ticket + 8 * TICKET_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

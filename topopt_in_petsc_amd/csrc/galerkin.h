@@ -199,29 +199,42 @@ __global__ __launch_bounds__(64) void k_galerkin_fine_masked(Geom gf, Geom gc, c
                                                              const int *__restrict__ list, double *__restrict__ Kel,
                                                              int compact) {
     // interpolation weights and KE in LDS: both are indexed per lane (constant memory would serialise)
-    __shared__ double s_W[512], s_KE[576];
+    __shared__ double s_W[512], s_KE[576], s_E[8];
+    __shared__ unsigned s_m[27];
     for (int q = threadIdx.x; q < 512; q += 64) s_W[q] = c_W[q];
     for (int q = threadIdx.x; q < 576; q += 64) s_KE[q] = KE[q];
-    __syncthreads();
     const long t = list[blockIdx.x];
     const long slot = compact ? (long)blockIdx.x : t;  // compact: the matrix of the f-th listed element is row f
     const int Ie = (int)(t % gc.ex), Je = (int)((t / gc.ex) % gc.ey), Ke = (int)(t / ((long)gc.ex * gc.ey));
+    // the element's 27 fine nodes' masks and 8 child moduli, ONE round trip up front (round 3 read a mask byte inside
+    // every trip of the nested loops below, behind divergent `continue`s: ~600 dependent global loads per wave, 334 us for
+    // the 4096 flagged elements of the 128^3 cantilever -- the head of the set-up's longest chain)
+    if (threadIdx.x < 27) {
+        const int di = threadIdx.x % 3, dj = (threadIdx.x / 3) % 3, dk = threadIdx.x / 9;
+        s_m[threadIdx.x] = mask[(long)(2 * Ie + di) + (long)gf.nx * ((2 * Je + dj) + (long)gf.ny * (2 * Ke + dk))];
+    } else if (threadIdx.x >= 32 && threadIdx.x < 40) {
+        const int c = threadIdx.x - 32;
+        const int i = 2 * Ie + (c & 1), j = 2 * Je + ((c >> 1) & 1), k = 2 * Ke + ((c >> 2) & 1);
+        s_E[c] = E[(long)i + (long)gf.ex * (j + (long)gf.ey * k)];
+    }
+    __syncthreads();
     const int I = threadIdx.x >> 3, J = threadIdx.x & 7;
     double acc[9];
 #pragma unroll
     for (int q = 0; q < 9; q++) acc[q] = 0.0;
     for (int c = 0; c < 8; c++) {
-        const int i = 2 * Ie + (c & 1), j = 2 * Je + ((c >> 1) & 1), k = 2 * Ke + ((c >> 2) & 1);
-        const double Ec = E[(long)i + (long)gf.ex * (j + (long)gf.ey * k)];
+        const int ci = c & 1, cj = (c >> 1) & 1, ck = (c >> 2) & 1;   // child position inside the coarse element
+        const int i = 2 * Ie + ci, j = 2 * Je + cj, k = 2 * Ke + ck;
+        const double Ec = s_E[c];
         for (int a = 0; a < 8; a++) {
             const double wa = s_W[(c * 8 + a) * 8 + I];
             if (wa == 0.0) continue;
             const int ia = i + c_LX[a], ja = j + c_LY[a], ka = k + c_LZ[a];
-            const unsigned ma = mask[(long)ia + (long)gf.nx * (ja + (long)gf.ny * ka)];
+            const unsigned ma = s_m[(ci + c_LX[a]) + 3 * ((cj + c_LY[a]) + 3 * (ck + c_LZ[a]))];
             for (int b = 0; b < 8; b++) {
                 const double wb = s_W[(c * 8 + b) * 8 + J];
                 if (wb == 0.0) continue;
-                const unsigned mb = mask[(long)(i + c_LX[b]) + (long)gf.nx * ((j + c_LY[b]) + (long)gf.ny * (k + c_LZ[b]))];
+                const unsigned mb = s_m[(ci + c_LX[b]) + 3 * ((cj + c_LY[b]) + 3 * (ck + c_LZ[b]))];
                 const double w = wa * wb * Ec;
                 for (int r = 0; r < 3; r++)
                     for (int cc = 0; cc < 3; cc++)

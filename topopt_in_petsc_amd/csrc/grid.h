@@ -23,6 +23,7 @@ struct tp_grid {
     double *scal;       // [dev] 64 device scalars
     unsigned *ticket;   // [dev] arrival counter of the in-kernel reduction tails (common.h: reduce_tail), rests at 0
     double *h_scal;     // pinned host mirror
+    double *h_scal_dev; // its address as the device sees it (kernels that deposit a scalar for the host directly)
     hipEvent_t ev_scal; // marks the read-back of read_scal_begin
     // accounting (algorithmic model)
     double alg_bytes, flops;

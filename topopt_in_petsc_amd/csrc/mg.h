@@ -55,11 +55,15 @@ struct Level {
 // CG scalar slots in tp_grid::scal
 enum { S_BB = 0, S_RR = 1, S_PW = 2, S_RZ0 = 3, S_RZ1 = 4, S_TMP = 8 };
 
+// x += alpha p, r -= alpha w, ||r||^2 (also to pinned host memory if out_host); z1 != NULL: also the first Chebyshev step of
+// the NEXT V-cycle's pre-smoothing from its zero guess, z1 = dinv r / theta (k_cheb_first: the same product in the same
+// order) -- one pass over r less and one launch less per Krylov iteration
 __global__ __launch_bounds__(BLK) void k_cg_update_xr(double *__restrict__ x, double *__restrict__ r,
                                                       const double *__restrict__ p, const double *__restrict__ w,
                                                       const double *__restrict__ scal, int slot_rz, long off, long n,
                                                       double *__restrict__ partials, unsigned *ticket,
-                                                      double *__restrict__ out) {
+                                                      double *__restrict__ out, double *__restrict__ out_host,
+                                                      double *__restrict__ z1, const double *__restrict__ dinv, double inv_theta) {
     const double alpha = scal[slot_rz] / scal[S_PW];
     double s = 0.0;
     for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
@@ -68,9 +72,10 @@ __global__ __launch_bounds__(BLK) void k_cg_update_xr(double *__restrict__ x, do
         const double rn = fma(-alpha, w[q], r[q]);
         r[q] = rn;
         s = fma(rn, rn, s);
+        if (z1) z1[q] = dinv[q] * rn * inv_theta;
     }
     const double v[1] = {block_sum(s)};
-    reduce_tail<1>(v, partials, gridDim.x, blockIdx.x, ticket, out);
+    reduce_tail<1>(v, partials, gridDim.x, blockIdx.x, ticket, out, out_host);
 }
 // p = z + (rz_new/rz_old) p   (first: p = z)
 __global__ __launch_bounds__(BLK) void k_cg_update_p(double *__restrict__ p, const double *__restrict__ z,
@@ -1285,10 +1290,11 @@ struct MGSolver {
     // has ~200 us of work while the host wakes up (vcycle(0, b) then starts behind it).  It writes multigrid scratch
     // only; if the iteration turns out to be the last one, it was for nothing.
     const double *head_for = nullptr;
+    bool fine_first_done = false;  // the CG update has written x1 = dinv b / theta of the fine level already (solve())
     int vcycle_head(const double *b) {
         head_for = nullptr;
         if (nlv < 2) return TP_OK;
-        TP_TRY(smooth(0, b, opt.nsmooth, true));
+        TP_TRY(smooth(0, b, opt.nsmooth, true, -1, fine_first_done));
         head_for = b;
         return TP_OK;
     }
@@ -1597,6 +1603,7 @@ struct MGSolver {
         int its = 0, rc = TP_OK;
         int rz_cur = S_RZ0, rz_old = S_RZ1;
         static const bool spec_head = getenv("TP_NO_SPEC_HEAD") == nullptr;
+        static const bool fuse_cg = getenv("TP_NO_CG_FUSE") == nullptr;
         head_for = nullptr;
         if (rnorm > ttol) {
             for (its = 1; its <= opt.max_it; its++) {
@@ -1628,13 +1635,28 @@ struct MGSolver {
                     TP_TRY(op<EPI_APPLY_DOT>(0, a));
                     TP_TRY(finish_tail<1>(grid, last_nblocks, S_PW));
                 }
+                // one rank: ||r||^2 goes straight to pinned host memory from the reduction's last workgroup (no copy in
+                // the stream), and the update also writes the first Chebyshev step of the next V-cycle (see the kernel)
+                const bool direct_rr = fuse_cg && !grid->has_comm && tail_ticket(grid) && grid->h_scal_dev;
+                const bool fuse_first = direct_rr && spec_head && its < opt.max_it && nlv >= 2 && opt.nsmooth >= 1 && three_term(L) &&
+                                        !sg_capturing;
+                double th0 = 1.0, de0 = 1.0;
+                if (fuse_first) cheb_window(0, &th0, &de0);
                 TP_LAUNCH(k_cg_update_xr, dim3(nb), dim3(BLK), 0, s, x, r, p, w, grid->scal, rz_cur, off, n,
-                                   grid->partials, tail_ticket(grid), grid->scal + S_RR);
-                count_launch(grid, 48.0 * n, 6.0 * n);
+                                   grid->partials, tail_ticket(grid), grid->scal + S_RR, direct_rr ? grid->h_scal_dev : nullptr,
+                                   fuse_first ? L.x : nullptr, L.dinv, 1.0 / th0);
+                count_launch(grid, (fuse_first ? 64.0 : 48.0) * n, 6.0 * n);
                 TP_TRY(finish_tail<1>(grid, nb, S_RR));
                 double rr;
-                TP_TRY(read_scal_begin(grid, S_RR, 1));
+                if (direct_rr) {
+                    if (!grid->ev_scal) TP_HIP(hipEventCreateWithFlags(&grid->ev_scal, hipEventDisableTiming));
+                    TP_HIP(hipEventRecord(grid->ev_scal, s));
+                } else {
+                    TP_TRY(read_scal_begin(grid, S_RR, 1));
+                }
+                fine_first_done = fuse_first;
                 if (spec_head && its < opt.max_it) TP_TRY(vcycle_head(r));  // next iteration's first kernels, then wait
+                fine_first_done = false;
                 TP_TRY(read_scal_end(grid, 1, &rr));
                 rnorm = sqrt(rr);
                 if (hist && its < hist_cap) hist[its] = rnorm;

@@ -48,6 +48,11 @@ extern "C" int tp_grid_create(tp_grid **out, const tp_grid_opts *o) {
         delete g;
         return TP_ERR_HIP + (int)hipErrorOutOfMemory;
     }
+    g->h_scal_dev = nullptr;
+    if (hipHostGetDevicePointer((void **)&g->h_scal_dev, g->h_scal, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        g->h_scal_dev = nullptr;  // (the solver then copies its scalars back as before)
+    }
     (void)hipMemsetAsync(g->scal, 0, sizeof(double) * 64, g->stream);
     (void)hipMemsetAsync(g->ticket, 0, sizeof(unsigned) * TICKET_WORDS, g->stream);
     double W[512];
