@@ -92,7 +92,7 @@ inline void host_grandchild_matrices(const double *M, double *M2) {
 // 551 us at 128^3 for 1.2 G fma (the kernel heads the longest chain of the set-up: -> level 3 -> level 4 -> factorisation).
 // Round 4: the moduli of EIGHT elements are gathered by 512 threads (one value each), parked in registers while the
 // previous batch is computed, and passed through a double-buffered LDS table that every thread reads as broadcasts.
-// Same products in the same order as before: same bits.
+// Same products; summed as four partial sums in a fixed order (round 3: one chain).
 // A workgroup serves ONE THIRD of the 576 entries (192 threads = 3 waves; blockIdx.y = third): several small workgroups
 // share a CU and hide each other's barrier and LDS latency, and a thread may use up to 256 registers.
 constexpr int L2F_B = 6, L2F_T = 192;
@@ -144,7 +144,9 @@ __global__ __launch_bounds__(L2F_T, 2) void k_galerkin_l2_fast(Geom g0, Geom g2,
             l2f_d2 ev[2][8];
 #pragma unroll
             for (int u = 0; u < 8; u++) ev[0][u] = se[u];
-            double sacc = 0.0;
+            // four partial sums (one per x position of the 4 x 4 x 4 block), added up at the end in a fixed order: a single
+            // chain of 64 dependent FP64 fma left the two waves of a SIMD waiting on each other's latency
+            double sa[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int z = 0; z < 4; z++) {
                 if (z < 3) {
@@ -157,10 +159,11 @@ __global__ __launch_bounds__(L2F_T, 2) void k_galerkin_l2_fast(Geom g0, Geom g2,
 #pragma unroll
                     for (int x = 0; x < 4; x++) {
                         const int c2 = (x >> 1) + 2 * (y >> 1) + 4 * (z >> 1), g = (x & 1) + 2 * (y & 1) + 4 * (z & 1);
-                        sacc = fma(ev[z & 1][(x + 4 * y) >> 1][x & 1], m2[c2 * 8 + g], sacc);
+                        sa[x] = fma(ev[z & 1][(x + 4 * y) >> 1][x & 1], m2[c2 * 8 + g], sa[x]);
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            const double sacc = (sa[0] + sa[1]) + (sa[2] + sa[3]);
             Kc[(long)((int)blockIdx.x + (b0 + j) * (int)gridDim.x) * 576 + t] = sacc;
         }
 #pragma unroll
@@ -199,9 +202,8 @@ __global__ __launch_bounds__(64) void k_galerkin_fine_masked(Geom gf, Geom gc, c
                                                              const int *__restrict__ list, double *__restrict__ Kel,
                                                              int compact) {
     // interpolation weights and KE in LDS: both are indexed per lane (constant memory would serialise)
-    __shared__ double s_W[512], s_KE[576], s_E[8];
+    __shared__ double s_KE[576], s_E[8];
     __shared__ unsigned s_m[27];
-    for (int q = threadIdx.x; q < 512; q += 64) s_W[q] = c_W[q];
     for (int q = threadIdx.x; q < 576; q += 64) s_KE[q] = KE[q];
     const long t = list[blockIdx.x];
     const long slot = compact ? (long)blockIdx.x : t;  // compact: the matrix of the f-th listed element is row f
@@ -222,37 +224,71 @@ __global__ __launch_bounds__(64) void k_galerkin_fine_masked(Geom gf, Geom gc, c
     double acc[9];
 #pragma unroll
     for (int q = 0; q < 9; q++) acc[q] = 0.0;
-    for (int c = 0; c < 8; c++) {
-        const int ci = c & 1, cj = (c >> 1) & 1, ck = (c >> 2) & 1;   // child position inside the coarse element
-        const int i = 2 * Ie + ci, j = 2 * Je + cj, k = 2 * Ke + ck;
-        const double Ec = s_E[c];
-        for (int a = 0; a < 8; a++) {
-            const double wa = s_W[(c * 8 + a) * 8 + I];
-            if (wa == 0.0) continue;
-            const int ia = i + c_LX[a], ja = j + c_LY[a], ka = k + c_LZ[a];
-            const unsigned ma = s_m[(ci + c_LX[a]) + 3 * ((cj + c_LY[a]) + 3 * (ck + c_LZ[a]))];
-            for (int b = 0; b < 8; b++) {
-                const double wb = s_W[(c * 8 + b) * 8 + J];
-                if (wb == 0.0) continue;
-                const unsigned mb = s_m[(ci + c_LX[b]) + 3 * ((cj + c_LY[b]) + 3 * (ck + c_LZ[b]))];
-                const double w = wa * wb * Ec;
-                for (int r = 0; r < 3; r++)
-                    for (int cc = 0; cc < 3; cc++)
-                        if (!((ma >> r) & 1u) && !((mb >> cc) & 1u))
-                            acc[r * 3 + cc] = fma(w, s_KE[(3 * a + r) * 24 + 3 * b + cc], acc[r * 3 + cc]);
+    // The trilinear weight of coarse corner I at fine corner a of child c is a product over the three directions of
+    // w1(c_d + a_d, I_d) in {1, 1/2, 0}.  Of the 8 combinations (c_d, a_d, b_d) of one direction only 4 or 5 give a non-zero
+    // w1(c_d + a_d, I_d) w1(c_d + b_d, J_d): the lane walks ITS OWN 5 x 5 x 5 list (a zero-weight dummy pads the lists of 4)
+    // instead of all 8 x 8 x 8 triples -- round 3 did, with 3/4 of the trips skipped by divergent `continue`s: the kernel
+    // was bound by the instructions of trips that did nothing (277 us for 4096 elements).
+    // per direction and list entry: c_d | a_d << 1 | b_d << 2, and w1(c_d + a_d, I_d) * w1(c_d + b_d, J_d); in LDS, a column
+    // per lane (private arrays indexed by the loop counters would live in scratch memory)
+    __shared__ int s_cab[15][64];
+    __shared__ double s_wd[15][64];
+    const int ln = threadIdx.x;
+    {
+        const int Ib[3] = {c_LX[I], c_LY[I], c_LZ[I]}, Jb[3] = {c_LX[J], c_LY[J], c_LZ[J]};
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            int n = 0;
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const int cd = t & 1, ad = (t >> 1) & 1, bd = (t >> 2) & 1;
+                const int fa = cd + ad, fb = cd + bd;
+                const double wI = fa == 1 ? 0.5 : (fa == 2 * Ib[d] ? 1.0 : 0.0), wJ = fb == 1 ? 0.5 : (fb == 2 * Jb[d] ? 1.0 : 0.0);
+                if (wI * wJ != 0.0 && n < 5) {
+                    s_cab[d * 5 + n][ln] = t;
+                    s_wd[d * 5 + n][ln] = wI * wJ;
+                    n++;
+                }
             }
-            if (ma) {
-                // Dirichlet identity, shared between the elements around the node:
-                // multiplicity from the GLOBAL position of the node
-                const int kg = ka + gf.gz0;
-                const int mult = ((ia == 0 || ia == gf.nx - 1) ? 1 : 2) * ((ja == 0 || ja == gf.ny - 1) ? 1 : 2) *
-                                 ((kg == 0 || kg == gf.nz_glob - 1) ? 1 : 2);
-                const double w = wa * s_W[(c * 8 + a) * 8 + J] / (double)mult;
-                for (int r = 0; r < 3; r++)
-                    if ((ma >> r) & 1u) acc[r * 3 + r] += w;
-            }
+            for (; n < 5; n++) s_cab[d * 5 + n][ln] = 0, s_wd[d * 5 + n][ln] = 0.0;
         }
     }
+    // corner number from its (x, y, z) bits (c_LX, c_LY, c_LZ: counter-clockwise in the lower plane, then the upper one)
+    auto corner_of = [](int x, int y, int z) { return (y ? 3 - x : x) + 4 * z; };
+    for (int tz = 0; tz < 5; tz++)
+        for (int ty = 0; ty < 5; ty++)
+            for (int tx = 0; tx < 5; tx++) {
+                const double wIJ = s_wd[tx][ln] * s_wd[5 + ty][ln] * s_wd[10 + tz][ln];   // (powers of two: exact)
+                if (wIJ == 0.0) continue;
+                const int ex_ = s_cab[tx][ln], ey_ = s_cab[5 + ty][ln], ez_ = s_cab[10 + tz][ln];
+                const int ci = ex_ & 1, cj = ey_ & 1, ck = ez_ & 1;      // child position inside the coarse element
+                const int c = ci + 2 * cj + 4 * ck;
+                const int ax = (ex_ >> 1) & 1, ay = (ey_ >> 1) & 1, az = (ez_ >> 1) & 1;
+                const int bx = (ex_ >> 2) & 1, by = (ey_ >> 2) & 1, bz = (ez_ >> 2) & 1;
+                const int a = corner_of(ax, ay, az), b = corner_of(bx, by, bz);
+                const unsigned ma = s_m[(ci + ax) + 3 * ((cj + ay) + 3 * (ck + az))];
+                const unsigned mb = s_m[(ci + bx) + 3 * ((cj + by) + 3 * (ck + bz))];
+                const double w = wIJ * s_E[c];
+                // a clamped row / column takes weight 0 (fma(0, k, acc) = acc: the same bits as skipping the term, no branch)
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+#pragma unroll
+                    for (int cc = 0; cc < 3; cc++) {
+                        const double wm = (((ma >> r) | (mb >> cc)) & 1u) ? 0.0 : w;
+                        acc[r * 3 + cc] = fma(wm, s_KE[(3 * a + r) * 24 + 3 * b + cc], acc[r * 3 + cc]);
+                    }
+                if (a == b && ma) {
+                    // Dirichlet identity, shared between the elements around the node:
+                    // multiplicity from the GLOBAL position of the node
+                    const int ia = 2 * Ie + ci + ax, ja = 2 * Je + cj + ay, ka = 2 * Ke + ck + az;
+                    const int kg = ka + gf.gz0;
+                    const int mult = ((ia == 0 || ia == gf.nx - 1) ? 1 : 2) * ((ja == 0 || ja == gf.ny - 1) ? 1 : 2) *
+                                     ((kg == 0 || kg == gf.nz_glob - 1) ? 1 : 2);
+                    const double wi = wIJ / (double)mult;
+                    for (int r = 0; r < 3; r++)
+                        if ((ma >> r) & 1u) acc[r * 3 + r] += wi;
+                }
+            }
     for (int r = 0; r < 3; r++)
         for (int cc = 0; cc < 3; cc++) Kel[slot * 576 + (3 * I + r) * 24 + 3 * J + cc] = acc[r * 3 + cc];
 }
