@@ -30,6 +30,9 @@
 #ifndef FT_ABL
 #define FT_ABL 0  // ablation builds (tools/ablate_fine.sh): 1 no block products, 2 no plane loads, 3 no stores, 4 no barrier, 5 no E, 6 no epilogue loads, 8 one workgroup less per CU, 9 data movement only (no LDS, no barrier, no arithmetic)
 #endif
+#ifndef FT_STORE_AUX
+#define FT_STORE_AUX 0  // cache policy bits of the output stores (gfx942+: 1 sc0, 2 sc1, 4 nt)
+#endif
 constexpr int RING = 4;
 constexpr int SLOT = 4 * TILE * TILE;  // padded ring slot (STG_N = 867 used)
 
@@ -312,8 +315,8 @@ __device__ __forceinline__ void fine_tile_run(const TileArgs &t, const NodeArgs 
         typedef unsigned u4_t __attribute__((ext_vector_type(4)));
         typedef unsigned u2_t __attribute__((ext_vector_type(2)));
         const d2_t o01 = {o[0], o[1]};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, o01), rs, voff_out, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, o[2]), rs, voff_out + 16u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, o01), rs, voff_out, 0, FT_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, o[2]), rs, voff_out + 16u, 0, FT_STORE_AUX);
     };
     for (int s = 0; s < nsteps; s++) step(s);
     if (EPI == EPI_APPLY_DOT || EPI == EPI_CHEB_DOT) {
