@@ -296,6 +296,9 @@ def cpu_baseline(sample, rtol, fine_eig, gpu_el, gpu_ndof, budget_s, nlv=4, nsmo
                           " / cycles per level " + cycles if cycles else "", r["its"], t, cores, host["cpu_model"], host["os_cpu_count"])}
 
 
+MEASURE_S = float(os.environ.get("TP_BENCH_MEASURE_S", "1.0"))   # seconds of back-to-back launches per micro-measurement
+
+
 def fine_kernel_times(tp, torch, ex, ey, ez, reps):
     """HIP-event averages of the two fine-level kernels on an ex x ey x ez mesh (1 level, synthetic density):
     (spmv_ms, cheb_ms, n_nodes, n_elems)."""
@@ -310,12 +313,16 @@ def fine_kernel_times(tp, torch, ex, ey, ez, reps):
 
     def timed(fn, n):
         # warm-up long enough for the clocks to settle: the first launches after an idle phase measured 15-20 % slower
-        # (rocprofv3: 274 .. 351 us for one kernel of this loop against 257 .. 273 us in a busy process)
+        # (rocprofv3: 274 .. 351 us for one kernel of this loop against 257 .. 273 us in a busy process); then at least
+        # MEASURE_S seconds of launches (steadier averages, and a GPU phase long enough for a 5-s utilisation sampler)
         t0 = time.time()
+        calls = 0
         while time.time() - t0 < 0.15:
             for _ in range(5):
                 fn()
+            calls += 5
             torch.cuda.synchronize()
+        n = max(n, int(MEASURE_S * calls / max(time.time() - t0, 1e-3)))
         e0.record()
         for _ in range(n):
             fn()
@@ -560,10 +567,13 @@ def main():
 
     def timed(fn, reps):
         t0 = time.time()
+        calls = 0
         while time.time() - t0 < 0.15:  # clocks settled (see fine_kernel_times)
             for _ in range(5):
                 fn()
+            calls += 5
             torch.cuda.synchronize()
+        reps = max(reps, int(MEASURE_S * calls / max(time.time() - t0, 1e-3)))
         ev0.record()
         for _ in range(reps):
             fn()
@@ -639,7 +649,7 @@ def main():
     cheb_ms = (t_smooth - t_copy) / ksm
     spmv_ms = timed(lambda: le.MatMult(u, y), a.spmv_reps)
     b2b = {"avg_launch_ms": cheb_ms, "achieved": cheb_bytes / (cheb_ms * 1e-3) / 1e9, "frac": cheb_bytes / (cheb_ms * 1e-3) / 1e9 / 8000.0,
-           "how": "HIP events around %d back-to-back launches on the same vectors (Infinity Cache warm)" % (ksm * max(a.spmv_reps // 4, 2))}
+           "how": "HIP events around >= %d back-to-back launches (>= %.1f s) on the same vectors (Infinity Cache warm)" % (ksm * max(a.spmv_reps // 4, 2), MEASURE_S)}
     how = "back-to-back launches"
     roof_bytes = cheb_bytes
     if cheb_in_step_n:

@@ -24,6 +24,11 @@
  *     for those parts PARITY IS UNPINNED against the reference and is anchored
  *     instead by solver-independent invariants (tests/test_oracle_*.py).
  *
+ * THREADS.  The loops that carry the time of a design iteration (CSR assembly, Galerkin SpGEMM, CSR products, restriction,
+ * vector updates, compliance) run under OpenMP, and every one of them is written so that a thread computes WHOLE result
+ * entries with the serial form's order of additions (reductions: fixed chunks, partial sums added in chunk order): results do
+ * not depend on the thread count, bit for bit (tests: 1 against 8 threads).  bench.py's cpu_baseline uses all usable cores.
+ *
  * Build: see oracle/Makefile  (gcc -O2 -ffp-contract=off -fopenmp -shared).
  */
 #include <math.h>

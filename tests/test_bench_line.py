@@ -9,6 +9,7 @@ import time
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("TP_BENCH_MEASURE_S", "0.05")   # the bench's micro-measurements: short in the tests (inherited by its subprocesses)
 
 
 @pytest.mark.gpu
