@@ -456,7 +456,7 @@ __global__ __launch_bounds__(TX *TY, WPS) void k_fine_u4(TileArgs t, NodeArgs a)
         masked = __builtin_amdgcn_readfirstlane(__syncthreads_or(any != 0u)) != 0;
     }
     if (masked)
-        fine_u4_run<EPI, TX, TY, WPS == 2, true, WPS == 2>(t, a, lds, bxi, byi, bzi);  // (two waves per SIMD: registers for the carried plane)
+        fine_u4_run<EPI, TX, TY, (WPS * TX * TY <= 512), true, (WPS * TX * TY <= 512)>(t, a, lds, bxi, byi, bzi);  // (two waves per SIMD: registers for the carried plane)
     else
         fine_u4_run<EPI, TX, TY, CARRY, false>(t, a, lds, bxi, byi, bzi);
 }

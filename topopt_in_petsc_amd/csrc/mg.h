@@ -602,7 +602,7 @@ struct MGSolver {
                 static const int shape_env = getenv("TP_FINE_SHAPE") ? atoi(getenv("TP_FINE_SHAPE")) : 0;  // 1: 16x16, 2: 32x8
                 // measured on the BASELINE meshes (tools/probe/fine_probe.hip, profiles/r03_fine_probe.txt): the long
                 // rows of 32 x 8 win once a chunk of them fills the chip (256^3, 512x256x256; Chebyshev from 256x128x128)
-                const bool wide = shape_env ? shape_env == 2 : t32 >= (IS_CHEB ? 160 : 256);
+                const bool wide = shape_env ? shape_env >= 2 : t32 >= (IS_CHEB ? 160 : 256);
                 const bool timed3 = grid->kt_on && IS_CHEB && !split && !sg_capturing;
                 if (timed3) kernel_timer_mark(grid);
                 for (int pass = 0; pass < (split ? 2 : 1); pass++) {
@@ -622,7 +622,11 @@ struct MGSolver {
                     TileArgs ta{L.g.nx, L.g.ny, L.g.nzl, L.g.ex, L.g.ey, L.g.ezl, lo, hi, kz3,
                                 L.E, L.mask, L.colmask, L.sym_slot * SYMKE_STRIDE, 0, 0, nullptr, xcd_remap(), 0, r1lo, r1hi,
                                 0, nullptr, nullptr, 0, nullptr};
-                    if (wide) {
+                    if (wide && shape_env == 3) {  // experiment: 32 x 16 threads (31 x 15 nodes out: 1.10 instead of 1.18 x the bytes), one workgroup of 8 waves per CU
+                        gdim = dim3((L.g.nx + 30) / 31, (L.g.ny + 14) / 15, tz);
+                        last_nblocks = gdim.x * gdim.y * gdim.z;
+                        TP_LAUNCH((k_fine_u4<EPI, 32, 16, 1, true>), gdim, dim3(512), 0, grid->stream, ta, a);
+                    } else if (wide) {
                         gdim = dim3((L.g.nx + 30) / 31, (L.g.ny + 6) / 7, tz);
                         last_nblocks = gdim.x * gdim.y * gdim.z;
                         TP_LAUNCH((k_fine_u4<EPI, 32, 8, 2, true>), gdim, dim3(256), 0, grid->stream, ta, a);
