@@ -107,6 +107,31 @@ __device__ inline double cd_readlane(double v, int l) {
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
+// 32 steps of the substitution x L^T = t on a row of a tile held by 16 lanes (two columns per lane, c0 = 2 * (lane & 15)):
+// step M: x_M = acc_M / l_MM in its owner (lane M / 2 of the row), handed to the row's lanes by a DPP row_share, then
+// acc_c -= x_M l_cM for c > M.  sDt[m][c] = l_cm with the reciprocal of the diagonal on the diagonal.  (The DPP control is an
+// immediate: the steps are a compile-time recursion.)
+template <int M>
+__device__ __forceinline__ void cd_sub_steps(double &x0, double &x1, const double *sDt, int c0, int q16) {
+    if constexpr (M < CD_NB) {
+        const cd_d2 lm = *reinterpret_cast<const cd_d2 *>(sDt + M * CD_NB + c0);  // l_{c0 M}, l_{c0+1 M}
+        const double dm = sDt[M * CD_NB + M];                                    // 1 / l_MM
+        const double xm = ((M & 1) ? x1 : x0) * dm;
+        if (q16 == (M >> 1)) {
+            if (M & 1) x1 = xm;
+            else x0 = xm;
+        }
+        const unsigned long long u = __builtin_bit_cast(unsigned long long, xm);
+        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x150 + (M >> 1), 0xf, 0xf, false);
+        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x150 + (M >> 1), 0xf, 0xf, false);
+        const double xb = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);  // x_M of this row, in all its lanes
+        // columns at or left of M are finished: weight 0 (fma(-x, 0, acc) = acc)
+        x0 = fma(-xb, c0 > M ? lm[0] : 0.0, x0);
+        x1 = fma(-xb, c0 + 1 > M ? lm[1] : 0.0, x1);
+        cd_sub_steps<M + 1>(x0, x1, sDt, c0, q16);
+    }
+}
+
 // Ld: per block column the 32 x 32 diagonal factor, row-major, with the RECIPROCALS of its diagonal on the diagonal
 __global__ __launch_bounds__(CD_T) void k_cd_factor(CdGeom c, double *Lb, double *__restrict__ Ld, XcdRunCtrl *ctl, int P, long long *prof) {
     __shared__ double sOwn[CD_KBMAX * CD_BLK];  // finished tiles of my row block, transposed, slot j % KB
@@ -236,38 +261,36 @@ __global__ __launch_bounds__(CD_T) void k_cd_factor(CdGeom c, double *Lb, double
             break;
         }
         mark(3);
-        // ---- (C) the others: L_ik = T L_kk^-T (row per lane), into my LDS and out; the owner of k: its next row block
-        if (act && !diag && wave == 0) {
-            double *sDt = sStage;  // (wave 0's staging area: free between the products of (A) and (B))
-            {   // the factor of block column k (row-major, reciprocal diagonal) -> transposed: sDt[m][c] = l_cm
+        // ---- (C) the others: L_ik = T L_kk^-T, into my LDS and out; the owner of k: its next row block.
+        // Round 4: the substitution runs on all four waves -- 16 lanes per row of the tile, two columns per lane, the finished
+        // x_m handed to the row's lanes by a DPP row_share -- where round 3 ran it as a row per lane on half of ONE wave (496
+        // dependent-ish fma per lane behind LDS broadcasts: the longer of the kernel's two single-wave stages, 9.5 of the
+        // 28 us of a block column).  Same operations on every entry in the same order: same bits.
+        if (act && !diag) {  // (workgroup-uniform)
+            double *sDt = sStage;  // (the staging areas are free between the products of (B) and (A))
+            {   // the factor of block column k (row-major, reciprocal diagonal) -> transposed: sDt[m][c] = l_cm; all threads
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Ld + (long)k * CD_BLK, 0, CD_BLK * 8, 0x00020000);
-                cd_u4 v[8];
+                cd_u4 v[2];
 #pragma unroll
-                for (int q = 0; q < 8; q++) v[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (q * WAVE + lane) * 16, 0, 16 /* sc1 */);
+                for (int q = 0; q < 2; q++) v[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (q * CD_T + t) * 16, 0, 16 /* sc1 */);
 #pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const int idx = (q * WAVE + lane) * 2, rr = idx >> 5, cc = idx & 31;
+                for (int q = 0; q < 2; q++) {
+                    const int idx = (q * CD_T + t) * 2, rr = idx >> 5, cc = idx & 31;
                     const cd_d2 d = __builtin_bit_cast(cd_d2, v[q]);
                     sDt[cc * CD_NB + rr] = d[0];
                     sDt[(cc + 1) * CD_NB + rr] = d[1];
                 }
             }
-            if (lane < CD_NB) {
-                // x L^T = t, a row per lane: x_m = acc_m / l_mm, then acc_c -= x_m l_cm for c > m (independent updates; the
-                // factors l_cm, c = m + 1 .., are consecutive in the transposed copy: 16-byte broadcast reads)
-                const int r = lane;
-                double x[CD_NB];
+            __syncthreads();
+            double *own = sOwn + (k % c.KB) * CD_BLK, *out = Lb + cd_blk(c, i, k);
+            const int q16 = lane & 15, c0 = 2 * q16;
 #pragma unroll
-                for (int cc = 0; cc < CD_NB; cc++) x[cc] = sT[r * CD_LD + cc];
-#pragma unroll
-                for (int m = 0; m < CD_NB; m++) {
-                    x[m] = x[m] * sDt[m * CD_NB + m];
-#pragma unroll
-                    for (int c2 = m + 1; c2 < CD_NB; c2++) x[c2] = fma(-x[m], sDt[m * CD_NB + c2], x[c2]);
-                }
-                double *own = sOwn + (k % c.KB) * CD_BLK, *out = Lb + cd_blk(c, i, k);
-#pragma unroll
-                for (int cc = 0; cc < CD_NB; cc++) own[cc * CD_NB + r] = x[cc], out[cc * CD_NB + r] = x[cc];
+            for (int pass = 0; pass < 2; pass++) {
+                const int r = pass * 16 + wave * 4 + (lane >> 4);
+                double x0 = sT[r * CD_LD + c0], x1 = sT[r * CD_LD + c0 + 1];
+                cd_sub_steps<0>(x0, x1, sDt, c0, q16);
+                own[c0 * CD_NB + r] = x0, own[(c0 + 1) * CD_NB + r] = x1;
+                out[c0 * CD_NB + r] = x0, out[(c0 + 1) * CD_NB + r] = x1;
             }
         }
         if (diag) {
