@@ -10,7 +10,7 @@
 // at the price of a factorisation per design iteration, which runs on a stream of its own beside the spectra estimates of
 // the other levels:
 //   k_cd_fill     stencil (DIA) rows -> block-band storage of the lower triangle (32 x 32 blocks, stored transposed);
-//   k_cd_factor   block Cholesky, left-looking per tile.  KB+1 workgroups on ONE XCD (join protocol and barrier of
+//   k_cd_factor   block Cholesky, left-looking per tile (round 4: the tile substitution of stage (C) on all four waves).  KB+1 workgroups on ONE XCD (join protocol and barrier of
 //                 coarse_run.h); a workgroup OWNS a row block (i -> workgroup i mod (KB+1)) and walks its tiles left to right
 //                 with the row block's finished tiles in LDS.  Per block column k: the owner of row block k finishes the
 //                 diagonal tile (one product of its own data) and factors it in one wave (registers + LDS, no workgroup
