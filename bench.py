@@ -566,14 +566,22 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def timed(fn, reps):
-        t0 = time.time()
-        calls = 0
-        while time.time() - t0 < 0.15:  # clocks settled (see fine_kernel_times)
-            for _ in range(5):
+        if world > 1:
+            # several ranks: fn() contains halo exchanges, so every rank must make the SAME number of calls -- nothing here
+            # may depend on a rank's own clock (a time-based count did, in an earlier version of this function: one rank
+            # then waits in an exchange its neighbour never posts)
+            for _ in range(10):
                 fn()
-            calls += 5
             torch.cuda.synchronize()
-        reps = max(reps, int(MEASURE_S * calls / max(time.time() - t0, 1e-3)))
+        else:
+            t0 = time.time()
+            calls = 0
+            while time.time() - t0 < 0.15:  # clocks settled (see fine_kernel_times)
+                for _ in range(5):
+                    fn()
+                calls += 5
+                torch.cuda.synchronize()
+            reps = max(reps, int(MEASURE_S * calls / max(time.time() - t0, 1e-3)))
         ev0.record()
         for _ in range(reps):
             fn()
