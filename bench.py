@@ -566,6 +566,9 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def timed(fn, reps):
+        if os.environ.get("TP_BENCH_TEST_SLOW_RANK") == str(rank):   # tests/test_bench_line.py: this rank's clock runs differently
+            fast = fn
+            fn = lambda: (time.sleep(0.02), fast())
         if world > 1:
             # several ranks: fn() contains halo exchanges, so every rank must make the SAME number of calls -- nothing here
             # may depend on a rank's own clock (a time-based count did, in an earlier version of this function: one rank

@@ -79,6 +79,18 @@ def test_bench_spawns_its_own_ranks(scaling):
 
 
 @pytest.mark.gpu
+def test_bench_ranks_make_the_same_calls_whatever_their_clocks():
+    """Round 3's hang: the micro-measurement helper warmed up for a fixed TIME, so the number of Chebyshev sweeps -- each with
+    halo exchanges -- depended on a rank's own clock; one batch of difference and one rank waits for ever.  Here rank 1 is
+    slowed down inside that helper (TP_BENCH_TEST_SLOW_RANK): the run must still end, with its line."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + TWO_RANKS + ["--no-other-scaling", "--budget-s", "120"],
+                       capture_output=True, text=True, timeout=150, cwd=ROOT, env=dict(os.environ, TP_BENCH_TEST_SLOW_RANK="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.split("\n") if ln.strip()][-1])
+    assert "error" not in d and d["n_gpus"] == 2 and d["value"] > 0
+
+
+@pytest.mark.gpu
 def test_bench_under_torch_distributed_run():
     """the driver's form for N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N"""
     import socket
