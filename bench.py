@@ -678,10 +678,11 @@ def main():
             traffic = rec
     gen3 = os.environ.get("TP_FINE_V", "0") in ("3",) or (os.environ.get("TP_FINE_V", "0") == "0" and ((nx + 30) // 31) * ((ny + 6) // 7) >= 160)
     kname = "k_fine_u4" if gen3 else "k_fine_tile"
-    roofline = {"bound": "hbm", "kernel": "%s<EPI_CHEB> (fine-level matrix-free hex8 operator fused with "
-                                          "the Chebyshev-Jacobi update; the largest kernel of the Krylov loop and the largest bandwidth-bound kernel of the step: "
-                                          "profiles/r03b_bench_step_shares.txt -- only the once-per-step factorisation of the coarsest level, "
-                                          "k_cd_factor, a latency-bound chain of 69 block columns on a side stream, adds up to more time: DESIGN 4.5)" % kname,
+    roofline = {"bound": "hbm", "kernel": "%s<EPI_CHEB> / <EPI_CHEB_DOT> (fine-level matrix-free hex8 operator fused with the Chebyshev-Jacobi "
+                                          "update, without / with the fused r.z: ONE loop, 34 launches per step; the largest kernel of the step by time and by "
+                                          "bytes: profiles/r04_bench_step_shares.txt -- 1.22 + 0.59 ms of 12.7; next: the level-2 block stencil, 121 launches "
+                                          "of 12 us = 1.50 ms out of the Infinity Cache (`level2_stencil` below), and the once-per-step factorisation of the "
+                                          "coarsest level, k_cd_factor, one latency-bound launch of 1.5 ms on a side stream: DESIGN 4.5)" % kname,
                 "share_of_step": cheb_step_share,
                 "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                 "traffic": (traffic or {}).get("cheb_hbm_bytes_per_launch", None) and traffic["cheb_hbm_bytes_per_launch"] / 1e9,
@@ -694,6 +695,25 @@ def main():
                          "frac": spmv_bytes / (spmv_ms * 1e-3) / 1e9 / 8000.0,
                          "traffic": (traffic or {}).get("hbm_bytes_per_launch", None) and traffic["hbm_bytes_per_launch"] / 1e9,
                          "fp64_tflops_dense_equiv": 1152.0 * n_el_own / (spmv_ms * 1e-3) / 1e12}}
+    # the runner-up by total time: the level-2 operator (27 x 3 x 3 block stencil stored by diagonals, 33^3 nodes at 128^3), launched
+    # 15 times per Krylov iteration.  Algorithmic bytes per SURVEY 8(d): (243 + 6) * 8 B per node of the level -- the kernel reads
+    # the symmetric half of the coefficients twice over (mirrored addresses), and at 72 MB the level never leaves the Infinity
+    # Cache between its launches, in the step as here: the figure is a cache rate, not an HBM rate.
+    if world == 1 and le.level_count() >= 4:
+        try:
+            b2, x2 = le.level_vec(2).normal_(), le.level_vec(2)
+            t8 = timed(lambda: le.smooth(2, b2, x2, 8, False), max(a.spmv_reps // 4, 2))
+            t0_ = timed(lambda: le.smooth(2, b2, x2, 0, False), max(a.spmv_reps // 4, 2))
+            l2_ms = (t8 - t0_) / 8
+            l2_bytes = (243.0 + 6.0) * 8.0 * le.level_nodes(2)
+            roofline["level2_stencil"] = {"kernel": "k_dia_row_split<3, EPI_CHEB, 3, true> (level-2 block stencil + Chebyshev update)",
+                                          "alg_bytes_per_launch": l2_bytes, "avg_launch_ms": l2_ms, "achieved": l2_bytes / (l2_ms * 1e-3) / 1e9,
+                                          "frac": l2_bytes / (l2_ms * 1e-3) / 1e9 / 8000.0, "launches_per_krylov_iteration": 15,
+                                          "note": "served by the 256 MB Infinity Cache (72 MB of coefficients, read as their symmetric half twice): "
+                                                  "a cache rate measured against the HBM peak; back-to-back launches"}
+            b2 = x2 = None
+        except Exception as e:      # (a level that is not a stored stencil: nothing to report)
+            roofline["level2_stencil"] = {"skipped": repr(e)}
     # the north-star mesh of the SpMV target (256^3 elements, 50.9 M DOF; vectors 407 MB each: beyond the 256 MB
     # Infinity Cache), measured in this run on rank 0 of a 1-GPU job
     if world == 1 and not a.no_cube256 and a.workload == "cantilever128":
