@@ -41,6 +41,8 @@ WORKLOADS = {
     "c5": dict(el=(512, 256, 256), nlvls=4, nsmooth=2, ncoarse=60),             # configs[4] ("4-level GMG") on ONE GPU (101.7 M DOF, ~35 GB of the 288 GB); with --gpus 8 --scaling strong: its slabs
     # configs[1] with the reference's own absolute filter radius (TopOpt.cc:121 rmin = 0.08: ElemConn 5, 1331-tap cone)
     "c2_rmin008": dict(el=(128, 64, 64), nlvls=3, nsmooth=2, ncoarse=45, rmin=0.08),
+    # the metric mesh with the reference's own absolute filter radius (rmin = 0.08: ElemConn 10, 9261-tap cone, z-streamed kernel)
+    "cantilever128_rmin008": dict(el=(128, 128, 128), nlvls=5, nsmooth=2, ncoarse=20, cycles="1,3,1,1", rmin=0.08),
     "tiny": dict(el=(32, 16, 16), nlvls=3, nsmooth=2, ncoarse=30),
 }
 

@@ -676,3 +676,65 @@ def test_one_xcd_kernels_give_up_path(tmp_path, where):
     # every solve of both processes is a cold start on the same hierarchy built by the same kernels
     assert list(f["its"]) == list(n["its"]) and max(f["its"]) < 200 and max(f["rel"]) <= 1e-5
     assert np.abs(f["U"] - n["U"]).max() <= 1e-12 * np.abs(n["U"]).max()
+
+
+@pytest.mark.parametrize("rfac", [9.5, 10.24])
+def test_conv_filter_streamed_radius(tp, orc, rfac):
+    """ElemConn 9 and 10 (k_conv_filter_zring: the reference's default rmin = 0.08 gives 10 at 128^3 and on C3, TopOpt.cc:121,
+    Filter.cc:326-327) against the oracle's explicit H, filter types 1 and 0, forward and gradients."""
+    ex, ey, ez = 34, 22, 22
+    h = 1.0 / ey
+    grid = tp.Grid(ex + 1, ey + 1, ez + 1, h)
+    of = orc.Filter(ex + 1, ey + 1, ez + 1, h, rfac * h)
+    rng = np.random.default_rng(7)
+    x = rng.random(ex * ey * ez) * 0.9 + 0.05
+    df0 = rng.standard_normal(x.size)
+    dg0 = np.full(x.size, 1.0 / x.size)
+    for ftype in (1, 0):
+        f = tp.Filter(grid, ftype, rfac * h)
+        assert f.ElemConn == of.conn == int(np.ceil(rfac)) - 1
+        assert rel(host(f.Hs()), of.hs()) <= 1e-14
+        xt, xp = grid.elem_vec(), grid.elem_vec()
+        f.FilterProject(dev(x), xt, xp)
+        xto, xpo = of.project(ftype, x)
+        assert rel(host(xt), xto) <= 1e-14
+        df, dg = dev(df0), dev(dg0)
+        f.Gradients(dev(x), xt, df, [dg])
+        assert rel(host(df), of.gradient(ftype, x, xto, df0)) <= 1e-13
+        dgo = of.gradient(ftype, x, xto, dg0) if ftype == 1 else dg0
+        assert rel(host(dg), dgo) <= 1e-13
+
+
+@pytest.mark.parametrize("conn", [10, 13, 16, 20])
+def test_conv_filter_streamed_bits(tmp_path, conn):
+    """the z-streamed kernel and the direct stencil loop give the same bits for ElemConn 10 .. 20 (9261 .. 68921 taps; the direct
+    form is selected with TP_NO_FILTER_TILE=1; the environment is read once per process); 20 = C5 at the reference's rmin"""
+    import subprocess, sys
+    worker = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import topopt_in_petsc_amd as tp\n"
+        "tp.load_library()\n"
+        "conn = int(sys.argv[2])\n"
+        "grid = tp.Grid(57, 45, 43, 1.0 / 44)\n"
+        "f = tp.Filter(grid, 1, (conn + 0.3) / 44.0)\n"
+        "assert f.ElemConn == conn, f.ElemConn\n"
+        "x = grid.synth_density(12345)\n"
+        "xt, xp = grid.elem_vec(), grid.elem_vec()\n"
+        "f.FilterProject(x, xt, xp)\n"
+        "df = torch.sin(torch.arange(x.numel(), dtype=torch.float64, device='cuda'))\n"
+        "f.Gradients(x, xt, df, [])\n"
+        "np.savez(sys.argv[1], xt=xt.cpu().numpy(), df=df.cpu().numpy(), hs=f.Hs().cpu().numpy())\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env in (("streamed", {}), ("direct", {"TP_NO_FILTER_TILE": "1"})):
+        e = dict(os.environ)
+        e.pop("TP_NO_FILTER_TILE", None)
+        e.update(env)
+        out = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", worker, out, str(conn)], env=e, capture_output=True, text=True, timeout=200)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = np.load(out)
+    for k in ("xt", "df", "hs"):
+        assert np.array_equal(res["streamed"][k].view(np.int64), res["direct"][k].view(np.int64)), k
+    assert np.abs(res["streamed"]["xt"]).max() > 0

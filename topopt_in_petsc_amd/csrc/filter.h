@@ -120,6 +120,73 @@ __global__ __launch_bounds__(8 * TYE * TZE) void k_conv_filter_wide(int ex, int 
     }
 }
 // ghosted input: mode 0: a, 1: a / b, 2: a * b
+// Radii beyond ElemConn 8 (round 4; the reference's absolute default rmin = 0.08 gives 10 at 128^3 and on C3, 20 on C5): the
+// (32 + 2C) x (T + 2C) x (T + 2C) neighbourhood of a block no longer fits the LDS, so the z direction is STREAMED: a block of
+// 32 x 16 x 4 elements (one wave per z layer, eight x-outputs per thread) stages one (32 + 2C) x (16 + 2C) plane at a time,
+// double buffered, and every wave whose layer lies within C of the plane adds that plane's (2C+1)^2 taps to its sums -- the
+// plane's row segment in registers, the weights of a (dk, dj) row wave-uniform (scalar loads).  An output sees its planes in
+// ascending z and inside a plane the taps in the order of k_conv_filter, the skipped out-of-domain terms as exact zeros: the
+// same bits as the direct form.  8 fma per LDS read: FP64 issue bounds it, (2C+1)^3 fma per element.
+template <int C>
+__global__ __launch_bounds__(256) void k_conv_filter_zring(int ex, int ey, int ez_own, int e0z, int ez_glob,
+                                                           const double *__restrict__ xg, const double *__restrict__ wtab,
+                                                           double *__restrict__ out, const double *__restrict__ d1,
+                                                           const double *__restrict__ d2) {
+    constexpr int TXE = 32, TYE = 16, TZE = 4, NX = 8, W1 = 2 * C + 1, SX = TXE + 2 * C, SY = TYE + 2 * C, NT = 256;
+    __shared__ double s_x[2][SY * SX];
+    const int x0 = blockIdx.x * TXE, y0 = blockIdx.y * TYE, z0 = blockIdx.z * TZE;
+    const int tz = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);  // z layer of this WAVE
+    const int tx = threadIdx.x & 3, ty = (threadIdx.x >> 2) & 15;
+    auto stage = [&](int buf, int kl) {  // plane with local z index kl (zeros outside the domain / the ghosted copy)
+        const bool zok = kl + e0z >= 0 && kl + e0z < ez_glob && kl < ez_own + C && kl >= -C;
+        for (int f = threadIdx.x; f < SY * SX; f += NT) {
+            const int sx = f % SX, sy = f / SX;
+            const int gi = x0 - C + sx, gj = y0 - C + sy;
+            const bool ok = zok && gi >= 0 && gi < ex && gj >= 0 && gj < ey;
+            s_x[buf][f] = ok ? xg[(long)gi + (long)ex * (gj + (long)ey * (kl + C))] : 0.0;
+        }
+    };
+    double acc[NX];
+#pragma unroll
+    for (int o = 0; o < NX; o++) acc[o] = 0.0;
+    const int p_lo = z0 - C, p_hi = z0 + TZE - 1 + C;
+    stage(0, p_lo);
+    __syncthreads();
+    for (int p = p_lo; p <= p_hi; p++) {
+        const int buf = (p - p_lo) & 1;
+        if (p < p_hi) stage(buf ^ 1, p + 1);   // (the other buffer: its last readers passed the barrier at the end of the previous trip)
+        const int dk = p - (z0 + tz) + C;      // wave-uniform
+        if (dk >= 0 && dk < W1) {
+            for (int dj = 0; dj < W1; dj++) {
+                const double *__restrict__ row = s_x[buf] + (ty + dj) * SX + NX * tx;
+                const double *__restrict__ w = wtab + (dk * W1 + dj) * W1;
+                double v[NX + 2 * C];
+#pragma unroll
+                for (int q = 0; q < NX + 2 * C; q++) v[q] = row[q];
+#pragma unroll
+                for (int di = 0; di < W1; di++) {
+                    const double wv = w[di];
+#pragma unroll
+                    for (int o = 0; o < NX; o++) acc[o] = fma(wv, v[o + di], acc[o]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int j = y0 + ty, k = z0 + tz;
+    if (j >= ey || k >= ez_own) return;
+#pragma unroll
+    for (int o = 0; o < NX; o++) {
+        const int i = x0 + NX * tx + o;
+        if (i >= ex) break;
+        const long t = (long)i + (long)ex * (j + (long)ey * k);
+        double s = acc[o];
+        if (d1) s = s / d1[t];
+        if (d2) s = s / d2[t];
+        out[t] = s;
+    }
+}
+
 __global__ __launch_bounds__(BLK) void k_fill_pw(double *__restrict__ y, const double *__restrict__ a,
                                                  const double *__restrict__ b, int mode, long n) {
     for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK)
@@ -247,6 +314,28 @@ static int filter_conv(tp_filter *f, double *out, const double *d1, const double
     else if (!no_tile && c == 8)
         TP_CONV_WIDE(8, 4, 2);
 #undef TP_CONV_WIDE
+#define TP_CONV_ZRING(CC)                                                                                                             \
+    TP_LAUNCH((k_conv_filter_zring<CC>), dim3((g->ex + 31) / 32, (g->ey + 15) / 16, (g->ez_own + 3) / 4), dim3(256), 0, g->stream, \
+              g->ex, g->ey, g->ez_own, g->rank * g->ez_own, g->ez_glob, f->xg, f->wtab, out, d1, d2)
+    else if (!no_tile && c == 9)
+        TP_CONV_ZRING(9);
+    else if (!no_tile && c == 10)
+        TP_CONV_ZRING(10);
+    else if (!no_tile && c == 11)
+        TP_CONV_ZRING(11);
+    else if (!no_tile && c == 12)
+        TP_CONV_ZRING(12);
+    else if (!no_tile && c == 13)
+        TP_CONV_ZRING(13);
+    else if (!no_tile && c == 14)
+        TP_CONV_ZRING(14);
+    else if (!no_tile && c == 15)
+        TP_CONV_ZRING(15);
+    else if (!no_tile && c == 16)
+        TP_CONV_ZRING(16);
+    else if (!no_tile && c == 20)
+        TP_CONV_ZRING(20);
+#undef TP_CONV_ZRING
     else
         TP_LAUNCH(k_conv_filter, dim3((int)((f->nel + BLK - 1) / BLK)), dim3(BLK), 0, g->stream, g->ex, g->ey,
                            g->ez_own, c, g->rank * g->ez_own, g->ez_glob, f->xg, f->wtab, out, d1, d2);
