@@ -120,7 +120,7 @@ __global__ __launch_bounds__(8 * TYE * TZE) void k_conv_filter_wide(int ex, int 
     }
 }
 // ghosted input: mode 0: a, 1: a / b, 2: a * b
-// Radii beyond ElemConn 8 (round 4; the reference's absolute default rmin = 0.08 gives 10 at 128^3 and on C3, 20 on C5): the
+// Radii beyond ElemConn 8, up to 24 (round 4; the reference's absolute default rmin = 0.08 gives 10 at 128^3 and on C3, 20 on C5): the
 // (32 + 2C) x (T + 2C) x (T + 2C) neighbourhood of a block no longer fits the LDS, so the z direction is STREAMED: a block of
 // 32 x 16 x 4 elements (one wave per z layer, eight x-outputs per thread) stages one (32 + 2C) x (16 + 2C) plane at a time,
 // double buffered, and every wave whose layer lies within C of the plane adds that plane's (2C+1)^2 taps to its sums -- the
@@ -333,8 +333,22 @@ static int filter_conv(tp_filter *f, double *out, const double *d1, const double
         TP_CONV_ZRING(15);
     else if (!no_tile && c == 16)
         TP_CONV_ZRING(16);
+    else if (!no_tile && c == 17)
+        TP_CONV_ZRING(17);
+    else if (!no_tile && c == 18)
+        TP_CONV_ZRING(18);
+    else if (!no_tile && c == 19)
+        TP_CONV_ZRING(19);
     else if (!no_tile && c == 20)
         TP_CONV_ZRING(20);
+    else if (!no_tile && c == 21)
+        TP_CONV_ZRING(21);
+    else if (!no_tile && c == 22)
+        TP_CONV_ZRING(22);
+    else if (!no_tile && c == 23)
+        TP_CONV_ZRING(23);
+    else if (!no_tile && c == 24)
+        TP_CONV_ZRING(24);
 #undef TP_CONV_ZRING
     else
         TP_LAUNCH(k_conv_filter, dim3((int)((f->nel + BLK - 1) / BLK)), dim3(BLK), 0, g->stream, g->ex, g->ey,
