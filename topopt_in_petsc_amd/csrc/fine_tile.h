@@ -74,16 +74,30 @@ __device__ __forceinline__ void fine_tile_run(const TileArgs &t, const NodeArgs 
         const int gi = min(max(bx - 1 + c / 3, 0), t.nx - 1), gj = min(max(by - 1 + r, 0), t.ny - 1);
         st_off[s] = 3u * (unsigned)(gi + t.nx * gj) + (unsigned)(c % 3);
     }
+    // EPI_APPLY_DOT: the product's input may be the CG direction in the making, staged = fma(beta, x, z) (NodeArgs::pz; one
+    // rank).  ONE loop for both uses (two instantiations of this loop are scheduled differently by the compiler, see load_prev):
+    // the plain product runs with z = x and beta = 0 -- fma(0, x, x) = x, the second load an L1 hit.
+    constexpr bool FUSEP = (EPI == EPI_APPLY_DOT);
+    const double *__restrict__ zin = (FUSEP && a.pz) ? a.pz : x;
+    const double pbeta = (FUSEP && a.pz && a.pscal) ? a.pscal[a.slot_new] / a.pscal[a.slot_old] : 0.0;
     // plane p of the input (zeroed outside the slab when it is written to the ring); always 4 loads from valid addresses
     auto load_plane = [&](int p, double v[4]) {
         const double *__restrict__ xp = x + 3 * plane * min(max(p, 0), t.nzl - 1);
 #pragma unroll
         for (int s = 0; s < 4; s++) v[s] = FT_ABL == 2 ? 1.0 + tid : xp[st_off[s]];
     };
-    auto store_plane = [&](int buf, int p, const double v[4]) {
+    auto load_plane_z = [&](int p, double v[4]) {
+        const double *__restrict__ zp = zin + 3 * plane * min(max(p, 0), t.nzl - 1);
+#pragma unroll
+        for (int s = 0; s < 4; s++) v[s] = zp[st_off[s]];
+    };
+    auto store_plane = [&](int buf, int p, const double v[4], const double vz[4]) {
         const bool inside = p >= 0 && p < t.nzl;  // uniform
 #pragma unroll
-        for (int s = 0; s < 4; s++) s_u[buf][min(tid + s * TILE * TILE, STG_N)] = inside ? v[s] : 0.0;  // [STG_N]: dump slot
+        for (int s = 0; s < 4; s++) {
+            const double val = FUSEP ? fma(pbeta, v[s], vz[s]) : v[s];
+            s_u[buf][min(tid + s * TILE * TILE, STG_N)] = inside ? val : 0.0;  // [STG_N]: dump slot
+        }
     };
     // MASKED tiles: mask bytes of the 17 x 17 staged nodes of a plane, kept in the padding of the plane's ring slot
     unsigned mk_off[2];
@@ -153,15 +167,20 @@ __device__ __forceinline__ void fine_tile_run(const TileArgs &t, const NodeArgs 
         for (int c = 0; c < 3; c++) dd[c] = FT_ABL == 6 ? 1.0 : pp[c];
     };
 
-    double pre[4];
+    double pre[4], prez[4] = {0, 0, 0, 0};
     unsigned pmk[2] = {0, 0};
     double Enext;
     {   // prologue: planes j = 0, 1 -> ring, plane j = 2 -> registers (written at the top of step 0); one round trip
-        double p0[4], p1[4];
+        double p0[4], p1[4], z0[4] = {0, 0, 0, 0}, z1[4] = {0, 0, 0, 0};
         unsigned m0[2] = {0, 0}, m1[2] = {0, 0};
         load_plane(kz0 - 1, p0);
         load_plane(kz0, p1);
         load_plane(kz0 + 1, pre);
+        if (FUSEP) {
+            load_plane_z(kz0 - 1, z0);
+            load_plane_z(kz0, z1);
+            load_plane_z(kz0 + 1, prez);
+        }
         if (MASKED) {
             load_mask(kz0 - 1, m0);
             load_mask(kz0, m1);
@@ -170,8 +189,8 @@ __device__ __forceinline__ void fine_tile_run(const TileArgs &t, const NodeArgs 
         Enext = load_E(kz0 - 1);
         if (HAS_B) load_epi(kz0 - 1);
         if (IS_CHEB) load_prev(kz0 - 1);
-        store_plane(0, kz0 - 1, p0);
-        store_plane(1, kz0, p1);
+        store_plane(0, kz0 - 1, p0, z0);
+        store_plane(1, kz0, p1, z1);
         if (MASKED) {
             store_mask(0, m0);
             store_mask(1, m1);
@@ -213,10 +232,11 @@ __device__ __forceinline__ void fine_tile_run(const TileArgs &t, const NodeArgs 
             return;
         }
         // ---- top of the step: retire last step's prefetch into the ring, request the next one
-        store_plane((s + 2) & 3, el + 2, pre);       // plane j = s + 2: read from step s + 1 on (behind this step's barrier)
+        store_plane((s + 2) & 3, el + 2, pre, prez);  // plane j = s + 2: read from step s + 1 on (behind this step's barrier)
         if (MASKED) store_mask((s + 2) & 3, pmk);
         const double Eraw = (el >= 0 && el < t.ezl) ? Enext : 0.0;
         load_plane(el + 3, pre);                     // plane j = s + 3: top plane of step s + 2
+        if (FUSEP) load_plane_z(el + 3, prez);
         if (MASKED) load_mask(el + 3, pmk);
         Enext = load_E(el + 1);
         // ---- element in the Walsh-Hadamard basis
@@ -277,10 +297,11 @@ __device__ __forceinline__ void fine_tile_run(const TileArgs &t, const NodeArgs 
                 if (MASKED) di[c] = ((mown >> c) & 1u) ? 1.0 : di[c];
             }
         }
-        double o[3];
+        double o[3], xo3[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const double xo = s_u[s & 3][o00 + c];  // own input value (the ring holds the true values)
+            xo3[c] = xo;
             double y = s0[c] + s_y[s & 1][yprev * 3 + c];
             if (MASKED) y = ((mown >> c) & 1u) ? xo : y;
             if (EPI == EPI_APPLY) {
@@ -317,6 +338,13 @@ __device__ __forceinline__ void fine_tile_run(const TileArgs &t, const NodeArgs 
         const d2_t o01 = {o[0], o[1]};
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, o01), rs, voff_out, 0, FT_STORE_AUX);
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, o[2]), rs, voff_out + 16u, 0, FT_STORE_AUX);
+        if (FUSEP) {  // the new CG direction of the thread's node (a descriptor of size 0 drops the stores of the plain product)
+            double *pn = a.pnew ? a.pnew : a.out;
+            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(pn + 3 * plane * max(el, 0), 0, (s >= 1 && a.pnew) ? (int)(24 * plane) : 0, 0x00020000);
+            const d2_t p01 = {xo3[0], xo3[1]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, p01), rp, voff_out, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, xo3[2]), rp, voff_out + 16u, 0, 0);
+        }
     };
     for (int s = 0; s < nsteps; s++) step(s);
     if (EPI == EPI_APPLY_DOT || EPI == EPI_CHEB_DOT) {

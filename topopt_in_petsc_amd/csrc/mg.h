@@ -322,7 +322,7 @@ struct MGSolver {
     bool replicate = false;
     bool allow_replicate = false;  // set by the owner when the coarsest level is a stored stencil (elasticity)
     tp_solver_opts opt;
-    double *cg_r = nullptr, *cg_p = nullptr, *cg_w = nullptr;
+    double *cg_r = nullptr, *cg_p = nullptr, *cg_w = nullptr, *cg_p2 = nullptr;
     bool ready = false;
     int last_nblocks = 0;  // workgroups (= reduction partials) of the last op<EPI_APPLY_DOT>
     static constexpr int NLANCZOS_COARSE = 40;
@@ -489,7 +489,7 @@ struct MGSolver {
             TP_HIP(hipMemsetAsync(R.S, 0, rb * 27 * DOF, grid->stream));
         }
         size_t nb = sizeof(double) * (size_t)lv[0].ndof();
-        for (double **p : {&cg_r, &cg_p, &cg_w}) {
+        for (double **p : {&cg_r, &cg_p, &cg_w, &cg_p2}) {
             TP_HIP(hipMalloc((void **)p, nb));
             TP_HIP(hipMemsetAsync(*p, 0, nb, grid->stream));
         }
@@ -502,7 +502,7 @@ struct MGSolver {
             Level<DOF> &L = lv[l];
             for (double *p : {L.b, L.x, L.x2, L.r, L.d, L.dinv, L.S, L.Kel}) (void)hipFree(p);
         }
-        for (double *p : {cg_r, cg_p, cg_w}) (void)hipFree(p);
+        for (double *p : {cg_r, cg_p, cg_w, cg_p2}) (void)hipFree(p);
         (void)hipFree(run_cnt);
         run_cnt = nullptr;
         (void)hipFree(run_ctl);
@@ -793,6 +793,14 @@ struct MGSolver {
     // Fine tile kernel: Chebyshev in its 3-term form  u+ = u + c1 (u - u-) + c2 D^-1 (b - A u); u- sits in the output
     // buffer (read and overwritten by the same thread), so no direction vector is streamed.
     static bool three_term(const Level<DOF> &L) { return DOF == 3 && L.kind == LV_MATFREE && L.use_tile; }
+    // does op<> serve this level with k_fine_tile (second generation)?  (the kernel that takes the fused p update)
+    static bool runs_fine_tile(const Level<DOF> &L) {
+        if (!(DOF == 3 && L.kind == LV_MATFREE && L.use_tile)) return false;
+        const int fine_v = fine_version();
+        const int t32 = ((L.g.nx + 30) / 31) * ((L.g.ny + 6) / 7);
+        const bool third = (fine_v >= 3 || (fine_v == 0 && t32 >= 160)) && 24.0 * L.g.nodes() < 2.0e9;
+        return !third && (fine_v >= 2 || fine_v == 0);
+    }
     int halo(int l, double *v) {
         if (lv[l].no_comm) return TP_OK;
         if (pend[l].ptr == v) return drain_halo(l);  // already under way: ordered behind it, nothing to exchange
@@ -1585,7 +1593,7 @@ struct MGSolver {
         hipStream_t s = grid->stream;
         const long off = L.own_off(), n = L.own_n();
         const int nb = grid_for(n, 2048);  // one resident round of workgroups; the reduction tail wants few arrivals
-        double *r = cg_r, *p = cg_p, *w = cg_w;
+        double *r = cg_r, *p = cg_p, *p_alt = cg_p2, *w = cg_w;
         {
             NodeArgs a{};
             a.x = x;
@@ -1619,16 +1627,35 @@ struct MGSolver {
                     TP_TRY(precond(r, &z));
                     TP_TRY(dot_to_slot(grid, r + off, z + off, n, rz_cur));
                 }
-                {
-                    const long pl = (long)DOF * L.g.plane();
-                    TP_TRY(planes_split(0, p, [&](int p0, int np) -> int {
-                        TP_LAUNCH(k_cg_update_p, dim3(grid_for(pl * np)), dim3(BLK), 0, s, p, z, grid->scal, rz_cur, rz_old,
-                                  its == 1 ? 1 : 0, pl * p0, pl * np);
-                        return TP_OK;
-                    }));
-                }
-                count_launch(grid, 24.0 * n, 2.0 * n);
-                {
+                // one rank, second-generation fine kernel: p = z + beta p inside the product's launch (fine_tile.h: the staged
+                // input is fma(beta, p_old, z), the owner of a node stores it to the other p buffer) -- one pass over p and z
+                // and one launch less per iteration; same values, bit for bit
+                const bool fuse_p = fuse_cg && !grid->has_comm && runs_fine_tile(L) && !sg_capturing;
+                if (fuse_p) {
+                    NodeArgs a{};
+                    a.x = its == 1 ? z : p;   // (first iteration: p = z -- beta 0 on z itself, whatever the buffer holds)
+                    a.pz = z;
+                    a.pnew = p_alt;
+                    a.pscal = its == 1 ? nullptr : grid->scal;
+                    a.slot_new = rz_cur;
+                    a.slot_old = rz_old;
+                    a.out = w;
+                    a.partials = grid->partials;
+                    a.ticket = tail_ticket(grid);
+                    a.red_out = grid->scal + S_PW;
+                    TP_TRY(op<EPI_APPLY_DOT>(0, a));
+                    TP_TRY(finish_tail<1>(grid, last_nblocks, S_PW));
+                    std::swap(p, p_alt);
+                } else {
+                    {
+                        const long pl = (long)DOF * L.g.plane();
+                        TP_TRY(planes_split(0, p, [&](int p0, int np) -> int {
+                            TP_LAUNCH(k_cg_update_p, dim3(grid_for(pl * np)), dim3(BLK), 0, s, p, z, grid->scal, rz_cur, rz_old,
+                                      its == 1 ? 1 : 0, pl * p0, pl * np);
+                            return TP_OK;
+                        }));
+                    }
+                    count_launch(grid, 24.0 * n, 2.0 * n);
                     NodeArgs a{};
                     a.x = p;
                     a.out = w;

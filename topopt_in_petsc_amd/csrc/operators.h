@@ -148,6 +148,13 @@ struct NodeArgs {
     double *partials;    // APPLY_DOT / CHEB_DOT: per-block partials of x . (A x) / b . x_out
     unsigned *ticket;    // ... arrival counter and result of the in-kernel reduction tail (common.h)
     double *red_out;
+    // APPLY_DOT of the fine tile kernel (fine_tile.h), one rank: the CG direction update fused into the product.  The staged
+    // input is fma(beta, x, pz) with beta = pscal[slot_new] / pscal[slot_old] (0 if pscal is NULL), and the owner of a node
+    // stores that value to pnew: p_new = z + beta p_old and w = A p_new, p . w in ONE launch.  pz = NULL: plain product.
+    const double *pz;
+    double *pnew;
+    const double *pscal;
+    int slot_new, slot_old;
 };
 
 template <int DOF, class Op, int EPI>
