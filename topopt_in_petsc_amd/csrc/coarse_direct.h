@@ -18,7 +18,8 @@
 //                 published (look-ahead: this is where the flops are, off the critical path); barrier; the others solve
 //                 their tile against the 32 x 32 factor (one wave, row per lane) and publish it; barrier.
 //   k_cd_diag_inv the 32 x 32 diagonal factors inverted (one wave per block);
-//   k_cd_invert   W = L^-1 by block forward substitution, one workgroup per block of 32 columns, no synchronisation
+//   k_cd_dc_*     (round 4, default) W = L^-1 and W^T by divide and conquer over block ranges: 7 levels of batched tile products;
+//   k_cd_invert   (TP_CD_INVERT_COLUMNS=1) W = L^-1 by block forward substitution, one workgroup per block of 32 columns, no synchronisation
 //                 between workgroups (columns are independent); the last KB row blocks of the workgroup's columns live
 //                 in an LDS ring; also writes W^T;
 //   k_cd_tri      y = W b,  x = W^T y: one wave per row.
@@ -422,6 +423,110 @@ __global__ __launch_bounds__(CD_T) void k_cd_invert(CdGeom c, const double *__re
             for (int e = 0; e < 4; e++) wp[e] = sO[r * CD_LD + c0 + e], tp[e] = sO[(c0 + e) * CD_LD + r];
         }
         __syncthreads();
+    }
+}
+
+// ---- W = L^-1 by divide and conquer over block ranges (round 4).  k_cd_invert walks a block column top to bottom: 69
+// dependent row steps of ~8 us for the first column, 0.56 ms, most of the chip idle.  For L = [[L11, 0], [L21, L22]]
+//     L^-1 = [[W11, 0], [-W22 L21 W11, W22]]:
+// the two halves are independent and the coupling is two products, so the work is log2(69) = 7 levels of batched 32 x 32
+// tile products, one wave per output tile, every level two launches -- T = L21 W11 (L21 is the band's corner: only the first
+// KB block rows of the lower half have entries), then W21 = -W22 T (only the KB block columns of W22 that meet T's rows).
+// W and W^T are both kept current (a tile of W^T is the A operand of the second product as it lies in memory).
+// Segment of level lv (1 ..): blocks [lo, lo + 2^lv), split at mid = lo + 2^(lv-1); nothing to do where mid >= nblk.
+// a 32 x 32 row-major tile (pitch in doubles) on its way to LDS as [m][c]: requested into registers a term ahead of its use
+__device__ inline void cd_req_rows(const double *src, long pitch, cd_u4 (&v)[8], int lane) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int idx = q * WAVE + lane, m = idx >> 4, c2 = (idx & 15) * 2;
+        v[q] = *reinterpret_cast<const cd_u4 *>(src + (long)m * pitch + c2);
+    }
+}
+__device__ inline void cd_put(double *lds, const cd_u4 (&v)[8], int lane) {  // (idx -> [m][c2]: the linear order of the tile)
+#pragma unroll
+    for (int q = 0; q < 8; q++) reinterpret_cast<cd_u4 *>(lds)[q * WAVE + lane] = v[q];
+}
+// level 0: the diagonal tiles, W_ii = Linv_i (stored transposed: element (r, m) at [m * 32 + r])
+__global__ __launch_bounds__(CD_T) void k_cd_dc_diag(CdGeom c, const double *__restrict__ Linv, double *__restrict__ W, double *__restrict__ Wt) {
+    const int i = blockIdx.x, t = threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int idx = t * 4 + e, r = idx >> 5, col = idx & 31;
+        const double v = Linv[(long)i * CD_BLK + col * CD_NB + r];  // W(r, col)
+        W[(long)(i * CD_NB + r) * c.np + i * CD_NB + col] = v;
+        Wt[(long)(i * CD_NB + col) * c.np + i * CD_NB + r] = v;
+    }
+}
+// T_(i, jc) = sum_j L_ij W_(j, jc),  i in [mid, mid + KB) (block row y of the corner), jc in [lo, mid) (x), segment z
+__global__ __launch_bounds__(WAVE) void k_cd_dc_t(CdGeom c, int lv, const double *__restrict__ Lb, const double *__restrict__ W, double *__restrict__ T) {
+    __shared__ double sA[CD_BLK], sB[CD_BLK];
+    const int half = 1 << (lv - 1), lo = (int)blockIdx.z << lv, mid = lo + half, hi = min(lo + 2 * half, c.nblk);
+    const int i = mid + (int)blockIdx.y, jc = lo + (int)blockIdx.x, lane = threadIdx.x;
+    if (mid >= c.nblk || i >= hi || i >= mid + c.KB) return;
+    double acc[16];
+#pragma unroll
+    for (int x = 0; x < 16; x++) acc[x] = 0.0;
+    cd_u4 pa[8], pb[8];
+    const int j0 = max(max(lo, i - c.KB), jc);  // (W_(j, jc) = 0 above the diagonal)
+    auto request = [&](int j) {
+        const cd_u4 *la = reinterpret_cast<const cd_u4 *>(Lb + cd_blk(c, i, j));  // [m][a] = L_ij(a, m): the A operand as stored
+#pragma unroll
+        for (int q = 0; q < 8; q++) pa[q] = la[q * WAVE + lane];
+        cd_req_rows(W + (long)j * CD_NB * c.np + jc * CD_NB, c.np, pb, lane);
+    };
+    request(j0);
+    for (int j = j0; j < mid; j++) {
+        cd_put(sA, pa, lane);
+        cd_put(sB, pb, lane);
+        if (j + 1 < mid) request(j + 1);
+        __syncthreads();
+        cd_gemm_nt(acc, sA, sB, lane);
+        __syncthreads();
+    }
+    const int tr = lane >> 3, tc = lane & 7;
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        double *dst = T + (long)(i * CD_NB + 4 * tr + x) * c.np + jc * CD_NB + 4 * tc;
+        *reinterpret_cast<cd_d2 *>(dst) = cd_d2{acc[x * 4 + 0], acc[x * 4 + 1]};
+        *reinterpret_cast<cd_d2 *>(dst + 2) = cd_d2{acc[x * 4 + 2], acc[x * 4 + 3]};
+    }
+}
+// W_(i, jc) = - sum_k W_(i, k) T_(k, jc),  i in [mid, hi) (y), jc in [lo, mid) (x), k in [mid, min(i, mid + KB - 1)], segment z
+__global__ __launch_bounds__(WAVE) void k_cd_dc_w(CdGeom c, int lv, const double *__restrict__ T, double *W, double *Wt) {
+    __shared__ double sA[CD_BLK], sB[CD_BLK];
+    const int half = 1 << (lv - 1), lo = (int)blockIdx.z << lv, mid = lo + half, hi = min(lo + 2 * half, c.nblk);
+    const int i = mid + (int)blockIdx.y, jc = lo + (int)blockIdx.x, lane = threadIdx.x;
+    if (mid >= c.nblk || i >= hi) return;
+    double acc[16];
+#pragma unroll
+    for (int x = 0; x < 16; x++) acc[x] = 0.0;
+    cd_u4 pa[8], pb[8];
+    const int k1 = min(i, min(mid + c.KB, hi) - 1);
+    auto request = [&](int k) {
+        cd_req_rows(Wt + (long)k * CD_NB * c.np + i * CD_NB, c.np, pa, lane);   // A = W_(i, k): [m][a] = the tile (k, i) of W^T, row-major
+        cd_req_rows(T + (long)k * CD_NB * c.np + jc * CD_NB, c.np, pb, lane);
+    };
+    request(mid);
+    for (int k = mid; k <= k1; k++) {
+        cd_put(sA, pa, lane);
+        cd_put(sB, pb, lane);
+        if (k + 1 <= k1) request(k + 1);
+        __syncthreads();
+        cd_gemm_nt(acc, sA, sB, lane);
+        __syncthreads();
+    }
+    const int tr = lane >> 3, tc = lane & 7;
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        double *dst = W + (long)(i * CD_NB + 4 * tr + x) * c.np + jc * CD_NB + 4 * tc;
+        *reinterpret_cast<cd_d2 *>(dst) = cd_d2{-acc[x * 4 + 0], -acc[x * 4 + 1]};
+        *reinterpret_cast<cd_d2 *>(dst + 2) = cd_d2{-acc[x * 4 + 2], -acc[x * 4 + 3]};
+    }
+#pragma unroll
+    for (int y = 0; y < 4; y++) {  // the transposed tile: row 4 tc + y of W^T's tile (jc, i), four consecutive entries 4 tr ..
+        double *dst = Wt + (long)(jc * CD_NB + 4 * tc + y) * c.np + i * CD_NB + 4 * tr;
+        *reinterpret_cast<cd_d2 *>(dst) = cd_d2{-acc[0 * 4 + y], -acc[1 * 4 + y]};
+        *reinterpret_cast<cd_d2 *>(dst + 2) = cd_d2{-acc[2 * 4 + y], -acc[3 * 4 + y]};
     }
 }
 

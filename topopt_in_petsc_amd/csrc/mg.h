@@ -935,7 +935,7 @@ struct MGSolver {
     // ---- the coarsest level solved exactly (coarse_direct.h): opt.coarse_direct, one rank or the replicated copy
     struct CoarseDirect {
         CdGeom g{};
-        double *Lb = nullptr, *Ld = nullptr, *Linv = nullptr, *W = nullptr, *Wt = nullptr, *y = nullptr;
+        double *Lb = nullptr, *Tm = nullptr, *Ld = nullptr, *Linv = nullptr, *W = nullptr, *Wt = nullptr, *y = nullptr;
         XcdRunCtrl *ctl = nullptr;
         int level = -1;       // the level the factor belongs to (nlv - 1, or nlv: the replicated copy)
         bool factored = false;
@@ -978,7 +978,7 @@ struct MGSolver {
         return opt.coarse_direct >= 2 || L.ndof() > (long)RUN_RPB * 8;
     }
     void coarse_direct_free() {
-        for (double **p : {&cd.Lb, &cd.Ld, &cd.Linv, &cd.W, &cd.Wt, &cd.y}) {
+        for (double **p : {&cd.Lb, &cd.Tm, &cd.Ld, &cd.Linv, &cd.W, &cd.Wt, &cd.y}) {
             (void)hipFree(*p);
             *p = nullptr;
         }
@@ -1003,6 +1003,7 @@ struct MGSolver {
             TP_HIP(hipMalloc((void **)&cd.Ld, sizeof(double) * (size_t)g.nblk * CD_NB * CD_NB));
             TP_HIP(hipMalloc((void **)&cd.Linv, sizeof(double) * (size_t)g.nblk * CD_NB * CD_NB));
             TP_HIP(hipMalloc((void **)&cd.W, sizeof(double) * (size_t)g.np * g.np));
+            TP_HIP(hipMalloc((void **)&cd.Tm, sizeof(double) * (size_t)g.np * g.np));
             TP_HIP(hipMalloc((void **)&cd.Wt, sizeof(double) * (size_t)g.np * g.np));
             TP_HIP(hipMalloc((void **)&cd.y, sizeof(double) * (size_t)g.np));
             TP_HIP(hipMalloc((void **)&cd.ctl, sizeof(XcdRunCtrl)));
@@ -1036,7 +1037,18 @@ struct MGSolver {
         }
         if (stages >= 3) {
             TP_LAUNCH(k_cd_diag_inv, dim3(g.nblk), dim3(WAVE), 0, s, cd.Ld, cd.Linv);
-            TP_LAUNCH(k_cd_invert, dim3(g.nblk), dim3(CD_T), 0, s, g, cd.Lb, cd.Linv, cd.W, cd.Wt);
+            static const bool dc = getenv("TP_CD_INVERT_COLUMNS") == nullptr;  // (1: round 3's block-column substitution)
+            if (dc) {
+                TP_LAUNCH(k_cd_dc_diag, dim3(g.nblk), dim3(CD_T), 0, s, g, cd.Linv, cd.W, cd.Wt);
+                for (int lv = 1; (1 << (lv - 1)) < g.nblk; lv++) {
+                    const int half = 1 << (lv - 1), nseg = (g.nblk + 2 * half - 1) / (2 * half);
+                    TP_LAUNCH(k_cd_dc_t, dim3(half, std::min(g.KB, half), nseg), dim3(WAVE), 0, s, g, lv, cd.Lb, cd.W, cd.Tm);
+                    TP_LAUNCH(k_cd_dc_w, dim3(half, half, nseg), dim3(WAVE), 0, s, g, lv, cd.Tm, cd.W, cd.Wt);
+                    grid->launches += 2;
+                }
+            } else {
+                TP_LAUNCH(k_cd_invert, dim3(g.nblk), dim3(CD_T), 0, s, g, cd.Lb, cd.Linv, cd.W, cd.Wt);
+            }
         }
         grid->launches += 4;
         const double nb2 = (double)g.np * g.np;
