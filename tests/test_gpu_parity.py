@@ -738,3 +738,40 @@ def test_conv_filter_streamed_bits(tmp_path, conn):
     for k in ("xt", "df", "hs"):
         assert np.array_equal(res["streamed"][k].view(np.int64), res["direct"][k].view(np.int64)), k
     assert np.abs(res["streamed"]["xt"]).max() > 0
+
+
+def test_exact_coarse_solve_inverse_forms_agree(tmp_path):
+    """W = L^-1 of the exact coarse solve by divide and conquer over block ranges (default) and by the block-column
+    substitution of round 3 (TP_CD_INVERT_COLUMNS=1; the environment is read once per process): the same solve -- iteration
+    counts equal, U to rounding."""
+    import subprocess, sys
+    worker = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import topopt_in_petsc_amd as tp\n"
+        "tp.load_library()\n"
+        "grid = tp.Grid(65, 65, 65, 1.0 / 64)\n"
+        "le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=4, nsmooth=2, ncoarse=20, rtol=1e-8, coarse_direct=1))\n"
+        "le.set_cycles([1, 3, 1])\n"
+        "le.SetUpLoadAndBC()\n"
+        "flt = tp.Filter(grid, 1, 2.56 / 64)\n"
+        "x = grid.synth_density(12345)\n"
+        "xt, xp = grid.elem_vec(), grid.elem_vec()\n"
+        "flt.FilterProject(x, xt, xp)\n"
+        "le.SolveState(xp, 1e-9, 1.0, 3.0, hist_cap=64)\n"
+        "assert le.coarse_direct_active() > 0\n"
+        "np.savez(sys.argv[1], U=le.U.cpu().numpy(), its=le.last_its, hist=le.last_hist)\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env in (("dc", {}), ("columns", {"TP_CD_INVERT_COLUMNS": "1"})):
+        e = dict(os.environ)
+        e.pop("TP_CD_INVERT_COLUMNS", None)
+        e.update(env)
+        out = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", worker, out], env=e, capture_output=True, text=True, timeout=200)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = np.load(out)
+    a, b = res["dc"], res["columns"]
+    assert int(a["its"]) == int(b["its"]) and int(a["its"]) < 60
+    assert np.abs(a["hist"] / b["hist"] - 1).max() <= 1e-8
+    assert np.abs(a["U"] - b["U"]).max() <= 1e-9 * np.abs(b["U"]).max()
