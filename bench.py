@@ -195,7 +195,7 @@ def cpu_baseline_worker(argv):
     the oracle's design iteration in a process of its own (all host cores, nothing of torch or the GPU library loaded)."""
     out, sample, rtol, fine_eig, ex, ey, ez, ndof, budget, nlv, nsmooth, ncoarse, cycles, direct = argv
     res = cpu_baseline(sample, float(rtol), int(fine_eig), (int(ex), int(ey), int(ez)), int(ndof), float(budget), int(nlv),
-                       int(nsmooth), int(ncoarse), "" if cycles == "-" else cycles, bool(int(direct)))
+                       int(nsmooth), int(ncoarse), "" if cycles == "-" else cycles, bool(int(direct)))   # (budget <= 0: the sample mesh only)
     with open(out + ".tmp", "w") as f:
         json.dump(res, f)
     os.replace(out + ".tmp", out)
@@ -383,10 +383,54 @@ def main():
         cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", cpu_json, a.cpu_sample, repr(a.rtol), str(a.fine_eig),
                str(ex0), str(ey0), str(ez0), str(3 * (ex0 + 1) * (ey0 + 1) * (ez0 + 1)), repr(a.cpu_budget), str(nlv), str(a.nsmooth),
                str(a.ncoarse), a.cycles or "-", str(direct_guess)]
+        # How many threads, and where?  All hardware threads unbound is NOT the fastest way to run these memory-bound loops
+        # (measured on the 2 x 64-core host of the GPU box, tools/r04_cpu_threads.sh: 256 threads 13.9 s, 128 bound to cores
+        # 7.4 s, 64 spread over the cores 5.1 s per design iteration).  The baseline is the BEST of a short list, chosen on
+        # the sample mesh in a process each (OpenMP placement is fixed at start-up); the list and the choice go into the line.
+        threads_tried = []
+        if "TP_CPU_THREADS" not in os.environ and env.get("OMP_NUM_THREADS") in (None, "1"):
+            try:
+                usable = len(os.sched_getaffinity(0))
+            except AttributeError:
+                usable = os.cpu_count() or 1
+            smt = 1
+            try:
+                sib = open("/sys/devices/system/cpu/cpu0/topology/thread_siblings_list").read().strip()
+                smt = max(1, len([t for part in sib.split(",") for t in (range(int(part.split("-")[0]), int(part.split("-")[-1]) + 1))]))
+            except (OSError, ValueError):
+                pass
+            phys = max(1, usable // smt)
+            cands = []
+            for t in (usable, phys, max(1, phys // 2), max(1, phys // 4)):
+                if t not in cands:
+                    cands.append(t)
+            probe_json = cpu_json + ".probe"
+            for t in cands:
+                pe = dict(env, TP_CPU_THREADS=str(t))
+                if t < usable:
+                    pe.update(OMP_PROC_BIND="spread", OMP_PLACES="cores")
+                pc = list(cmd)
+                pc[3], pc[11] = probe_json, "0"      # (out file; budget 0: the sample mesh only)
+                try:
+                    pp = subprocess.run(pc, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120, start_new_session=True, env=pe)
+                    if pp.returncode == 0 and os.path.exists(probe_json):
+                        threads_tried.append({"threads": t, "bound": t < usable, "sample_seconds": json.load(open(probe_json))["seconds"]})
+                except subprocess.TimeoutExpired:
+                    pass
+                finally:
+                    if os.path.exists(probe_json):
+                        os.unlink(probe_json)
+            if threads_tried:
+                best = min(threads_tried, key=lambda r: r["sample_seconds"])
+                env["TP_CPU_THREADS"] = str(best["threads"])
+                if best["bound"]:
+                    env.update(OMP_PROC_BIND="spread", OMP_PLACES="cores")
         try:
-            p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=a.cpu_budget * 1.5 + 120, start_new_session=True)
+            p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=a.cpu_budget * 1.5 + 120, start_new_session=True, env=env)
             if p.returncode == 0 and os.path.exists(cpu_json):
                 cpu_res = json.load(open(cpu_json))
+                cpu_res["threads_tried"] = threads_tried
+                cpu_res["omp_proc_bind"], cpu_res["omp_places"] = env.get("OMP_PROC_BIND"), env.get("OMP_PLACES")
             else:
                 cpu_err = "oracle process exited with %d: %s" % (p.returncode, p.stderr[-400:])
         except subprocess.TimeoutExpired:
