@@ -20,7 +20,7 @@ if ROOT not in sys.path:
 SUBPROCESS_CAP_S = float(os.environ.get("TP_TEST_SUBPROCESS_CAP", "240"))
 PER_TEST_LIMIT_S = int(os.environ.get("TP_TEST_LIMIT", "300"))
 
-_ORDER = ["test_gpu_parity", "test_golden", "test_gpu_configs", "test_gpu_fine_generations", "test_gpu_refksp", "test_mma",
+_ORDER = ["test_harness", "test_gpu_parity", "test_golden", "test_gpu_configs", "test_gpu_fine_generations", "test_gpu_refksp", "test_mma",
           "test_abi", "test_oracle_elements", "test_oracle_filter", "test_oracle_solver", "test_oracle_refksp", "test_mpiio",
           "test_cpp_host", "test_reference_on_shim", "test_multirank", "test_bench_line"]
 
