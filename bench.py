@@ -193,15 +193,28 @@ class Watchdog:
 def cpu_baseline_worker(argv):
     """`bench.py --cpu-baseline-worker out.json sample rtol fine_eig ex ey ez ndof budget nlv nsmooth ncoarse cycles direct`:
     the oracle's design iteration in a process of its own (all host cores, nothing of torch or the GPU library loaded)."""
-    out, sample, rtol, fine_eig, ex, ey, ez, ndof, budget, nlv, nsmooth, ncoarse, cycles, direct = argv
+    out, sample, rtol, fine_eig, ex, ey, ez, ndof, budget, nlv, nsmooth, ncoarse, cycles, direct = argv[:14]
+    extras_npz = argv[14] if len(argv) > 14 and argv[14] != "-" else None   # where the parity extras' vectors go (same-mesh run only)
     res = cpu_baseline(sample, float(rtol), int(fine_eig), (int(ex), int(ey), int(ez)), int(ndof), float(budget), int(nlv),
-                       int(nsmooth), int(ncoarse), "" if cycles == "-" else cycles, bool(int(direct)))   # (budget <= 0: the sample mesh only)
+                       int(nsmooth), int(ncoarse), "" if cycles == "-" else cycles, bool(int(direct)), extras_npz)   # (budget <= 0: the sample mesh only)
     with open(out + ".tmp", "w") as f:
         json.dump(res, f)
     os.replace(out + ".tmp", out)
 
 
-def cpu_step(orc, el, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, matfree_too, coarse_direct=False):
+# Bounds of the line's parity object (asserted: bench.py exits with code 4 on a breach; tests/test_bench_line.py asserts the same)
+PARITY_BOUNDS = {
+    "converged": 1e-10,           # rtol 1e-12: compliance and raw sensitivities (max error / max |dfdx|), GPU vs oracle: north_star's figure
+    "gx_abs": 1e-13,              # volume constraint
+    "vs_arbiter_factor": 3.0,     # rtol of the line (unconverged): |gpu - arbiter| <= factor * |oracle - arbiter| ...
+    "vs_arbiter_floor": 1e-10,    # ... or <= floor, for the compliance and for every ||r_k||
+}
+if os.environ.get("TP_BENCH_TEST_PARITY_BOUND"):   # tests/test_bench_line.py: an unreachable bound must end the run with code 4
+    PARITY_BOUNDS["converged"] = float(os.environ["TP_BENCH_TEST_PARITY_BOUND"])
+TIGHT_RTOL = 1e-12   # the converged parity step (SURVEY 8c pin 5: converged quantities are solver independent)
+
+
+def cpu_step(orc, el, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, matfree_too, coarse_direct=False, extras_npz=None):
     """One design iteration of the oracle (the reference's data path: assembled CSR + Galerkin SpGEMM) on `el` elements;
     with matfree_too the solve is repeated with the fine-level operator applied matrix-free (OpenMP gather).  Returns a
     dict: n_dof, its, seconds (assembled), seconds_mf (matrix-free or None), levels, and the numbers the GPU step is
@@ -238,10 +251,42 @@ def cpu_step(orc, el, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, matfree_too
         mg.fine_matfree(False)
     import numpy as np
     hist = np.asarray(hist, dtype=float)
-    return {"n_dof": 3 * nx * ny * nz, "its": int(its), "seconds": t3 - t0, "seconds_mf": t_mf, "levels": nlv,
-            "fx": float(fx), "gx": float(gx), "rel_residual": float(hist[min(its, len(hist) - 1)] / hist[0]) if len(hist) else None,
-            "hist": [float(v) for v in hist[:64]], "df_abs_sum": float(np.abs(df).sum()),
-            "phase_seconds": {"filter": tf - t0, "assemble": t1 - tf, "solve": t2 - t1, "sensitivities+filter": t3 - t2}}
+    res = {"n_dof": 3 * nx * ny * nz, "its": int(its), "seconds": t3 - t0, "seconds_mf": t_mf, "levels": nlv,
+           "fx": float(fx), "gx": float(gx), "rel_residual": float(hist[min(its, len(hist) - 1)] / hist[0]) if len(hist) else None,
+           "hist": [float(v) for v in hist[:64]], "df_abs_sum": float(np.abs(df).sum()),
+           "phase_seconds": {"filter": tf - t0, "assemble": t1 - tf, "solve": t2 - t1, "sensitivities+filter": t3 - t2}}
+    if extras_npz:
+        # ---- what the parity object of the line needs beyond the timed step (none of it is timed):
+        # (1) the CONVERGED step: the same system solved to rtol 1e-12 from the zero guess -- compliance and raw
+        #     sensitivities are then independent of the path the solver took;
+        # (2) the ARBITER (oracle/arbiter.py): the same algorithm on the same double-precision inputs in 80-bit
+        #     arithmetic -- history and compliance at the line's rtol and at convergence.
+        te0 = time.perf_counter()
+        Ut, its_t, hist_t = mg.solve(R * N, rtol=TIGHT_RTOL)
+        fx_t, _, df_t, _ = orc.compliance_sens(nx, ny, nz, KE, Ut, xp)
+        te1 = time.perf_counter()
+        E = orc.simp(xp)
+        del mg, U, Ut
+        from oracle import arbiter as arb
+        amg = arb.MG(nx, ny, nz, 3, nlv, nsmooth, ncoarse, fine_eig=fine_eig)
+        amg.set_coarse_direct(coarse_direct)
+        if cycles:
+            amg.set_cycles([int(v) for v in cycles.split(",")][: max(nlv - 1, 0)])
+        amg.assemble(KE, E, N)
+        Ua, its_a, hist_a = amg.solve(arb.f64(R * N), rtol=rtol)
+        fx_a = arb.compliance_sens(nx, ny, nz, KE, Ua, xp)[0]
+        Uat, its_at, _ = amg.solve(arb.f64(R * N), rtol=TIGHT_RTOL)
+        fx_at, _, df_at, _ = arb.compliance_sens(nx, ny, nz, KE, Uat, xp)
+        te2 = time.perf_counter()
+        np.savez(extras_npz, df_tight=np.asarray(df_t, dtype=np.float64), df_tight_arb=np.asarray(df_at, dtype=np.float64))
+        res["extras"] = {"tight_rtol": TIGHT_RTOL, "its_tight": int(its_t), "fx_tight": float(fx_t),
+                         "rel_residual_tight": float(hist_t[-1] / hist_t[0]),
+                         "arbiter": {"its": int(its_a), "fx": float(fx_a), "hist": [float(v) for v in hist_a[:64]],
+                                     "its_tight": int(its_at), "fx_tight": float(fx_at),
+                                     "arithmetic": "x87 long double (64-bit mantissa), every operation of the oracle's algorithm: "
+                                                   "oracle/topopt_oracle.c rebuilt with double -> long double"},
+                         "seconds": {"tight": te1 - te0, "arbiter": te2 - te1}, "npz": extras_npz}
+    return res
 
 
 def host_description():
@@ -261,7 +306,7 @@ def host_description():
     return {"cpu_model": model, "os_cpu_count": os.cpu_count(), "usable_cpus": usable}
 
 
-def cpu_baseline(sample, rtol, fine_eig, gpu_el, gpu_ndof, budget_s, nlv=4, nsmooth=4, ncoarse=30, cycles="", coarse_direct=False):
+def cpu_baseline(sample, rtol, fine_eig, gpu_el, gpu_ndof, budget_s, nlv=4, nsmooth=4, ncoarse=30, cycles="", coarse_direct=False, extras_npz=None):
     """the oracle timed on the host cores beside the GPU line -- on the SAME mesh when the budget
     (--cpu-budget seconds) allows it, judged from a first run on the bounded sample mesh; both data paths: assembled
     CSR (the reference's) and matrix-free fine level.  OpenMP over ALL usable host cores (sched_getaffinity; an
@@ -274,13 +319,14 @@ def cpu_baseline(sample, rtol, fine_eig, gpu_el, gpu_ndof, budget_s, nlv=4, nsmo
     from oracle import oracle as orc
     cores = int(os.environ["OMP_NUM_THREADS"])
     sel = tuple(int(v) for v in sample.split("x"))
-    r = cpu_step(orc, sel, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, True, coarse_direct)
+    same0 = tuple(gpu_el) == sel
+    r = cpu_step(orc, sel, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, True, coarse_direct, extras_npz if same0 else None)
     est = (r["seconds"] + r["seconds_mf"]) * gpu_ndof / r["n_dof"]  # work per DOF and iteration count are close to mesh independent
     what = "%dx%dx%d elements (%d DOF -- NOT the GPU line's %d-DOF mesh: the same mesh was estimated at %.0f s, over the --cpu-budget of %.0f s)" % (
         sel + (r["n_dof"], gpu_ndof, est, budget_s))
     same = tuple(gpu_el) == sel
     if est <= budget_s and not same:
-        r = cpu_step(orc, tuple(gpu_el), rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, True, coarse_direct)
+        r = cpu_step(orc, tuple(gpu_el), rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, True, coarse_direct, extras_npz)
         same = True
     if same:
         what = "%dx%dx%d elements (%d DOF: the GPU line's mesh)" % (tuple(gpu_el) + (r["n_dof"],))
@@ -289,6 +335,7 @@ def cpu_baseline(sample, rtol, fine_eig, gpu_el, gpu_ndof, budget_s, nlv=4, nsmo
             "omp_num_threads": cores, "host": host,
             "sample_n_dof": nd, "gpu_line_n_dof": gpu_ndof, "seconds": t, "phase_seconds": r["phase_seconds"],
             "fx": r["fx"], "gx": r["gx"], "cg_its": r["its"], "rel_residual": r["rel_residual"], "hist": r["hist"],
+            "extras": r.get("extras") if same else None,
             "matrix_free": {"value": nd / t_mf, "unit": "DOF-updates/s", "seconds": t_mf,
                             "what": "the same step with the fine-level operator of the solve applied from KE and the moduli (OpenMP gather over "
                                     "the 8 elements of a node) instead of the assembled CSR; Galerkin operators as before"},
@@ -382,7 +429,11 @@ def main():
         env.pop("OMP_NUM_THREADS", None) if env.get("OMP_NUM_THREADS") == "1" else None
         cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", cpu_json, a.cpu_sample, repr(a.rtol), str(a.fine_eig),
                str(ex0), str(ey0), str(ez0), str(3 * (ex0 + 1) * (ey0 + 1) * (ez0 + 1)), repr(a.cpu_budget), str(nlv), str(a.nsmooth),
-               str(a.ncoarse), a.cycles or "-", str(direct_guess)]
+               str(a.ncoarse), a.cycles or "-", str(direct_guess), "-"]
+        extras_npz = None
+        if not a.no_parity:
+            extras_npz = cpu_json + ".extras.npz"
+            cmd[-1] = extras_npz
         # How many threads, and where?  All hardware threads unbound is NOT the fastest way to run these memory-bound loops
         # (measured on the 2 x 64-core host of the GPU box, tools/r04_cpu_threads.sh: 256 threads 13.9 s, 128 bound to cores
         # 7.4 s, 64 spread over the cores 5.1 s per design iteration).  The baseline is the BEST of a short list, chosen on
@@ -410,7 +461,7 @@ def main():
                 if t < usable:
                     pe.update(OMP_PROC_BIND="spread", OMP_PLACES="cores")
                 pc = list(cmd)
-                pc[3], pc[11] = probe_json, "0"      # (out file; budget 0: the sample mesh only)
+                pc[3], pc[11], pc[-1] = probe_json, "0", "-"      # (out file; budget 0: the sample mesh only; no parity extras)
                 try:
                     pp = subprocess.run(pc, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120, start_new_session=True, env=pe)
                     if pp.returncode == 0 and os.path.exists(probe_json):
@@ -426,7 +477,7 @@ def main():
                 if best["bound"]:
                     env.update(OMP_PROC_BIND="spread", OMP_PLACES="cores")
         try:
-            p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=a.cpu_budget * 1.5 + 120, start_new_session=True, env=env)
+            p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=a.cpu_budget * 4 + 120, start_new_session=True, env=env)
             if p.returncode == 0 and os.path.exists(cpu_json):
                 cpu_res = json.load(open(cpu_json))
                 cpu_res["threads_tried"] = threads_tried
@@ -434,7 +485,7 @@ def main():
             else:
                 cpu_err = "oracle process exited with %d: %s" % (p.returncode, p.stderr[-400:])
         except subprocess.TimeoutExpired:
-            cpu_err = "oracle process exceeded %.0f s" % (a.cpu_budget * 1.5 + 120)
+            cpu_err = "oracle process exceeded %.0f s" % (a.cpu_budget * 4 + 120)
         finally:
             if os.path.exists(cpu_json):
                 os.unlink(cpu_json)
@@ -484,8 +535,8 @@ def main():
             self.xt, self.xp, self.df, self.dg = g.elem_vec(), g.elem_vec(), g.elem_vec(), g.elem_vec()
             self.info = {}
 
-        def solver(self, nlv_, ncoarse_, nsmooth_, direct, cycles):
-            le_ = tp.LinearElasticity(self.grid, tp.SolverOptions(nlvls=nlv_, rtol=a.rtol, fine_eig=a.fine_eig, ncoarse=ncoarse_,
+        def solver(self, nlv_, ncoarse_, nsmooth_, direct, cycles, rtol=None):
+            le_ = tp.LinearElasticity(self.grid, tp.SolverOptions(nlvls=nlv_, rtol=a.rtol if rtol is None else rtol, fine_eig=a.fine_eig, ncoarse=ncoarse_,
                                                                   nsmooth=nsmooth_, coarse_direct=int(direct), cheb_lo=a.cheb_lo, cheb_hi=a.cheb_hi))
             if cycles:
                 le_.set_cycles([int(v) for v in cycles.split(",")])
@@ -581,22 +632,90 @@ def main():
         info.clear()
         info.update(keep)
 
-    # ---- parity at the line's own mesh: the CPU baseline solved the same problem with the same cycle; one more GPU
-    # step (outside the timed region, residual history recorded) is compared with its numbers
+    # ---- parity at the line's own mesh (VERDICT r4 "next" 1).  The CPU baseline solved the same problem with the same cycle;
+    # its process also ran (a) the CONVERGED step (rtol 1e-12) and (b) the ARBITER -- the oracle's algorithm in 80-bit
+    # arithmetic on the same double-precision inputs (oracle/arbiter.py).  Two more GPU steps outside the timed region:
+    #   * at the line's rtol: iteration count, ||r_k|| and compliance against the oracle AND against the arbiter.  These
+    #     are unconverged quantities: two double-precision runs of the same algorithm that sum in different orders differ
+    #     by the rounding sensitivity of the CG trajectory (it grows with the mesh).  The bound is therefore stated against
+    #     the arbiter: the GPU may be at most PARITY_BOUNDS["vs_arbiter_factor"] times as far from it as the oracle is
+    #     (or within 1e-10 outright);
+    #   * at rtol 1e-12: compliance and raw sensitivities are solver independent -- north_star's 1e-10, as is.
+    # A breach makes the run exit with code 4 AFTER the line is out ("parity": {"ok": false, "breaches": [...]}).
     parity = None
     if cpu_res is not None and cpu_res.get("same_mesh") and not a.no_parity:
-        wd.phase("parity step", 300)
+        import numpy as np
+        wd.phase("parity steps", 600)
         keep = dict(info)
         step(hist_cap=64)
         hg = [float(v) for v in le.last_hist]
         ho = cpu_res["hist"]
+
+        def hist_err(h1, h2, k=None):
+            m = min(len(h1), len(h2)) if k is None else min(len(h1), len(h2), k)
+            return max(abs(h1[i] / h2[i] - 1.0) for i in range(m)) if m else None
+
         k = min(len(hg), len(ho), 10)
         parity = {"against": "cpu_baseline (oracle, same mesh, same cycle)", "its_gpu": le.last_its, "its_cpu": cpu_res["cg_its"],
                   "its_equal": le.last_its == cpu_res["cg_its"], "fx_gpu": info["fx"], "fx_cpu": cpu_res["fx"],
                   "fx_rel_err": abs(info["fx"] / cpu_res["fx"] - 1.0), "gx_abs_err": abs(info["gx"] - cpu_res["gx"]),
-                  "hist_max_rel_err_first10": max(abs(hg[i] / ho[i] - 1.0) for i in range(k)) if k else None,
-                  "hist_max_rel_err_all": max(abs(hg[i] / ho[i] - 1.0) for i in range(min(len(hg), len(ho)))) if k else None,
-                  "hist_compared": k}
+                  "hist_max_rel_err_first10": hist_err(hg, ho, 10), "hist_max_rel_err_all": hist_err(hg, ho),
+                  "hist_compared": k, "bounds": dict(PARITY_BOUNDS)}
+        breaches = []
+        if not parity["its_equal"]:
+            breaches.append("its_equal")
+        if parity["gx_abs_err"] > PARITY_BOUNDS["gx_abs"]:
+            breaches.append("gx_abs_err")
+        ext = cpu_res.get("extras")
+        if ext:
+            arbr = ext["arbiter"]
+            ha = arbr["hist"]
+            g_a = {"its_equal": le.last_its == arbr["its"], "fx_rel_err": abs(info["fx"] / arbr["fx"] - 1.0), "hist_max_rel_err": hist_err(hg, ha)}
+            o_a = {"its_equal": cpu_res["cg_its"] == arbr["its"], "fx_rel_err": abs(cpu_res["fx"] / arbr["fx"] - 1.0), "hist_max_rel_err": hist_err(ho, ha)}
+            fac, flo = PARITY_BOUNDS["vs_arbiter_factor"], PARITY_BOUNDS["vs_arbiter_floor"]
+            parity["arbiter"] = {"what": arbr["arithmetic"], "its": arbr["its"], "fx": arbr["fx"], "gpu_vs_arbiter": g_a, "oracle_vs_arbiter": o_a,
+                                 "closer_to_arbiter": {"fx": "gpu" if g_a["fx_rel_err"] <= o_a["fx_rel_err"] else "oracle",
+                                                       "hist": "gpu" if g_a["hist_max_rel_err"] <= o_a["hist_max_rel_err"] else "oracle"}}
+            if not g_a["its_equal"]:
+                breaches.append("arbiter.its_equal")
+            if g_a["fx_rel_err"] > max(flo, fac * o_a["fx_rel_err"]):
+                breaches.append("arbiter.fx_rel_err")
+            if g_a["hist_max_rel_err"] > max(flo, fac * o_a["hist_max_rel_err"]):
+                breaches.append("arbiter.hist_max_rel_err")
+            # the converged step on the GPU: same operator (the step above left it assembled for xp), zero guess, rtol 1e-12
+            le_t = case.solver(nlv, a.ncoarse, a.nsmooth, a.coarse == "direct", a.cycles, rtol=ext["tight_rtol"])
+            le_t.U.zero_()
+            df_t, dg_t = grid.elem_vec(), grid.elem_vec()
+            fx_t, _ = le_t.ComputeObjectiveConstraintsSensitivities(df_t, dg_t, case.xp, Emin, Emax, penal, volfrac)
+            z = np.load(ext["npz"])
+            dfg = df_t.cpu().numpy()
+            scale = float(np.abs(z["df_tight"]).max())
+            conv = {"rtol": ext["tight_rtol"], "its_gpu": le_t.last_its, "its_cpu": ext["its_tight"], "its_arbiter": arbr["its_tight"],
+                    "rel_residual_gpu": le_t.last_rnorm / le_t.last_bnorm, "fx_gpu": fx_t, "fx_cpu": ext["fx_tight"], "fx_arbiter": arbr["fx_tight"],
+                    "fx_rel_err": abs(fx_t / ext["fx_tight"] - 1.0), "fx_rel_err_vs_arbiter": abs(fx_t / arbr["fx_tight"] - 1.0),
+                    "fx_rel_err_oracle_vs_arbiter": abs(ext["fx_tight"] / arbr["fx_tight"] - 1.0),
+                    "dfdx_max_err_rel_to_max": float(np.abs(dfg - z["df_tight"]).max()) / scale,
+                    "dfdx_max_err_rel_to_max_vs_arbiter": float(np.abs(dfg - z["df_tight_arb"]).max()) / scale,
+                    "dfdx_max_err_rel_to_max_oracle_vs_arbiter": float(np.abs(z["df_tight"] - z["df_tight_arb"]).max()) / scale,
+                    "dfdx_l2_rel_err": float(np.linalg.norm(dfg - z["df_tight"]) / np.linalg.norm(z["df_tight"]))}
+            parity["converged"] = conv
+            for key in ("fx_rel_err", "dfdx_max_err_rel_to_max"):
+                if conv[key] > PARITY_BOUNDS["converged"]:
+                    breaches.append("converged." + key)
+            le_t.close()
+            le_t = df_t = dg_t = None
+            try:
+                os.unlink(ext["npz"])
+            except OSError:
+                pass
+            ext.pop("npz", None)
+            arbr.pop("hist", None)
+        else:   # (no extras: the oracle only -- the round-4 bounds of the unconverged quantities)
+            if parity["fx_rel_err"] > 1e-9:
+                breaches.append("fx_rel_err")
+            if (parity["hist_max_rel_err_first10"] or 0.0) > 1e-8:
+                breaches.append("hist_max_rel_err_first10")
+        parity["ok"], parity["breaches"] = not breaches, breaches
         info.clear()
         info.update(keep)
 
@@ -842,6 +961,9 @@ def main():
         finally:
             os._exit(0)
     case.close()
+    if parity is not None and not parity.get("ok", True):
+        print("bench.py: parity bounds broken: %s" % ", ".join(parity["breaches"]), file=sys.stderr)
+        sys.exit(4)
 
 
 if __name__ == "__main__":

@@ -12,14 +12,25 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-c_dp = C.POINTER(C.c_double)
+# Two flavours of the SAME source: "f64" (the oracle: double, the reference's arithmetic type) and "ld" (the arbiter,
+# oracle/arbiter.py: topopt_oracle.c with every `double` turned into x87 `long double` by the Makefile -- 64-bit
+# mantissa, unit round-off 5.4e-20 -- used to decide which of two double-precision results is the closer one).  The
+# arbiter module executes this file a second time with _FLAVOUR preset to "ld".
+_FLAVOUR = globals().get("_FLAVOUR", "f64")
+REAL = np.float64 if _FLAVOUR == "f64" else np.longdouble
+c_real = C.c_double if _FLAVOUR == "f64" else C.c_longdouble
+_SO = "liboracle.so" if _FLAVOUR == "f64" else "liboracle_ld.so"
+
+
+def _z(n):
+    return np.zeros(n, dtype=REAL)
 
 
 def build(force=False):
-    so = os.path.join(_HERE, "liboracle.so")
+    so = os.path.join(_HERE, _SO)
     srcs = [os.path.join(_HERE, f) for f in ("topopt_oracle.c", "mma_oracle.c", "Makefile")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, _SO], stdout=subprocess.DEVNULL)
     return so
 
 
@@ -31,12 +42,12 @@ def lib():
         os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         _LIB = C.CDLL(build())
         L = _LIB
-        L.orc_hash_u01.restype = C.c_double
+        L.orc_hash_u01.restype = c_real
         L.orc_hash_u01.argtypes = [C.c_uint64, C.c_uint64]
-        L.orc_elem_lambda_bound.restype = C.c_double
+        L.orc_elem_lambda_bound.restype = c_real
         L.orc_elem_lambda_bound.argtypes = [C.c_int, C.c_void_p]
         L.orc_mg_create.restype = C.c_void_p
-        L.orc_mg_create.argtypes = [C.c_int] * 7 + [C.c_double] * 2
+        L.orc_mg_create.argtypes = [C.c_int] * 7 + [c_real] * 2
         L.orc_mg_destroy.argtypes = [C.c_void_p]
         L.orc_mg_set_fine_eig.argtypes = [C.c_void_p, C.c_int]
         L.orc_mg_set_coarse_direct.argtypes = [C.c_void_p, C.c_int]
@@ -45,15 +56,15 @@ def lib():
         L.orc_mg_assemble.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_mg_precond.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_mg_solve.restype = C.c_int
-        L.orc_mg_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int,
+        L.orc_mg_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, c_real, c_real, c_real, C.c_int,
                                    C.c_int, C.c_void_p, C.c_void_p]
         L.orc_mg_level_size.restype = C.c_long
         L.orc_mg_level_size.argtypes = [C.c_void_p, C.c_int]
         L.orc_mg_level_nnz.restype = C.c_long
         L.orc_mg_level_nnz.argtypes = [C.c_void_p, C.c_int]
-        L.orc_mg_level_lambda.restype = C.c_double
+        L.orc_mg_level_lambda.restype = c_real
         L.orc_mg_level_lambda.argtypes = [C.c_void_p, C.c_int]
-        L.orc_mg_level_lambda_min.restype = C.c_double
+        L.orc_mg_level_lambda_min.restype = c_real
         L.orc_mg_level_lambda_min.argtypes = [C.c_void_p, C.c_int]
         for f in ("orc_mg_level_apply", "orc_mg_prolong", "orc_mg_restrict"):
             getattr(L, f).argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -61,72 +72,73 @@ def lib():
         L.orc_mg_level_csr.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_mg_smooth.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.orc_filter_create.restype = C.c_void_p
-        L.orc_filter_create.argtypes = [C.c_int] * 3 + [C.c_double] * 4
+        L.orc_filter_create.argtypes = [C.c_int] * 3 + [c_real] * 4
         L.orc_filter_destroy.argtypes = [C.c_void_p]
         L.orc_filter_conn.argtypes = [C.c_void_p]
         L.orc_filter_nnz.restype = C.c_long
         L.orc_filter_nnz.argtypes = [C.c_void_p]
         L.orc_filter_hs.argtypes = [C.c_void_p, C.c_void_p]
-        L.orc_filter_project.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double,
-                                         C.c_double]
+        L.orc_filter_project.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_real,
+                                         c_real]
         L.orc_filter_gradient.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                          C.c_double, C.c_double]
-        L.orc_mnd.restype = C.c_double
+                                          c_real, c_real]
+        L.orc_mnd.restype = c_real
         L.orc_mnd.argtypes = [C.c_long, C.c_void_p]
-        L.orc_heaviside.argtypes = [C.c_long, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
-        L.orc_heaviside_chain.argtypes = [C.c_long, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+        L.orc_heaviside.argtypes = [C.c_long, C.c_void_p, c_real, c_real, C.c_void_p]
+        L.orc_heaviside_chain.argtypes = [C.c_long, C.c_void_p, c_real, c_real, C.c_void_p]
         L.orc_pdef_create.restype = C.c_void_p
-        L.orc_pdef_create.argtypes = [C.c_int] * 3 + [C.c_double] * 4 + [C.c_int] * 3 + [C.c_double] * 2
+        L.orc_pdef_create.argtypes = [C.c_int] * 3 + [c_real] * 4 + [C.c_int] * 3 + [c_real] * 2
         L.orc_pdef_destroy.argtypes = [C.c_void_p]
         L.orc_pdef_kf.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_pdef_apply.restype = C.c_int
-        L.orc_pdef_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p]
-        L.orc_pdef_last_rnorm.restype = C.c_double
+        L.orc_pdef_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, c_real, C.c_int, C.c_void_p]
+        L.orc_pdef_last_rnorm.restype = c_real
         L.orc_pdef_last_rnorm.argtypes = [C.c_void_p]
         L.orc_pdef_clamp.restype = C.c_long
         L.orc_pdef_clamp.argtypes = [C.c_long, C.c_void_p]
-        L.orc_mma_create.restype = C.c_void_p
-        L.orc_mma_create.argtypes = [C.c_long, C.c_int, C.c_void_p]
-        L.orc_mma_destroy.argtypes = [C.c_void_p]
-        L.orc_mma_set_device_order.argtypes = [C.c_void_p, C.c_int]
-        L.orc_mma_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.orc_mma_outer_movelimit.argtypes = [C.c_long, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
-                                              C.c_void_p]
-        L.orc_mma_design_change.restype = C.c_double
-        L.orc_mma_design_change.argtypes = [C.c_long, C.c_void_p, C.c_void_p]
-        L.orc_mma_update.restype = C.c_int
-        L.orc_mma_update.argtypes = [C.c_void_p] * 7
-        L.orc_mma_kkt.argtypes = [C.c_void_p] * 9
-        L.orc_simp.argtypes = [C.c_long, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p]
-        L.orc_synth_density.argtypes = [C.c_int] * 5 + [C.c_double, C.c_uint64, C.c_void_p]
+        if _FLAVOUR == "f64":   # (the arbiter library holds topopt_oracle.c only)
+            L.orc_mma_create.restype = C.c_void_p
+            L.orc_mma_create.argtypes = [C.c_long, C.c_int, C.c_void_p]
+            L.orc_mma_destroy.argtypes = [C.c_void_p]
+            L.orc_mma_set_device_order.argtypes = [C.c_void_p, C.c_int]
+            L.orc_mma_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+            L.orc_mma_outer_movelimit.argtypes = [C.c_long, c_real, c_real, c_real, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p]
+            L.orc_mma_design_change.restype = c_real
+            L.orc_mma_design_change.argtypes = [C.c_long, C.c_void_p, C.c_void_p]
+            L.orc_mma_update.restype = C.c_int
+            L.orc_mma_update.argtypes = [C.c_void_p] * 7
+            L.orc_mma_kkt.argtypes = [C.c_void_p] * 9
+        L.orc_simp.argtypes = [C.c_long, C.c_void_p, c_real, c_real, c_real, C.c_void_p]
+        L.orc_synth_density.argtypes = [C.c_int] * 5 + [c_real, C.c_uint64, C.c_void_p]
         L.orc_matfree_apply.argtypes = [C.c_int] * 4 + [C.c_void_p] * 5
-        L.orc_cantilever_bc.argtypes = [C.c_int] * 3 + [C.c_double] * 3 + [C.c_void_p] * 2
-        L.orc_compliance_sens.argtypes = ([C.c_int] * 3 + [C.c_void_p] * 3 + [C.c_double] * 4 + [C.c_void_p] * 4)
-        L.orc_hex8_ke.argtypes = [C.c_void_p] * 3 + [C.c_double, C.c_int, C.c_void_p]
-        L.orc_hex8_ke_box.argtypes = [C.c_double] * 4 + [C.c_void_p]
-        L.orc_pde_kf.argtypes = [C.c_double] * 4 + [C.c_void_p] * 2
+        L.orc_cantilever_bc.argtypes = [C.c_int] * 3 + [c_real] * 3 + [C.c_void_p] * 2
+        L.orc_compliance_sens.argtypes = ([C.c_int] * 3 + [C.c_void_p] * 3 + [c_real] * 4 + [C.c_void_p] * 4)
+        L.orc_hex8_ke.argtypes = [C.c_void_p] * 3 + [c_real, C.c_int, C.c_void_p]
+        L.orc_hex8_ke_box.argtypes = [c_real] * 4 + [C.c_void_p]
+        L.orc_pde_kf.argtypes = [c_real] * 4 + [C.c_void_p] * 2
     return _LIB
 
 
 def _p(a):
     if a is None:
         return None
-    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
-    return a.ctypes.data
+    assert a.dtype == REAL and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)   # (keeps a reference to `a`: a converted temporary lives until the call returns)
 
 
 def f64(a):
-    return np.ascontiguousarray(a, dtype=np.float64)
+    return np.ascontiguousarray(a, dtype=REAL)
 
 
 def hex8_ke_box(dx, dy, dz, nu=0.3):
-    ke = np.zeros(576)
+    ke = _z(576)
     lib().orc_hex8_ke_box(dx, dy, dz, nu, _p(ke))
     return ke
 
 
 def pde_kf(dx, dy, dz, R):
-    kf, tf = np.zeros(64), np.zeros(8)
+    kf, tf = _z(64), _z(8)
     lib().orc_pde_kf(dx, dy, dz, R, _p(kf), _p(tf))
     return kf, tf
 
@@ -139,7 +151,7 @@ def elem_lambda_bound(ke):
 
 def cantilever_bc(nx, ny, nz, h):
     n = 3 * nx * ny * nz
-    N, R = np.zeros(n), np.zeros(n)
+    N, R = _z(n), _z(n)
     hx, hy, hz = (h, h, h) if np.isscalar(h) else h
     lib().orc_cantilever_bc(nx, ny, nz, hx, hy, hz, _p(N), _p(R))
     return N, R
@@ -153,7 +165,7 @@ def simp(x, Emin=1e-9, Emax=1.0, penal=3.0):
 
 
 def synth_density(ex, ey, ez, h, seed=12345, e0z=0, ez_glob=None):
-    x = np.zeros(ex * ey * ez)
+    x = _z(ex * ey * ez)
     lib().orc_synth_density(ex, ey, ez, e0z, ez_glob or ez, h, seed, _p(x))
     return x
 
@@ -167,8 +179,8 @@ def matfree_apply(nx, ny, nz, dof, KE, E, N, u):
 
 def compliance_sens(nx, ny, nz, KE, U, xPhys, Emin=1e-9, Emax=1.0, penal=3.0, volfrac=0.12):
     nel = (nx - 1) * (ny - 1) * (nz - 1)
-    fx, gx = C.c_double(), C.c_double()
-    dfdx, dgdx = np.zeros(nel), np.zeros(nel)
+    fx, gx = c_real(), c_real()
+    dfdx, dgdx = _z(nel), _z(nel)
     lib().orc_compliance_sens(nx, ny, nz, _p(f64(KE)), _p(f64(U)), _p(f64(xPhys)), Emin, Emax, penal, volfrac,
                               C.addressof(fx), C.addressof(gx), _p(dfdx), _p(dgdx))
     return fx.value, gx.value, dfdx, dgdx
@@ -229,26 +241,26 @@ class MG:
         return y
 
     def diag(self, l):
-        d = np.zeros(self.size(l))
+        d = _z(self.size(l))
         self.L.orc_mg_level_diag(self.h, l, _p(d))
         return d
 
     def csr(self, l):
         import scipy.sparse as sp
         n, nnz = self.size(l), self.L.orc_mg_level_nnz(self.h, l)
-        rp, ci, v = np.zeros(n + 1, dtype=np.int64), np.zeros(nnz, dtype=np.int32), np.zeros(nnz)
+        rp, ci, v = np.zeros(n + 1, dtype=np.int64), np.zeros(nnz, dtype=np.int32), _z(nnz)
         self.L.orc_mg_level_csr(self.h, l, rp.ctypes.data, ci.ctypes.data, _p(v))
         return sp.csr_matrix((v, ci, rp), shape=(n, n))
 
     def prolong(self, l, xc):
         xc = f64(xc)
-        xf = np.zeros(self.size(l))
+        xf = _z(self.size(l))
         self.L.orc_mg_prolong(self.h, l, _p(xc), _p(xf))
         return xf
 
     def restrict(self, l, rf):
         rf = f64(rf)
-        rc = np.zeros(self.size(l + 1))
+        rc = _z(self.size(l + 1))
         self.L.orc_mg_restrict(self.h, l, _p(rf), _p(rc))
         return rc
 
@@ -266,8 +278,8 @@ class MG:
     def solve(self, b, x0=None, rtol=1e-5, atol=1e-50, dtol=1e5, maxit=200, use_pc=True):
         b = f64(b)
         x = np.zeros_like(b) if x0 is None else f64(x0).copy()
-        hist = np.zeros(maxit + 1)
-        rn = C.c_double()
+        hist = _z(maxit + 1)
+        rn = c_real()
         its = self.L.orc_mg_solve(self.h, _p(b), _p(x), rtol, atol, dtol, maxit, int(use_pc), _p(hist),
                                   C.addressof(rn))
         return x, its, hist[: max(its, 0) + 1].copy()
@@ -294,7 +306,7 @@ class Filter:
         return self.L.orc_filter_nnz(self.h)
 
     def hs(self):
-        a = np.zeros(self.nel)
+        a = _z(self.nel)
         self.L.orc_filter_hs(self.h, _p(a))
         return a
 
@@ -326,8 +338,8 @@ class PDEFilter:
 
     def apply(self, x, rtol=1e-8, maxit=60):
         x = f64(x)
-        out = np.zeros(self.nel)
-        hist = np.zeros(maxit + 1)
+        out = _z(self.nel)
+        hist = _z(maxit + 1)
         its = self.L.orc_pdef_apply(self.h, _p(x), _p(out), rtol, maxit, _p(hist))
         return out, its, hist[: max(its, 0) + 1].copy()
 
@@ -372,14 +384,14 @@ class MMA:
         self.L.orc_mma_set_device_order(self.h, nb)
 
     def SetOuterMovelimit(self, Xmin, Xmax, movlim, x):
-        xmin, xmax = np.zeros(self.n), np.zeros(self.n)
+        xmin, xmax = _z(self.n), _z(self.n)
         self.L.orc_mma_outer_movelimit(self.n, Xmin, Xmax, movlim, _p(f64(x)), _p(xmin), _p(xmax))
         return xmin, xmax
 
     def Update(self, x, dfdx, gx, dgdx, xmin, xmax):
         """returns the new design"""
         xn = f64(x).copy()
-        g = f64(np.asarray(gx, dtype=np.float64))
+        g = f64(np.asarray(gx, dtype=REAL))
         dg = f64(np.concatenate([f64(d) for d in dgdx]))
         self.last_inner = self.L.orc_mma_update(self.h, _p(xn), _p(f64(dfdx)), _p(g), _p(dg), _p(f64(xmin)),
                                                 _p(f64(xmax)))
@@ -389,14 +401,14 @@ class MMA:
         return self.L.orc_mma_design_change(self.n, _p(f64(x)), _p(xold))
 
     def state(self):
-        lam = np.zeros(self.m)
-        z = C.c_double()
+        lam = _z(self.m)
+        z = c_real()
         self.L.orc_mma_get_state(self.h, _p(lam), C.addressof(z), None, None)
         return lam, z.value
 
     def kkt(self, x, dfdx, fx, dgdx, xmin, xmax):
-        n2, ni = C.c_double(), C.c_double()
+        n2, ni = c_real(), c_real()
         dg = f64(np.concatenate([f64(d) for d in dgdx]))
-        self.L.orc_mma_kkt(self.h, _p(f64(x)), _p(f64(dfdx)), _p(f64(np.asarray(fx, dtype=np.float64))), _p(dg),
+        self.L.orc_mma_kkt(self.h, _p(f64(x)), _p(f64(dfdx)), _p(f64(np.asarray(fx, dtype=REAL))), _p(dg),
                            _p(f64(xmin)), _p(f64(xmax)), C.addressof(n2), C.addressof(ni))
         return n2.value, ni.value

@@ -232,12 +232,43 @@ def gpu_randbc_mode(rank, world):
     print("rank %d gpu_randbc OK its=%d" % (rank, its), flush=True)
 
 
+def gpu_giveup_mode(rank, world):
+    """a one-XCD kernel that gives up on ONE rank (TP_TEST_FORCE_GIVEUP="<1 solve | 2 set-up>:<rank>", set by the
+    test) -- every rank must take the recovery branch (hierarchy rebuilt without the one-XCD forms, solve repeated): the run
+    ends on all ranks, the replicated coarse solve is the same kind everywhere afterwards, the result is the oracle's."""
+    import topopt_in_petsc_amd as tp
+    torch.cuda.set_device(0)
+    ex, ey, ez, nlv, nsm, nco = 32, 16, 64, 4, 2, 20   # coarsest level 5 x 3 x 9 nodes = 405 rows: replicated, solved exactly (coarse_direct = 2)
+    nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
+    grid = tp.Grid(nx, ny, nz, h, rank=rank, nranks=world)
+    le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=nlv, rtol=1e-9, max_it=300, nsmooth=nsm, ncoarse=nco, coarse_direct=2))
+    le.SetUpLoadAndBC()
+    x = grid.synth_density()
+    df, dg = grid.elem_vec(), grid.elem_vec()
+    fx, gx = le.ComputeObjectiveConstraintsSensitivities(df, dg, x, 1e-9, 1.0, 3.0, 0.12, hist_cap=400)
+    direct_after = int(le.coarse_direct_active())
+    t = torch.tensor([direct_after], dtype=torch.int64)
+    gathered = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t)
+    assert all(int(v) == 0 for v in gathered), "after the recovery the exact coarse solve must be off on EVERY rank: %s" % gathered
+    xo = orc.synth_density(ex, ey, ez, h)
+    KE = orc.hex8_ke_box(h, h, h, 0.3)
+    N, R = orc.cantilever_bc(nx, ny, nz, h)
+    mg = orc.MG(nx, ny, nz, 3, nlv, nsm, nco)
+    mg.assemble(KE, orc.simp(xo), N)
+    U, its, hist = mg.solve(R * N, rtol=1e-9, maxit=300)
+    fo = orc.compliance_sens(nx, ny, nz, KE, U, xo)[0]
+    assert le.last_its == its, (le.last_its, its)
+    assert abs(fx / fo - 1) <= 1e-8
+    print("rank %d gpu_giveup OK its=%d" % (rank, its), flush=True)
+
+
 if __name__ == "__main__":
     mode = sys.argv[1]
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     try:
-        {"cpu": cpu_mode, "gpu": gpu_mode, "gpu_randbc": gpu_randbc_mode}[mode](rank, world)
+        {"cpu": cpu_mode, "gpu": gpu_mode, "gpu_randbc": gpu_randbc_mode, "gpu_giveup": gpu_giveup_mode}[mode](rank, world)
     finally:
         dist.destroy_process_group()

@@ -41,8 +41,36 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert cb["cores"] == cb["omp_num_threads"] and cb["host"]["usable_cpus"] >= 1 and cb["same_mesh"] is True
     # the CPU baseline solved the line's own mesh with the line's own cycle: the GPU step is checked against it in the line
     p = d["parity"]
+    assert p["ok"] is True and p["breaches"] == [], p
     assert p["its_equal"] and p["its_gpu"] == cb["cg_its"], p
-    assert p["fx_rel_err"] <= 1e-9 and p["hist_max_rel_err_first10"] <= 1e-8 and p["gx_abs_err"] <= 1e-13, p
+    assert p["gx_abs_err"] <= 1e-13, p
+    # the bounds bench.py itself enforces (exit code 4 on a breach): unconverged quantities against the ARBITER (the oracle's
+    # algorithm in 80-bit arithmetic) -- the GPU at most 3 x as far from it as the double-precision oracle is, or within 1e-10 --
+    assert p["bounds"] == {"converged": 1e-10, "gx_abs": 1e-13, "vs_arbiter_factor": 3.0, "vs_arbiter_floor": 1e-10}
+    ga, oa = p["arbiter"]["gpu_vs_arbiter"], p["arbiter"]["oracle_vs_arbiter"]
+    assert ga["its_equal"] and oa["its_equal"]
+    for key in ("fx_rel_err", "hist_max_rel_err"):
+        assert ga[key] <= max(1e-10, 3.0 * oa[key]), (key, ga, oa)
+    # ... and on this small mesh everything is far inside north_star's 1e-10 outright
+    assert p["fx_rel_err"] <= 1e-10 and p["hist_max_rel_err_all"] <= 1e-10 and ga["hist_max_rel_err"] <= 1e-10, p
+    # the converged step (rtol 1e-12): compliance and raw sensitivities are solver independent -- 1e-10, as north_star states it
+    c = p["converged"]
+    assert c["rtol"] == 1e-12 and c["rel_residual_gpu"] <= 1e-12 and c["its_gpu"] == c["its_cpu"] == c["its_arbiter"], c
+    assert c["fx_rel_err"] <= 1e-10 and c["dfdx_max_err_rel_to_max"] <= 1e-10 and c["fx_rel_err_vs_arbiter"] <= 1e-10, c
+
+
+@pytest.mark.gpu
+def test_bench_exits_nonzero_when_a_parity_bound_breaks():
+    """a bound of the parity object broken (here: made unreachable through TP_BENCH_TEST_PARITY_BOUND) -> the line is still
+    printed, with "ok": false and the breach named, and the exit code is 4"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--steps", "1", "--warmup", "1", "--no-cube256",
+                        "--no-stated-cycle", "--cpu-sample", "16x8x8"], capture_output=True, text=True, timeout=150, cwd=ROOT,
+                       env=dict(os.environ, TP_BENCH_TEST_PARITY_BOUND="1e-30"))
+    assert r.returncode == 4, (r.returncode, r.stderr[-2000:])
+    lines = [ln for ln in r.stdout.split("\n") if ln.strip()]
+    assert len(lines) == 1
+    p = json.loads(lines[0])["parity"]
+    assert p["ok"] is False and "converged.fx_rel_err" in p["breaches"] and "parity bounds broken" in r.stderr
 
 
 def _check_two_rank_line(r, scaling):

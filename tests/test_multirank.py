@@ -20,8 +20,8 @@ def _free_port():
     return p
 
 
-def _launch(mode, nproc=2, timeout=600, extra=()):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _launch(mode, nproc=2, timeout=600, extra=(), env_extra=None):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "mp_gloo_worker.py"), mode] + [str(v) for v in extra]
@@ -122,3 +122,12 @@ def test_three_ranks_one_gpu_odd_rank_count():
     """an odd number of slabs (the middle rank has neighbours on both sides, the replicated coarsest level is gathered
     from three unequal parts: rank 0 owns one node plane more)"""
     _launch("gpu", nproc=3, extra=(16, 8, 24, 3))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("force", ["1:1", "2:0"])
+def test_give_up_on_one_rank_is_handled_by_all(force):
+    """the one-XCD give-up is detected per rank, the recovery is collective.  One rank of two takes the
+    forced give-up branch (1: found by the solve, on rank 1; 2: found by the set-up, on rank 0): both ranks rebuild and
+    finish, with the launch-per-step coarse solve on both, and the oracle's iteration count and compliance."""
+    _launch("gpu_giveup", nproc=2, timeout=300, env_extra={"TP_TEST_FORCE_GIVEUP": force})

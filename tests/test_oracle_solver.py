@@ -419,3 +419,35 @@ def test_exact_coarse_solve_equals_sparse_lu(orc, nlv, cycles):
     mg2.assemble(KE, E, N)
     U_c, its_c, hist_c = mg2.solve(b, rtol=1e-6, maxit=300)
     assert its_d <= its_c + 1 and np.abs(U_d - U_c).max() <= 1e-4 * np.abs(U_c).max()
+
+
+def test_arbiter_is_the_same_algorithm_in_extended_precision():
+    """oracle/arbiter.py: topopt_oracle.c rebuilt with `long double` for `double`.  Same inputs -> the same iteration count, a
+    residual history and a compliance that agree with the double-precision oracle to rounding (1e-11 on a 10^4-DOF mesh), and
+    arrays that really are 80-bit: its residuals keep falling below what double precision can represent relative to ||b||."""
+    import numpy as np
+    from oracle import arbiter as arb
+    from oracle import oracle as orc
+    assert arb.REAL is np.longdouble and orc.REAL is np.float64 and np.finfo(np.longdouble).nmant >= 63
+    ex, ey, ez = 16, 8, 8
+    nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
+    x = orc.synth_density(ex, ey, ez, h)
+    KE = orc.hex8_ke_box(h, h, h, 0.3)
+    N, R = orc.cantilever_bc(nx, ny, nz, h)
+    xp = orc.Filter(nx, ny, nz, h, 2.56 * h).project(1, x)[1]
+    E = orc.simp(xp)
+    out = {}
+    for name, m in (("f64", orc), ("ld", arb)):
+        mg = m.MG(nx, ny, nz, 3, 3, 2, 30)
+        mg.assemble(KE, E, N)
+        U, its, hist = mg.solve(m.f64(R * N), rtol=1e-5)
+        Ut, its_t, hist_t = mg.solve(m.f64(R * N), rtol=1e-14, maxit=60)
+        fx, gx, df, _ = m.compliance_sens(nx, ny, nz, KE, U, xp)
+        out[name] = (its, np.asarray(hist, dtype=np.longdouble), fx, np.asarray(df, dtype=np.float64), hist_t, U.dtype)
+    assert out["ld"][5] == np.longdouble and out["f64"][5] == np.float64
+    assert out["f64"][0] == out["ld"][0]
+    assert np.abs(out["f64"][1] / out["ld"][1] - 1).max() < 1e-11
+    assert abs(out["f64"][2] / out["ld"][2] - 1) < 1e-12
+    assert np.abs(out["f64"][3] - out["ld"][3]).max() <= 1e-12 * np.abs(out["ld"][3]).max()
+    # extended precision: the true residual b - A x reaches 1e-14 ||b|| in the arbiter
+    assert float(out["ld"][4][-1] / out["ld"][4][0]) <= 1e-14

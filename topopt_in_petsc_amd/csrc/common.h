@@ -34,6 +34,14 @@ inline bool &tp_xcd_disabled() {
     static bool off = false;
     return off;
 }
+// test switch TP_TEST_FORCE_GIVEUP = "<mode>" or "<mode>:<rank>": does it ask rank `rank` for recovery branch `mode`?
+// rank < 0: does it ask ANY rank (the collective agreement must then be reached by all of them)
+inline bool tp_test_force_giveup(int mode, int rank) {
+    const char *e = getenv("TP_TEST_FORCE_GIVEUP");
+    if (!e || atoi(e) != mode) return false;
+    const char *c = strchr(e, ':');
+    return rank < 0 || !c || atoi(c + 1) == rank;
+}
 inline bool tp_debug_sync() {
     static const bool v = getenv("TP_DEBUG_SYNC") != nullptr && atoi(getenv("TP_DEBUG_SYNC")) != 0;
     return v;

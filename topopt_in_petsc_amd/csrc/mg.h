@@ -58,6 +58,10 @@ enum { S_BB = 0, S_RR = 1, S_PW = 2, S_RZ0 = 3, S_RZ1 = 4, S_TMP = 8 };
 // x += alpha p, r -= alpha w, ||r||^2 (also to pinned host memory if out_host); z1 != NULL: also the first Chebyshev step of
 // the NEXT V-cycle's pre-smoothing from its zero guess, z1 = dinv r / theta (k_cheb_first: the same product in the same
 // order) -- one pass over r less and one launch less per Krylov iteration
+// NT: x, p and w pass through with non-temporal loads / stores -- none of the three is read again before ~10 other vectors
+// of the same size have gone by, while r and z1 are the next kernel's input: the hint keeps the streamed ones from
+// displacing them (TP_CG_NT, measured in DESIGN 4.4)
+template <bool NT>
 __global__ __launch_bounds__(BLK) void k_cg_update_xr(double *__restrict__ x, double *__restrict__ r,
                                                       const double *__restrict__ p, const double *__restrict__ w,
                                                       const double *__restrict__ scal, int slot_rz, long off, long n,
@@ -68,8 +72,14 @@ __global__ __launch_bounds__(BLK) void k_cg_update_xr(double *__restrict__ x, do
     double s = 0.0;
     for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
         const long q = off + i;
-        x[q] = fma(alpha, p[q], x[q]);
-        const double rn = fma(-alpha, w[q], r[q]);
+        double rn;
+        if constexpr (NT) {
+            __builtin_nontemporal_store(fma(alpha, __builtin_nontemporal_load(p + q), __builtin_nontemporal_load(x + q)), x + q);
+            rn = fma(-alpha, __builtin_nontemporal_load(w + q), r[q]);
+        } else {
+            x[q] = fma(alpha, p[q], x[q]);
+            rn = fma(-alpha, w[q], r[q]);
+        }
         r[q] = rn;
         s = fma(rn, rn, s);
         if (z1) z1[q] = dinv[q] * rn * inv_theta;
@@ -1685,9 +1695,15 @@ struct MGSolver {
                                         !sg_capturing;
                 double th0 = 1.0, de0 = 1.0;
                 if (fuse_first) cheb_window(0, &th0, &de0);
-                TP_LAUNCH(k_cg_update_xr, dim3(nb), dim3(BLK), 0, s, x, r, p, w, grid->scal, rz_cur, off, n,
-                                   grid->partials, tail_ticket(grid), grid->scal + S_RR, direct_rr ? grid->h_scal_dev : nullptr,
-                                   fuse_first ? L.x : nullptr, L.dinv, 1.0 / th0);
+                static const bool cg_nt = getenv("TP_CG_NT") != nullptr && atoi(getenv("TP_CG_NT")) != 0;
+                if (cg_nt)
+                    TP_LAUNCH(k_cg_update_xr<true>, dim3(nb), dim3(BLK), 0, s, x, r, p, w, grid->scal, rz_cur, off, n,
+                              grid->partials, tail_ticket(grid), grid->scal + S_RR, direct_rr ? grid->h_scal_dev : nullptr,
+                              fuse_first ? L.x : nullptr, L.dinv, 1.0 / th0);
+                else
+                    TP_LAUNCH(k_cg_update_xr<false>, dim3(nb), dim3(BLK), 0, s, x, r, p, w, grid->scal, rz_cur, off, n,
+                              grid->partials, tail_ticket(grid), grid->scal + S_RR, direct_rr ? grid->h_scal_dev : nullptr,
+                              fuse_first ? L.x : nullptr, L.dinv, 1.0 / th0);
                 count_launch(grid, (fuse_first ? 64.0 : 48.0) * n, 6.0 * n);
                 TP_TRY(finish_tail<1>(grid, nb, S_RR));
                 double rr;

@@ -830,6 +830,22 @@ extern "C" int tp_elasticity_cantilever(tp_elasticity *e, double *N, double *RHS
 }
 
 static int elasticity_setup_from_E(tp_elasticity *e);
+// Did ANY rank raise `mine`?  The give-up of a one-XCD kernel is seen by the rank it happened on only, but what follows
+// from it -- the hierarchy rebuilt, the solve repeated, the one-XCD forms off from then on -- contains halo exchanges and
+// reductions and changes the (replicated) coarse solve: every rank of the grid must take the same branch.
+// One rank: no communication.  Collective over the grid's communicator otherwise: callers reach it on every rank or on none.
+static int agree_any(tp_grid *g, bool mine, bool *any) {
+    *any = mine;
+    if (!g->has_comm) return TP_OK;
+    double v = mine ? 1.0 : 0.0;
+    TP_HIP(hipMemcpyAsync(g->comm.red, &v, sizeof(double), hipMemcpyHostToDevice, g->stream));
+    TP_HIP(hipStreamSynchronize(g->stream));  // (v lives on this stack frame)
+    if (g->comm.allreduce_sum(g->comm.user, 1)) return TP_ERR_COMM;
+    TP_HIP(hipMemcpyAsync(&v, g->comm.red, sizeof(double), hipMemcpyDeviceToHost, g->stream));
+    TP_HIP(hipStreamSynchronize(g->stream));
+    *any = v > 0.0;
+    return TP_OK;
+}
 // A one-XCD persistent kernel gave up (common.h: tp_xcd_disabled): switch those forms off for the rest of the process,
 // hand their control blocks back zeroed and build the hierarchy again from the moduli with the launch-per-step forms.
 static int redo_without_xcd(tp_elasticity *e, const char *where) {
@@ -863,8 +879,14 @@ extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, dou
         // the solve: tp_elasticity_solve)
         bool bad = false;
         for (int l = 0; l <= mg.nlv; l++) bad = bad || mg.lv[l].lam != mg.lv[l].lam || mg.lv[l].lam_min != mg.lv[l].lam_min;
-        static const bool force = getenv("TP_TEST_FORCE_GIVEUP") != nullptr && atoi(getenv("TP_TEST_FORCE_GIVEUP")) == 2;
-        if ((bad && mg.xcd_gaveup()) || (force && !tp_xcd_disabled())) rc = redo_without_xcd(e, "the set-up");
+        // TP_TEST_FORCE_GIVEUP=2 / =1 (tests/test_gpu_parity.py::test_one_xcd_kernels_give_up_path): take the recovery branch of
+        // the set-up / of the solve once without a real give-up; "=2:R" / "=1:R" on rank R only (the multi-rank agreement)
+        static const bool force = tp_test_force_giveup(2, g->rank);
+        // several ranks: the decision is taken together, and only where a one-XCD Lanczos run exists on this grid at all
+        // (lan_ctl is allocated by the first one; same configuration on every rank) -- the default set-up pays nothing
+        bool mine = (bad && mg.xcd_gaveup()) || (force && !tp_xcd_disabled()), any = mine;
+        if (g->has_comm && (mg.lan_ctl != nullptr || tp_test_force_giveup(2, -1))) rc = agree_any(g, mine, &any);
+        if (rc == TP_OK && any) rc = redo_without_xcd(e, "the set-up");
     }
     if (rc != TP_OK) {  // join what the failed set-up left running on the side streams
         if (e->aux_stream) (void)hipStreamSynchronize(e->aux_stream);
@@ -1036,11 +1058,19 @@ extern "C" int tp_elasticity_solve(tp_elasticity *e, const double *RHS, double *
     int rc = e->mg.solve(e->d_bN, U, its, rnorm, bnorm, hist, hist_cap);
     // A solve that "diverged" because a one-XCD kernel gave up (its result is poisoned with NaN on purpose): build the
     // hierarchy again without those kernels and solve once more, from a zero guess (U holds NaN by now).
-    static const bool force = getenv("TP_TEST_FORCE_GIVEUP") != nullptr && atoi(getenv("TP_TEST_FORCE_GIVEUP")) == 1;
-    if (!tp_xcd_disabled() && ((rc == TP_ERR_DIVERGED && e->mg.gaveup_seen) || (force && rc == TP_OK))) {
-        TP_TRY(redo_without_xcd(e, "the solve"));
-        TP_HIP(hipMemsetAsync(U, 0, sizeof(double) * (size_t)n, g->stream));
-        rc = e->mg.solve(e->d_bN, U, its, rnorm, bnorm, hist, hist_cap);
+    static const bool force = tp_test_force_giveup(1, g->rank), force_any = tp_test_force_giveup(1, -1);
+    // Several ranks: a divergence is seen by all of them (the residual norm is a sum over ranks), the give-up flag behind it
+    // by one -- they agree on it before any of them rebuilds (agree_any is reached on every rank: rc and the test switch are
+    // the same everywhere).  The reported iteration count and history are those of the SECOND solve.
+    if (!tp_xcd_disabled() && (rc == TP_ERR_DIVERGED || (force_any && rc == TP_OK))) {
+        bool any = false;
+        TP_TRY(agree_any(g, (rc == TP_ERR_DIVERGED && e->mg.gaveup_seen) || (force && rc == TP_OK), &any));
+        if (any) {
+            TP_TRY(redo_without_xcd(e, "the solve"));
+            TP_HIP(hipMemsetAsync(U, 0, sizeof(double) * (size_t)n, g->stream));
+            rc = e->mg.solve(e->d_bN, U, its, rnorm, bnorm, hist, hist_cap);
+            fprintf(stderr, "topopt_amd: the solve was repeated from a zero guess: iteration count and residual history are the second solve's\n");
+        }
     }
     return rc;
 }
