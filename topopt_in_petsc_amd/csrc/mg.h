@@ -428,11 +428,19 @@ struct MGSolver {
                         }
                     }
             }
+            // Round 5: the factorisation is NOT joined here.  Nothing on the host depends on it (no Ritz values to read), and
+            // the solve does not touch the factor before the first V-cycle reaches the coarsest level -- ~0.35 ms of
+            // fine-level and level-1..3 work into the solve.  The solver's stream waits for the chain's event right before the
+            // first triangular product (coarse_direct_apply); until then the factorisation (ONE workgroup column on one
+            // XCD, 1.4 ms) runs beside the head of the solve.  TP_NO_DEFER_FACTOR=1: joined here, as in round 4.
+            static const bool no_defer = getenv("TP_NO_DEFER_FACTOR") != nullptr;
+            const bool defer = direct && !no_defer && lan_done[nlv - 1] && rc == TP_OK;
             for (int l = first_level; l < nlv; l++)
-                if (lan_done[l]) (void)hipStreamWaitEvent(main, lan_done[l], 0);
+                if (lan_done[l] && !(defer && l == nlv - 1)) (void)hipStreamWaitEvent(main, lan_done[l], 0);
             for (int l = first_level; l < nlv; l++)
-                if (lan_stream[l]) (void)hipStreamSynchronize(lan_stream[l]);
+                if (lan_stream[l] && !(defer && l == nlv - 1)) (void)hipStreamSynchronize(lan_stream[l]);
             if (side_stream) (void)hipStreamSynchronize(side_stream);
+            cd_pending = defer;
             if (rc) return rc;
             for (int l = first_level; l < nlv; l++) {
                 if (direct && l == nlv - 1)
@@ -988,6 +996,8 @@ struct MGSolver {
         return opt.coarse_direct >= 2 || L.ndof() > (long)RUN_RPB * 8;
     }
     void coarse_direct_free() {
+        if (cd_pending && lan_stream[nlv - 1]) (void)hipStreamSynchronize(lan_stream[nlv - 1]);
+        cd_pending = false;
         for (double **p : {&cd.Lb, &cd.Tm, &cd.Ld, &cd.Linv, &cd.W, &cd.Wt, &cd.y}) {
             (void)hipFree(*p);
             *p = nullptr;
@@ -1067,9 +1077,20 @@ struct MGSolver {
         cd.factored = true;
         return TP_OK;
     }
+    // the factorisation enqueued by this assembly is still running on its side stream: the solver's stream waits for it
+    // (device-side; the host does not block)
+    bool cd_pending = false;
+    int join_pending_factor() {
+        if (cd_pending) {
+            cd_pending = false;
+            TP_HIP(hipStreamWaitEvent(grid->stream, lan_done[nlv - 1], 0));
+        }
+        return TP_OK;
+    }
     // x = A^-1 b on level cd.level
     int coarse_direct_apply(int l, const double *b) {
         Level<DOF> &L = lv[l];
+        TP_TRY(join_pending_factor());
         const int rows_per = CD_T / WAVE, nb = (cd.g.n + rows_per - 1) / rows_per;
         TP_LAUNCH(k_cd_tri<false>, dim3(nb), dim3(CD_T), 0, grid->stream, cd.g, cd.W, b, cd.y);
         TP_LAUNCH(k_cd_tri<true>, dim3(nb), dim3(CD_T), 0, grid->stream, cd.g, cd.Wt, cd.y, L.x);
@@ -1084,6 +1105,7 @@ struct MGSolver {
     bool gaveup_seen = false;               // the last diverged solve found a give-up flag raised by a one-XCD kernel
     // did a one-XCD kernel (Chebyshev run, Lanczos run, factorisation) give up?  Blocking read of the sticky flags.
     bool xcd_gaveup() {
+        (void)join_pending_factor();
         unsigned long long f[3] = {0ull, 0ull, 0ull};
         XcdRunCtrl *blocks[3] = {run_ctl, lan_ctl, cd.ctl};
         for (int q = 0; q < 3; q++)
@@ -1103,6 +1125,7 @@ struct MGSolver {
             if (lan_stream[i]) (void)hipStreamSynchronize(lan_stream[i]);
         if (side_stream) (void)hipStreamSynchronize(side_stream);
         cd_early = false;
+        cd_pending = false;
     }
     unsigned long long run_base = 0;        // arrivals of all runs so far
     long coarse_runs = 0;

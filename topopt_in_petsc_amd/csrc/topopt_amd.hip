@@ -873,6 +873,7 @@ extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, dou
     // a sticky give-up flag)
     mg.cd_early = false;
     e->assembled = false;
+    TP_TRY(mg.join_pending_factor());  // a factorisation no solve has waited for must not be overtaken by the new coarse stencil
     int rc = elasticity_setup_from_E(e);
     if (rc == TP_OK && mg.opt.ksp_mode == 0 && !tp_xcd_disabled()) {
         // a Lanczos run on one XCD that gave up poisons its Ritz values with NaN (a factorisation that gave up shows in
