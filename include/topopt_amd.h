@@ -206,6 +206,10 @@ int tp_elasticity_create(tp_elasticity **e, tp_grid *g, const tp_solver_opts *o)
 int tp_elasticity_create_ke(tp_elasticity **e, tp_grid *g, const tp_solver_opts *o, const double *ke_host_576);
 int tp_elasticity_destroy(tp_elasticity *e);
 int tp_elasticity_get_ke(const tp_elasticity *e, double *ke_host_576);
+/* The element matrix the fine-level kernels apply (KE with the rounding residue of its box symmetry removed: it differs
+ * from KE by less than one unit in the last place of KE's largest entry), as a double-double pair hi + lo (host arrays of
+ * 576).  Test/diagnostic entry point: the parity checks hand it to the extended-precision arbiter (oracle/arbiter.py). */
+int tp_elasticity_get_ke_effective(const tp_elasticity *e, double *hi_host_576, double *lo_host_576);
 int tp_elasticity_cantilever(tp_elasticity *e, double *N, double *RHS);      /* :143-171 */
 int tp_elasticity_set_bc(tp_elasticity *e, const double *N);                /* N [dev] */
 /* AssembleStiffnessMatrix + KSPSetOperators/KSPSetUp (:487-549, :198-200):

@@ -1,0 +1,65 @@
+"""TEST INFRASTRUCTURE (like oracle.py): the element matrix the HIP fine-level kernels APPLY, restated on the host.
+
+The tile kernels (csrc/fine_tile.h, fine_u4.h, matfree_tile.h) evaluate KE u_e in the Walsh-Hadamard basis of the element's
+8 nodes: KE_eff = T D T, where D is the block-diagonal part of T KE T / 64 with its symmetric pairs averaged
+(csrc/matfree_tile.h: make_sym_ke).  For an exactly box-symmetric KE that is KE itself; the reference's KE
+(LinearElasticity.cc:841-998, a 2x2x2 Gauss sum in double) is box symmetric only to rounding -- its rows sum to 7e-16 max|KE|
+instead of 0 -- so KE_eff differs from it by 5e-16 max|KE| entrywise, about as much as KE itself differs from the same formula
+evaluated in 80-bit arithmetic (5.6e-16).  The compliance of a 128^3 cantilever is sensitive to exactly this kind of
+perturbation at the 1e-10 level (the element translation mode has amplitude ~1e3 against strains ~1e-2: any O(eps) change of
+how KE answers a rigid translation shows in the 10th digit), so the parity of the HIP path is checked in two steps
+(bench.py `parity`, tests/): (1) against the ARBITER run on this KE_eff -- the kernels must reproduce the exact-arithmetic
+trajectory of the operator they apply; (2) KE_eff against KE entrywise.
+
+The library exports the same matrix (tp_elasticity_get_ke_effective -> api.LinearElasticity.KE_effective, a double-double
+pair); tests/test_gpu_parity.py::test_effective_element_matrix checks the two bit for bit."""
+import numpy as np
+
+M2A = [0, 1, 3, 2, 4, 5, 7, 6]
+
+
+def symke_nz(q, r, s):
+    if q in (0, 7):
+        return True
+    if q in (1, 2, 4):
+        b = {1: 0, 2: 1, 4: 2}[q]
+        return r != b and s != b
+    m = {6: 0, 5: 1, 3: 2}[q]
+    return (r != m and s != m) or (r == m and s == m)
+
+
+def ke_effective(KE):
+    KE = np.asarray(KE, dtype=np.float64).reshape(24, 24)
+    pc = lambda v: bin(v).count("1")
+    # D = T KE T / 64 in double, term by term as the library's make_sym_ke accumulates it
+    D = np.zeros((24, 24))
+    for p in range(8):
+        for r in range(3):
+            for p2 in range(8):
+                for s in range(3):
+                    acc = 0.0
+                    for m in range(8):
+                        for m2 in range(8):
+                            v = KE[3 * M2A[m] + r, 3 * M2A[m2] + s]
+                            acc += -v if (pc(p & m) + pc(p2 & m2)) & 1 else v
+                    D[p * 3 + r, p2 * 3 + s] = acc / 64.0
+    Dp = np.zeros((24, 24), dtype=np.longdouble)
+    for q in range(8):
+        for r in range(3):
+            for s in range(r, 3):
+                if not symke_nz(q, r, s):
+                    continue
+                i, j = (q ^ (1 << r)) * 3 + r, (q ^ (1 << s)) * 3 + s
+                Dp[i, j] = Dp[j, i] = np.longdouble(0.5 * (D[i, j] + D[j, i]))
+    out = np.zeros((24, 24), dtype=np.longdouble)
+    for m in range(8):
+        for r in range(3):
+            for m2 in range(8):
+                for s in range(3):
+                    acc = np.longdouble(0)
+                    for p in range(8):
+                        for p2 in range(8):
+                            v = Dp[p * 3 + r, p2 * 3 + s]
+                            acc += -v if (pc(p & m) + pc(p2 & m2)) & 1 else v
+                    out[3 * M2A[m] + r, 3 * M2A[m2] + s] = acc
+    return out.reshape(-1)

@@ -775,3 +775,37 @@ def test_exact_coarse_solve_inverse_forms_agree(tmp_path):
     assert int(a["its"]) == int(b["its"]) and int(a["its"]) < 60
     assert np.abs(a["hist"] / b["hist"] - 1).max() <= 1e-8
     assert np.abs(a["U"] - b["U"]).max() <= 1e-9 * np.abs(b["U"]).max()
+
+
+@pytest.mark.gpu
+def test_effective_element_matrix(tp, orc):
+    """The element matrix the fine-level kernels apply (KE in its Walsh-Hadamard block form, csrc/matfree_tile.h) as the
+    library exports it (double-double) == the host restatement the parity checks hand to the arbiter (oracle/ke_effective.py),
+    bit for bit; it is KE to 1e-15 max|KE| entrywise, exactly translation invariant (KE itself: 7e-16), and the kernels really
+    apply it: on a free mesh of unit moduli the HIP operator agrees with the operator assembled from it to rounding."""
+    from oracle.ke_effective import ke_effective
+    ex, ey, ez = 8, 6, 4
+    nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / 128
+    grid = tp.Grid(nx, ny, nz, h)
+    le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=1))
+    KE = le.KE
+    kf = le.KE_effective()
+    assert kf.dtype == np.longdouble and np.array_equal(kf, ke_effective(KE))
+    mx = np.abs(KE).max()
+    assert 0 < float(np.abs(kf - KE).max()) <= 1e-15 * mx
+    assert float(np.abs(kf.reshape(24, 24).sum(1)).max()) == 0.0 and np.abs(KE.reshape(24, 24).sum(1)).max() > 1e-16 * mx
+    # the operator: no Dirichlet dofs, E = 1 everywhere
+    le.SetBC(torch.ones(3 * nx * ny * nz, dtype=torch.float64, device="cuda"), torch.zeros(3 * nx * ny * nz, dtype=torch.float64, device="cuda"))
+    le.AssembleStiffnessMatrix(grid.elem_vec(1.0), 0.0, 1.0, 3.0)
+    rng = np.random.default_rng(5)
+    u = rng.standard_normal(3 * nx * ny * nz)
+    y = le.MatMult(torch.from_numpy(u).cuda()).cpu().numpy()
+    yo = orc.matfree_apply(nx, ny, nz, 3, np.asarray(kf, dtype=np.float64), None, None, u)
+    assert np.abs(y - yo).max() <= 1e-13 * np.abs(yo).max()
+    # ... and a rigid translation is annihilated EXACTLY by it (every term of the sum cancels in the transformed basis),
+    # where the reference's KE leaves its rounding residue
+    t = np.tile(np.array([1000.0, -2000.0, 500.0]), nx * ny * nz)
+    yt = le.MatMult(torch.from_numpy(t).cuda()).cpu().numpy()
+    assert np.abs(yt).max() == 0.0
+    assert np.abs(orc.matfree_apply(nx, ny, nz, 3, KE, None, None, t)).max() > 0.0
+    grid.close()

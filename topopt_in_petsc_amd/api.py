@@ -270,6 +270,14 @@ class LinearElasticity:
         _chk(self.L.tp_elasticity_get_ke(self.handle, ke.ctypes.data), "tp_elasticity_get_ke")
         return ke
 
+    def KE_effective(self):
+        """the element matrix the fine-level kernels apply, as a numpy.longdouble array of 576 (hi + lo of the library's
+        double-double pair): KE with the rounding residue of its box symmetry removed, < 1 ulp of max|KE| away from KE"""
+        import numpy as np
+        hi, lo = np.zeros(576), np.zeros(576)
+        _chk(self.L.tp_elasticity_get_ke_effective(self.handle, hi.ctypes.data, lo.ctypes.data), "tp_elasticity_get_ke_effective")
+        return hi.astype(np.longdouble) + lo.astype(np.longdouble)
+
     def SetUpLoadAndBC(self):
         """cantilever load case, LinearElasticity.cc:143-171"""
         _chk(self.L.tp_elasticity_cantilever(self.handle, _ptr(self.N), _ptr(self.RHS)), "tp_elasticity_cantilever")

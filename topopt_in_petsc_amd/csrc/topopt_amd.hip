@@ -660,6 +660,48 @@ extern "C" int tp_elasticity_get_ke(const tp_elasticity *e, double *ke) {
     std::memcpy(ke, e->KE, sizeof(e->KE));
     return TP_OK;
 }
+// The element matrix the fine-level tile kernels APPLY: KE_eff = T D T with D = the packed block-diagonal part of
+// T KE T / 64 (matfree_tile.h: make_sym_ke; T = 8 x 8 Walsh-Hadamard over the element's nodes, per component).  It differs
+// from KE by what the packing drops or averages -- entries of relative size ~1e-17 that are rounding residue of KE itself
+// (an exactly box-symmetric KE has exact zeros there) -- so |KE_eff - KE| is below one unit in the last place of the
+// largest entry.  Returned as a double-double pair (hi + lo, summed in long double on the host): the parity checks feed it to
+// the 80-bit arbiter, which must see the operator the kernels see, not its rounding to double.  Without the tile kernels
+// (TP_NO_TILE, a KE that is not box symmetric) the kernels apply KE itself: hi = KE, lo = 0.
+extern "C" int tp_elasticity_get_ke_effective(const tp_elasticity *e, double *hi, double *lo) {
+    if (!e || !hi || !lo) return TP_ERR_ARG;
+    if (!e->mg.lv[0].use_tile) {
+        for (int i = 0; i < 576; i++) hi[i] = e->KE[i], lo[i] = 0.0;
+        return TP_OK;
+    }
+    SymKE sk;
+    (void)make_sym_ke(e->KE, &sk);
+    static long double D[24][24];
+    for (int i = 0; i < 24; i++)
+        for (int j = 0; j < 24; j++) D[i][j] = 0.0L;
+    for (int q = 0; q < 8; q++)
+        for (int r = 0; r < 3; r++)
+            for (int s2 = r; s2 < 3; s2++) {
+                const int id = symke_idx(q, r, s2);
+                if (id < 0) continue;
+                const int i = (q ^ (1 << r)) * 3 + r, j = (q ^ (1 << s2)) * 3 + s2;
+                D[i][j] = D[j][i] = (long double)sk.a[id];
+            }
+    for (int m = 0; m < 8; m++)
+        for (int r = 0; r < 3; r++)
+            for (int m2 = 0; m2 < 8; m2++)
+                for (int s2 = 0; s2 < 3; s2++) {
+                    long double acc = 0.0L;
+                    for (int p2 = 0; p2 < 8; p2++)
+                        for (int p3 = 0; p3 < 8; p3++) {
+                            const int sg = (__builtin_popcount(p2 & m) + __builtin_popcount(p3 & m2)) & 1;
+                            acc += sg ? -D[p2 * 3 + r][p3 * 3 + s2] : D[p2 * 3 + r][p3 * 3 + s2];
+                        }
+                    const int i = (3 * h_M2A[m] + r) * 24 + 3 * h_M2A[m2] + s2;
+                    hi[i] = (double)acc;
+                    lo[i] = (double)(acc - (long double)hi[i]);
+                }
+    return TP_OK;
+}
 extern "C" int tp_elasticity_set_bc(tp_elasticity *e, const double *N) {
     if (e) e->mg.topology_epoch++;  // captured launch chains reference the lists rebuilt below
     tp_grid *g = e->grid;

@@ -89,6 +89,7 @@ SYMBOLS = {
     "tp_elasticity_create_ke": (_i, [C.POINTER(_vp), _vp, C.POINTER(SolverOpts), _vp]),
     "tp_elasticity_destroy": (_i, [_vp]),
     "tp_elasticity_get_ke": (_i, [_vp, _vp]),
+    "tp_elasticity_get_ke_effective": (_i, [_vp, _vp, _vp]),
     "tp_elasticity_cantilever": (_i, [_vp, _vp, _vp]),
     "tp_elasticity_set_bc": (_i, [_vp, _vp]),
     "tp_elasticity_assemble": (_i, [_vp, _vp, _d, _d, _d]),
