@@ -46,6 +46,14 @@ __device__ __forceinline__ void fu_dma16(unsigned m0a, unsigned m0b, unsigned vo
 }
 
 template <int EPI, int TX, int TY, bool CARRY, bool MASKED, bool BITOPS = true>
+// experiment builds (make EXTRA='-DFU4_ST_MOD="\" nt\""' OUT=...): cache-policy modifier of the output stores / of the
+// once-streamed epilogue operands (b, previous iterate); measured in round 5: see there
+#ifndef FU4_ST_MOD
+#define FU4_ST_MOD ""
+#endif
+#ifndef FU4_LD_MOD
+#define FU4_LD_MOD ""
+#endif
 __device__ __forceinline__ void fine_u4_run(const TileArgs &t, const NodeArgs &a, char *lds, int bxi, int byi, int bzi) {
 #pragma clang fp contract(off)
     using S = FineU4<TX, TY>;
@@ -159,7 +167,7 @@ __device__ __forceinline__ void fine_u4_run(const TileArgs &t, const NodeArgs &a
     const fu_u4 empty = {(unsigned)x0, (unsigned)(x0 >> 32), 0u, FD_RSRC_FLAGS};
     auto stores = [&](fu_u4 d, const double o[3]) {
         const fd_d2 o01 = {o[0], o[1]};
-        asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %2, %3, 0 offen\n\tbuffer_store_dwordx2 %1, %2, %3, 0 offen offset:16\n\ts_nop 1" ::"v"(o01), "v"(o[2]),
+        asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %2, %3, 0 offen" FU4_ST_MOD "\n\tbuffer_store_dwordx2 %1, %2, %3, 0 offen offset:16" FU4_ST_MOD "\n\ts_nop 1" ::"v"(o01), "v"(o[2]),
                      "v"(voff_out), "s"(d)
                      : "memory");
     };
@@ -363,14 +371,14 @@ __device__ __forceinline__ void fine_u4_run(const TileArgs &t, const NodeArgs &a
         // ---- operands of step s + 1 (planes kz0 + s), then the stores of step s (plane kz0 - 1 + s; s = 0: nothing)
         if (HAS_B) {
             const fu_u4 db = desc(pb, lim_b);
-            asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, 0 offen\n\tbuffer_load_dwordx2 %1, %2, %3, 0 offen offset:16"
+            asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, 0 offen" FU4_LD_MOD "\n\tbuffer_load_dwordx2 %1, %2, %3, 0 offen offset:16" FU4_LD_MOD
                          : "+v"(b01), "+v"(b2)
                          : "v"(voff_out), "s"(db)
                          : "memory");
             pb += su;
             if (IS_CHEB) {
                 const fu_u4 dp = desc_lim0(pp, lim_p);
-                asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, 0 offen\n\tbuffer_load_dwordx2 %1, %2, %3, 0 offen offset:16"
+                asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, 0 offen" FU4_LD_MOD "\n\tbuffer_load_dwordx2 %1, %2, %3, 0 offen offset:16" FU4_LD_MOD
                              : "+v"(p01), "+v"(p2)
                              : "v"(voff_out), "s"(dp)
                              : "memory");

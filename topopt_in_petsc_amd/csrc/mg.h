@@ -60,8 +60,10 @@ enum { S_BB = 0, S_RR = 1, S_PW = 2, S_RZ0 = 3, S_RZ1 = 4, S_TMP = 8 };
 // order) -- one pass over r less and one launch less per Krylov iteration
 // NT: x, p and w pass through with non-temporal loads / stores -- none of the three is read again before ~10 other vectors
 // of the same size have gone by, while r and z1 are the next kernel's input: the hint keeps the streamed ones from
-// displacing them (TP_CG_NT, measured in DESIGN 4.4)
-template <bool NT>
+// displacing them in the Infinity Cache.  Measured at 128^3 (two runs each, round 5): 12.50 / 12.48 -> 12.40 / 12.32 ms per
+// design iteration, the following fine-level Chebyshev launches 58.9 / 57.3 -> 54.7 / 54.4 us (in-step roofline fraction
+// 0.40-0.41 -> 0.43)
+template <bool NT, bool NTS = false>
 __global__ __launch_bounds__(BLK) void k_cg_update_xr(double *__restrict__ x, double *__restrict__ r,
                                                       const double *__restrict__ p, const double *__restrict__ w,
                                                       const double *__restrict__ scal, int slot_rz, long off, long n,
@@ -80,9 +82,13 @@ __global__ __launch_bounds__(BLK) void k_cg_update_xr(double *__restrict__ x, do
             x[q] = fma(alpha, p[q], x[q]);
             rn = fma(-alpha, w[q], r[q]);
         }
-        r[q] = rn;
+        if constexpr (NTS) __builtin_nontemporal_store(rn, r + q);
+        else r[q] = rn;
         s = fma(rn, rn, s);
-        if (z1) z1[q] = dinv[q] * rn * inv_theta;
+        if (z1) {
+            if constexpr (NTS) __builtin_nontemporal_store(dinv[q] * rn * inv_theta, z1 + q);
+            else z1[q] = dinv[q] * rn * inv_theta;
+        }
     }
     const double v[1] = {block_sum(s)};
     reduce_tail<1>(v, partials, gridDim.x, blockIdx.x, ticket, out, out_host);
@@ -1384,6 +1390,12 @@ struct MGSolver {
         if (fuse_first) cheb_window(l + 1, &th, &de);
         auto restrict_planes = [&](int p0, int np) -> int {
             const long cpl = C.g.plane();
+            static const bool nt_r = getenv("TP_NT_RESTRICT") != nullptr && atoi(getenv("TP_NT_RESTRICT")) != 0;  // (experiment)
+            if (nt_r && l == 0)
+                TP_LAUNCH((k_restrict<DOF, true>), dim3((int)((cpl * np + BLK - 1) / BLK)), dim3(BLK), 0, grid->stream, C.g, L.g, L.r, C.b,
+                          fuse_first ? C.dinv : nullptr, fuse_first ? C.x : nullptr, fuse_first && !three_term(C) ? C.d : nullptr,
+                          1.0 / th, cpl * (p0 - C.g.own_lo), cpl * np);
+            else
             TP_LAUNCH((k_restrict<DOF>), dim3((int)((cpl * np + BLK - 1) / BLK)), dim3(BLK), 0, grid->stream, C.g, L.g, L.r, C.b,
                       fuse_first ? C.dinv : nullptr, fuse_first ? C.x : nullptr, fuse_first && !three_term(C) ? C.d : nullptr,
                       1.0 / th, cpl * (p0 - C.g.own_lo), cpl * np);
@@ -1718,8 +1730,13 @@ struct MGSolver {
                                         !sg_capturing;
                 double th0 = 1.0, de0 = 1.0;
                 if (fuse_first) cheb_window(0, &th0, &de0);
-                static const bool cg_nt = getenv("TP_CG_NT") != nullptr && atoi(getenv("TP_CG_NT")) != 0;
-                if (cg_nt)
+                static const bool cg_nt = !(getenv("TP_CG_NT") != nullptr && atoi(getenv("TP_CG_NT")) == 0);  // on (TP_CG_NT=0: plain loads / stores)
+                static const bool cg_nts = getenv("TP_CG_NTS") != nullptr && atoi(getenv("TP_CG_NTS")) != 0;  // (experiment: r, z1 stores too)
+                if (cg_nt && cg_nts)
+                    TP_LAUNCH((k_cg_update_xr<true, true>), dim3(nb), dim3(BLK), 0, s, x, r, p, w, grid->scal, rz_cur, off, n,
+                              grid->partials, tail_ticket(grid), grid->scal + S_RR, direct_rr ? grid->h_scal_dev : nullptr,
+                              fuse_first ? L.x : nullptr, L.dinv, 1.0 / th0);
+                else if (cg_nt)
                     TP_LAUNCH(k_cg_update_xr<true>, dim3(nb), dim3(BLK), 0, s, x, r, p, w, grid->scal, rz_cur, off, n,
                               grid->partials, tail_ticket(grid), grid->scal + S_RR, direct_rr ? grid->h_scal_dev : nullptr,
                               fuse_first ? L.x : nullptr, L.dinv, 1.0 / th0);
