@@ -27,20 +27,23 @@ _ORDER = ["test_harness", "test_gpu_parity", "test_golden", "test_gpu_configs", 
 _plain_run = subprocess.run
 
 
-def hardened_run(cmd, *args, timeout=None, **kw):
-    """subprocess.run with a process group per child and a killpg on expiry; the timeout is capped at SUBPROCESS_CAP_S."""
-    if kw.get("input") is not None or kw.get("stdin") is not None:
-        return _plain_run(cmd, *args, timeout=timeout, **kw)
-    limit = min(timeout or SUBPROCESS_CAP_S, SUBPROCESS_CAP_S)
+def hardened_run(cmd, *args, timeout=None, input=None, **kw):
+    """subprocess.run with a process group per child and a killpg on expiry.  Semantics of subprocess.run are kept:
+    an explicit `timeout` is honoured as given -- the cap SUBPROCESS_CAP_S only applies to calls that pass none --, expiry
+    raises subprocess.TimeoutExpired (after the group is dead; .output / .stderr carry what was captured, and the tail is
+    printed so that an uncaught expiry still shows where the child was), `input=` goes through communicate()."""
+    limit = timeout if timeout is not None else SUBPROCESS_CAP_S
     capture = kw.pop("capture_output", False)
     check = kw.pop("check", False)
     if capture:
         kw["stdout"], kw["stderr"] = subprocess.PIPE, subprocess.PIPE
+    if input is not None:
+        kw["stdin"] = subprocess.PIPE
     kw["start_new_session"] = True
     p = subprocess.Popen(cmd, *args, **kw)
     try:
-        out, err = p.communicate(timeout=limit)
-    except subprocess.TimeoutExpired:
+        out, err = p.communicate(input=input, timeout=limit)
+    except subprocess.TimeoutExpired as e:
         try:
             os.killpg(p.pid, signal.SIGKILL)
         except OSError:
@@ -50,8 +53,9 @@ def hardened_run(cmd, *args, timeout=None, **kw):
         except Exception:
             out, err = None, None
         tail = lambda b: (b if isinstance(b, str) else (b or b"").decode(errors="replace"))[-3000:]
-        pytest.fail("subprocess %r did not finish within %.0f s; its process group was killed\n---- stdout ----\n%s\n---- stderr ----\n%s"
-                    % (cmd, limit, tail(out), tail(err)), pytrace=False)
+        sys.stderr.write("subprocess %r did not finish within %.0f s; its process group was killed\n---- stdout ----\n%s\n---- stderr ----\n%s\n"
+                         % (cmd, limit, tail(out), tail(err)))
+        raise subprocess.TimeoutExpired(cmd, limit, output=out, stderr=err) from e
     r = subprocess.CompletedProcess(cmd, p.returncode, out, err)
     if check:
         r.check_returncode()

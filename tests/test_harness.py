@@ -16,9 +16,9 @@ def test_a_hanging_subprocess_is_killed_with_its_children(tmp_path):
             "open(%r, 'w').write(str(p.pid))\n"
             "time.sleep(600)\n") % str(pidfile)
     t0 = time.time()
-    with pytest.raises(pytest.fail.Exception) as ei:
+    with pytest.raises(subprocess.TimeoutExpired) as ei:   # subprocess.run's own exception: callers' handlers keep working
         subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=2)   # (conftest's hardened run)
-    assert "did not finish within" in str(ei.value) and time.time() - t0 < 30
+    assert ei.value.timeout == 2 and time.time() - t0 < 30
     pid = int(pidfile.read_text())
     for _ in range(50):   # the grandchild is gone (or a zombie being reaped), not sleeping on
         try:
@@ -37,6 +37,13 @@ def test_subprocess_results_pass_through_unchanged():
     assert r.returncode == 3 and r.stdout == "out\n" and r.stderr == "err\n"
     with pytest.raises(subprocess.CalledProcessError):
         subprocess.run([sys.executable, "-c", "raise SystemExit(2)"], check=True, timeout=30)
+
+
+def test_input_goes_through_the_hardened_run_too():
+    r = subprocess.run([sys.executable, "-c", "import sys; print(sys.stdin.read().upper())"], input="abc", capture_output=True, text=True, timeout=30)
+    assert r.returncode == 0 and r.stdout == "ABC\n"
+    with pytest.raises(subprocess.TimeoutExpired):
+        subprocess.run([sys.executable, "-c", "import sys, time; sys.stdin.read(); time.sleep(600)"], input="x", capture_output=True, text=True, timeout=2)
 
 
 def test_collection_order_puts_parity_first_and_subprocess_files_last(request):

@@ -133,6 +133,9 @@ __global__ __launch_bounds__(256) void k_conv_filter_zring(int ex, int ey, int e
                                                            double *__restrict__ out, const double *__restrict__ d1,
                                                            const double *__restrict__ d2) {
     constexpr int TXE = 32, TYE = 16, TZE = 4, NX = 8, W1 = 2 * C + 1, SX = TXE + 2 * C, SY = TYE + 2 * C, NT = 256;
+    // two planes of (16 + 2C) x (32 + 2C) doubles: 68.7 KB at C = 21, 81.9 KB at C = 24 -- sized for the 160 KB of a gfx950 CU
+    // (this library is built for gfx950 only; a 64-KB-LDS part would have to stop at C = 20)
+    static_assert(sizeof(double) * 2 * SY * SX <= 160 * 1024, "k_conv_filter_zring: the two staged planes exceed gfx950's 160 KB of LDS");
     __shared__ double s_x[2][SY * SX];
     const int x0 = blockIdx.x * TXE, y0 = blockIdx.y * TYE, z0 = blockIdx.z * TZE;
     const int tz = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);  // z layer of this WAVE

@@ -46,8 +46,10 @@ __device__ __forceinline__ void fu_dma16(unsigned m0a, unsigned m0b, unsigned vo
 }
 
 template <int EPI, int TX, int TY, bool CARRY, bool MASKED, bool BITOPS = true>
-// experiment builds (make EXTRA='-DFU4_ST_MOD="\" nt\""' OUT=...): cache-policy modifier of the output stores / of the
-// once-streamed epilogue operands (b, previous iterate); measured in round 5: see there
+// experiment builds (make EXTRA='-DFU4_ST_MOD="\" nt\""' OUT=../libtopopt_amd_x.so, loaded through TP_LIB): cache-policy modifier
+// of the output stores / of the once-streamed epilogue operands (b, previous iterate).  Measured at 256^3 in round 5: nt stores
+// 251.2 / 391.3 us (product / Chebyshev step) against 249.3 / 392.6 -- nothing; nt on the epilogue loads as well 254.2 / 441.7 --
+// the previous iterate is read back through the L2 by the same workgroup, the hint throws that away.  Default: none.
 #ifndef FU4_ST_MOD
 #define FU4_ST_MOD ""
 #endif

@@ -62,8 +62,9 @@ enum { S_BB = 0, S_RR = 1, S_PW = 2, S_RZ0 = 3, S_RZ1 = 4, S_TMP = 8 };
 // of the same size have gone by, while r and z1 are the next kernel's input: the hint keeps the streamed ones from
 // displacing them in the Infinity Cache.  Measured at 128^3 (two runs each, round 5): 12.50 / 12.48 -> 12.40 / 12.32 ms per
 // design iteration, the following fine-level Chebyshev launches 58.9 / 57.3 -> 54.7 / 54.4 us (in-step roofline fraction
-// 0.40-0.41 -> 0.43)
-template <bool NT, bool NTS = false>
+// 0.40-0.41 -> 0.43).  Measured and dropped in the same round: the stores of r and z1 non-temporal as well (12.39 / 12.28 against
+// 12.37 / 12.23: the next kernel then misses them), the restriction reading the fine residual non-temporally (12.6-12.8: slower)
+template <bool NT>
 __global__ __launch_bounds__(BLK) void k_cg_update_xr(double *__restrict__ x, double *__restrict__ r,
                                                       const double *__restrict__ p, const double *__restrict__ w,
                                                       const double *__restrict__ scal, int slot_rz, long off, long n,
@@ -82,13 +83,9 @@ __global__ __launch_bounds__(BLK) void k_cg_update_xr(double *__restrict__ x, do
             x[q] = fma(alpha, p[q], x[q]);
             rn = fma(-alpha, w[q], r[q]);
         }
-        if constexpr (NTS) __builtin_nontemporal_store(rn, r + q);
-        else r[q] = rn;
+        r[q] = rn;
         s = fma(rn, rn, s);
-        if (z1) {
-            if constexpr (NTS) __builtin_nontemporal_store(dinv[q] * rn * inv_theta, z1 + q);
-            else z1[q] = dinv[q] * rn * inv_theta;
-        }
+        if (z1) z1[q] = dinv[q] * rn * inv_theta;
     }
     const double v[1] = {block_sum(s)};
     reduce_tail<1>(v, partials, gridDim.x, blockIdx.x, ticket, out, out_host);
@@ -621,7 +618,9 @@ struct MGSolver {
             // third generation (fine_u4.h; TP_FINE_V=2: k_fine_tile, 1: k_matfree_tile): tile shape by mesh size.  Its
             // 32-bit window arithmetic needs every vector of the level below 2 GB.
             const int t32 = ((L.g.nx + 30) / 31) * ((L.g.ny + 6) / 7);   // 32 x 8 tiles per z-chunk
-            if ((fine_v >= 3 || (fine_v == 0 && t32 >= 160)) && 24.0 * L.g.nodes() < 2.0e9) {
+            const int gen = fine_generation(L);
+            if (a.pz && gen != 2) return TP_ERR_STATE;  // the fused p update exists in k_fine_tile only: never run it on a kernel that ignores it
+            if (gen == 3) {
                 constexpr bool IS_CHEB = (EPI == EPI_CHEB || EPI == EPI_CHEB_DOT);
                 static const int shape_env = getenv("TP_FINE_SHAPE") ? atoi(getenv("TP_FINE_SHAPE")) : 0;  // 1: 16x16, 2: 32x8
                 // measured on the BASELINE meshes (tools/probe/fine_probe.hip, profiles/r03_fine_probe.txt): the long
@@ -676,7 +675,7 @@ struct MGSolver {
                 TileArgs ta{L.g.nx, L.g.ny, L.g.nzl, L.g.ex, L.g.ey, L.g.ezl, lo, hi, kz,
                             L.E, L.mask, L.colmask, L.sym_slot * SYMKE_STRIDE, 0, 0, nullptr, xcd_remap(), 0, r1lo, r1hi,
                             0, nullptr, nullptr, 0, nullptr};
-                if (fine_v >= 2 || fine_v == 0) {
+                if (gen == 2) {
                     TP_LAUNCH((k_fine_tile<EPI>), dim3(tx, ty, tz), dim3(TILE * TILE), 0, grid->stream, ta, a);
                 } else {
                     if constexpr (EPI == EPI_CHEB_DOT) return TP_ERR_STATE;
@@ -817,14 +816,17 @@ struct MGSolver {
     // Fine tile kernel: Chebyshev in its 3-term form  u+ = u + c1 (u - u-) + c2 D^-1 (b - A u); u- sits in the output
     // buffer (read and overwritten by the same thread), so no direction vector is streamed.
     static bool three_term(const Level<DOF> &L) { return DOF == 3 && L.kind == LV_MATFREE && L.use_tile; }
-    // does op<> serve this level with k_fine_tile (second generation)?  (the kernel that takes the fused p update)
-    static bool runs_fine_tile(const Level<DOF> &L) {
-        if (!(DOF == 3 && L.kind == LV_MATFREE && L.use_tile)) return false;
+    // Which kernel generation serves a tuned matrix-free level?  ONE place decides, op<>() launches what it says and solve()
+    // asks it before it hands the fused p update to the product (only k_fine_tile takes NodeArgs::pz / pnew: ADVICE r4).
+    // 3: fine_u4.h (its 32-bit window arithmetic needs every vector of the level below 2 GB), 2: fine_tile.h, 1: matfree_tile.h
+    static int fine_generation(const Level<DOF> &L) {
+        if (!(DOF == 3 && L.kind == LV_MATFREE && L.use_tile)) return 0;
         const int fine_v = fine_version();
-        const int t32 = ((L.g.nx + 30) / 31) * ((L.g.ny + 6) / 7);
-        const bool third = (fine_v >= 3 || (fine_v == 0 && t32 >= 160)) && 24.0 * L.g.nodes() < 2.0e9;
-        return !third && (fine_v >= 2 || fine_v == 0);
+        const int t32 = ((L.g.nx + 30) / 31) * ((L.g.ny + 6) / 7);   // 32 x 8 tiles per z-chunk
+        if ((fine_v >= 3 || (fine_v == 0 && t32 >= 160)) && 24.0 * L.g.nodes() < 2.0e9) return 3;
+        return (fine_v >= 2 || fine_v == 0) ? 2 : 1;
     }
+    static bool runs_fine_tile(const Level<DOF> &L) { return fine_generation(L) == 2; }
     int halo(int l, double *v) {
         if (lv[l].no_comm) return TP_OK;
         if (pend[l].ptr == v) return drain_halo(l);  // already under way: ordered behind it, nothing to exchange
@@ -1390,13 +1392,7 @@ struct MGSolver {
         if (fuse_first) cheb_window(l + 1, &th, &de);
         auto restrict_planes = [&](int p0, int np) -> int {
             const long cpl = C.g.plane();
-            static const bool nt_r = getenv("TP_NT_RESTRICT") != nullptr && atoi(getenv("TP_NT_RESTRICT")) != 0;  // (experiment)
-            if (nt_r && l == 0)
-                TP_LAUNCH((k_restrict<DOF, true>), dim3((int)((cpl * np + BLK - 1) / BLK)), dim3(BLK), 0, grid->stream, C.g, L.g, L.r, C.b,
-                          fuse_first ? C.dinv : nullptr, fuse_first ? C.x : nullptr, fuse_first && !three_term(C) ? C.d : nullptr,
-                          1.0 / th, cpl * (p0 - C.g.own_lo), cpl * np);
-            else
-            TP_LAUNCH((k_restrict<DOF>), dim3((int)((cpl * np + BLK - 1) / BLK)), dim3(BLK), 0, grid->stream, C.g, L.g, L.r, C.b,
+                TP_LAUNCH((k_restrict<DOF>), dim3((int)((cpl * np + BLK - 1) / BLK)), dim3(BLK), 0, grid->stream, C.g, L.g, L.r, C.b,
                       fuse_first ? C.dinv : nullptr, fuse_first ? C.x : nullptr, fuse_first && !three_term(C) ? C.d : nullptr,
                       1.0 / th, cpl * (p0 - C.g.own_lo), cpl * np);
             return TP_OK;
@@ -1731,12 +1727,7 @@ struct MGSolver {
                 double th0 = 1.0, de0 = 1.0;
                 if (fuse_first) cheb_window(0, &th0, &de0);
                 static const bool cg_nt = !(getenv("TP_CG_NT") != nullptr && atoi(getenv("TP_CG_NT")) == 0);  // on (TP_CG_NT=0: plain loads / stores)
-                static const bool cg_nts = getenv("TP_CG_NTS") != nullptr && atoi(getenv("TP_CG_NTS")) != 0;  // (experiment: r, z1 stores too)
-                if (cg_nt && cg_nts)
-                    TP_LAUNCH((k_cg_update_xr<true, true>), dim3(nb), dim3(BLK), 0, s, x, r, p, w, grid->scal, rz_cur, off, n,
-                              grid->partials, tail_ticket(grid), grid->scal + S_RR, direct_rr ? grid->h_scal_dev : nullptr,
-                              fuse_first ? L.x : nullptr, L.dinv, 1.0 / th0);
-                else if (cg_nt)
+                if (cg_nt)
                     TP_LAUNCH(k_cg_update_xr<true>, dim3(nb), dim3(BLK), 0, s, x, r, p, w, grid->scal, rz_cur, off, n,
                               grid->partials, tail_ticket(grid), grid->scal + S_RR, direct_rr ? grid->h_scal_dev : nullptr,
                               fuse_first ? L.x : nullptr, L.dinv, 1.0 / th0);

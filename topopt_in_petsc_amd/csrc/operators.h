@@ -241,7 +241,7 @@ __global__ __launch_bounds__(BLK) void k_matfree_diag(MatfreeOp<DOF> op, double 
 // coarse b_c[I] = sum over the 27 fine neighbours of 2I of w * r_f ; owned coarse nodes
 // first != NULL: also the first Chebyshev step of the coarse level from a zero guess (k_cheb_first fused in):
 // x_c = dinv_c * b_c * inv_theta (and d_c = x_c where the level keeps a direction vector)
-template <int DOF, bool NT = false>
+template <int DOF>
 __global__ __launch_bounds__(BLK) void k_restrict(Geom gc, Geom gf, const double *__restrict__ rf,
                                                   double *__restrict__ bc, const double *__restrict__ dinv_c = nullptr,
                                                   double *__restrict__ x_c = nullptr, double *__restrict__ d_c = nullptr,
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(BLK) void k_restrict(Geom gc, Geom gf, const double
                 const double w = ok ? (di ? 0.5 : 1.0) * (dj ? 0.5 : 1.0) * (dk ? 0.5 : 1.0) : 0.0;
                 const long nf = ok ? (long)i + (long)gf.nx * (j + (long)gf.ny * k) : (long)(2 * I) + (long)gf.nx * (2 * J + (long)gf.ny * (2 * K));
 #pragma unroll
-                for (int r = 0; r < DOF; r++) s[r] = fma(w, NT ? __builtin_nontemporal_load(rf + nf * DOF + r) : rf[nf * DOF + r], s[r]);
+                for (int r = 0; r < DOF; r++) s[r] = fma(w, rf[nf * DOF + r], s[r]);
             }
         }
     }
