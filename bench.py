@@ -893,6 +893,21 @@ def main():
         rec = json.load(open(tj)).get("%dx%dx%d" % (ex, ey, part.ez_own))
         if rec:
             traffic = rec
+    # `traffic` belongs to the same variant mix as `alg_bytes_per_launch`: the PMC passes measured the
+    # with-previous-iterate variant (4 vectors + E: cheb_bytes) and the plain product; a first step of a sweep reads one vector
+    # (24 B per node) less -- its traffic is taken as the full variant's minus that vector's algorithmic bytes, and the mix is
+    # weighted by the launch counts of the step (roof_bytes is the same weighted mean of the algorithmic bytes)
+    roof_traffic, traffic_var = None, None
+    if traffic and traffic.get("cheb_hbm_bytes_per_launch"):
+        t_full = traffic["cheb_hbm_bytes_per_launch"]
+        t_first = t_full - 24.0 * n_nd_own
+        first_bytes = cheb_bytes - 24.0 * n_nd_own
+        share_first = min(max((cheb_bytes - roof_bytes) / (cheb_bytes - first_bytes), 0.0), 1.0)
+        roof_traffic = ((1.0 - share_first) * t_full + share_first * t_first) / 1e9
+        traffic_var = {"with_previous_iterate": {"traffic_GB": t_full / 1e9, "alg_GB": cheb_bytes / 1e9, "ratio": t_full / cheb_bytes, "source": "PMC"},
+                       "first_step_of_a_sweep": {"traffic_GB": t_first / 1e9, "alg_GB": first_bytes / 1e9, "ratio": t_first / first_bytes,
+                                                 "source": "PMC of the full variant minus the 24 B per node it does not read"},
+                       "share_of_first_steps": share_first, "mix_ratio": roof_traffic * 1e9 / roof_bytes}
     gen3 = os.environ.get("TP_FINE_V", "0") in ("3",) or (os.environ.get("TP_FINE_V", "0") == "0" and ((nx + 30) // 31) * ((ny + 6) // 7) >= 160)
     kname = "k_fine_u4" if gen3 else "k_fine_tile"
     roofline = {"bound": "hbm", "kernel": "%s<EPI_CHEB> / <EPI_CHEB_DOT> (fine-level matrix-free hex8 operator fused with the Chebyshev-Jacobi "
@@ -902,8 +917,9 @@ def main():
                                           "coarsest level, k_cd_factor, one latency-bound launch of 1.5 ms on a side stream: DESIGN 4.5)" % kname,
                 "share_of_step": cheb_step_share,
                 "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                "traffic": (traffic or {}).get("cheb_hbm_bytes_per_launch", None) and traffic["cheb_hbm_bytes_per_launch"] / 1e9,
+                "traffic": roof_traffic,
                 "traffic_unit": "GB per launch (PMC)",
+                "traffic_by_variant": traffic_var,
                 "traffic_source": "profiles/spmv_traffic.json (static: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                                   "of tools/pmc_traffic.py on this mesh, not measured in this run)" if traffic else None,
                 "alg_bytes_per_launch": roof_bytes, "avg_launch_ms": cheb_ms, "avg_launch_how": how, "back_to_back": b2b,
@@ -931,6 +947,34 @@ def main():
             b2 = x2 = None
         except Exception as e:      # (a level that is not a stored stencil: nothing to report)
             roofline["level2_stencil"] = {"skipped": repr(e)}
+    # ---- the filter's own kernel (VERDICT r4 "next" 8): back-to-back launches on the line's mesh.  Cone filter: 16 B per element
+    # of algorithmic traffic and 2 (2c+1)^3 flop per element -- FP64-issue bound from ElemConn 2 on, so the FP64 fraction
+    # (78.6 TFLOP/s vector peak) stands beside the HBM fraction; Helmholtz filter: the scalar 27-point operator applied
+    # matrix-free from the 8 x 8 element matrix, 16 B per node.
+    if world == 1:
+        try:
+            if ftype == 2:
+                un, yn = grid.node_vec(1).normal_(), grid.node_vec(1)
+                t_pa = timed(lambda: flt.PDEApply(un, yn), a.spmv_reps)
+                pb = 16.0 * n_nd_own
+                roofline["pde_filter"] = {"kernel": "k_node<1, MatfreeOp<1>, EPI_APPLY> (scalar 27-point Helmholtz operator K_f, matrix-free from KF; PDEFilter.cc:251-264)",
+                                          "alg_bytes_per_launch": pb, "avg_launch_ms": t_pa, "achieved": pb / (t_pa * 1e-3) / 1e9,
+                                          "frac": pb / (t_pa * 1e-3) / 1e9 / 8000.0, "n_nodes": n_nd_own,
+                                          "pde_solve_its": flt.last_pde_solve()[0],
+                                          "note": "back-to-back launches; %.1f MB per launch: the vectors stay in the Infinity Cache, the launch is latency bound" % (pb / 1e6)}
+                un = yn = None
+            else:
+                xe, ye = grid.elem_vec().uniform_(), grid.elem_vec()
+                t_h = timed(lambda: flt.MultH(xe, ye), a.spmv_reps)
+                cb_, taps = 16.0 * n_el_own, float((2 * flt.ElemConn + 1) ** 3)
+                roofline["conv_filter"] = {"kernel": "k_conv_filter_tiled / _wide / _zring<ElemConn> (cone filter as an LDS-tiled (2c+1)^3 stencil; MatMult(H), Filter.cc:68)",
+                                           "elem_conn": flt.ElemConn, "taps": taps, "alg_bytes_per_launch": cb_, "avg_launch_ms": t_h,
+                                           "achieved": cb_ / (t_h * 1e-3) / 1e9, "frac": cb_ / (t_h * 1e-3) / 1e9 / 8000.0,
+                                           "fp64_tflops": 2.0 * taps * n_el_own / (t_h * 1e-3) / 1e12,
+                                           "fp64_frac_of_78.6": 2.0 * taps * n_el_own / (t_h * 1e-3) / 1e12 / 78.6}
+                xe = ye = None
+        except Exception as e:
+            roofline["filter_kernel"] = {"skipped": repr(e)}
     # the north-star mesh of the SpMV target (256^3 elements, 50.9 M DOF; vectors 407 MB each: beyond the 256 MB
     # Infinity Cache), measured in this run on rank 0 of a 1-GPU job
     if world == 1 and not a.no_cube256 and a.workload == "cantilever128":

@@ -477,6 +477,14 @@ class Filter:
         _chk(self.L.tp_filter_gradients(self.handle, _ptr(x), _ptr(xTilde), _ptr(dfdx), len(dgdx), arr,
                                         int(projectionFilter), beta, eta), "tp_filter_gradients")
 
+    def MultH(self, x, y):
+        """y = H x with the cone weights (MatMult(H, ...), Filter.cc:68, :173-189), no division by Hs"""
+        _chk(self.L.tp_filter_mult_h(self.handle, _ptr(x), _ptr(y)), "tp_filter_mult_h")
+
+    def PDEApply(self, u, y):
+        """y = K_f u, the nodal Helmholtz operator of the PDE filter applied matrix-free (PDEFilter.cc:251-264 assembles it)"""
+        _chk(self.L.tp_pdefilter_apply(self.handle, _ptr(u), _ptr(y)), "tp_pdefilter_apply")
+
     def GetMND(self, x):
         v = C.c_double()
         _chk(self.L.tp_filter_mnd(self.handle, _ptr(x), C.byref(v)), "tp_filter_mnd")
