@@ -195,8 +195,9 @@ def cpu_baseline_worker(argv):
     the oracle's design iteration in a process of its own (all host cores, nothing of torch or the GPU library loaded)."""
     out, sample, rtol, fine_eig, ex, ey, ez, ndof, budget, nlv, nsmooth, ncoarse, cycles, direct = argv[:14]
     extras_npz = argv[14] if len(argv) > 14 and argv[14] != "-" else None   # where the parity extras' vectors go (same-mesh run only)
+    problem = json.loads(argv[15]) if len(argv) > 15 else None              # {"ftype", "bc", "rmin"} of the workload
     res = cpu_baseline(sample, float(rtol), int(fine_eig), (int(ex), int(ey), int(ez)), int(ndof), float(budget), int(nlv),
-                       int(nsmooth), int(ncoarse), "" if cycles == "-" else cycles, bool(int(direct)), extras_npz)   # (budget <= 0: the sample mesh only)
+                       int(nsmooth), int(ncoarse), "" if cycles == "-" else cycles, bool(int(direct)), extras_npz, problem)   # (budget <= 0: the sample mesh only)
     with open(out + ".tmp", "w") as f:
         json.dump(res, f)
     os.replace(out + ".tmp", out)
@@ -210,13 +211,14 @@ PARITY_BOUNDS = {
     "vs_oracle": 1e-9,                     # GPU vs the double-precision oracle on the reference's KE: everything above (measured 1.6e-10 /
                                            # 2.6e-10 at 128^3 -- the operator's 5e-16, amplified by the conditioning of this mesh)
     "gx_abs": 1e-13,                       # volume constraint
+    "behind_pde_filter": 1e-6,             # workloads with the Helmholtz filter (its own solve stops at rtol 1e-8): fx, first ten ||r_k||, gx
 }
 if os.environ.get("TP_BENCH_TEST_PARITY_BOUND"):   # tests/test_bench_line.py: an unreachable bound must end the run with code 4
     PARITY_BOUNDS["vs_arbiter_on_own_operator"] = float(os.environ["TP_BENCH_TEST_PARITY_BOUND"])
 TIGHT_RTOL = 1e-12   # the converged parity step (SURVEY 8c pin 5: converged quantities are solver independent)
 
 
-def cpu_step(orc, el, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, matfree_too, coarse_direct=False, extras_npz=None):
+def cpu_step(orc, el, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, matfree_too, coarse_direct=False, extras_npz=None, problem=None):
     """One design iteration of the oracle (the reference's data path: assembled CSR + Galerkin SpGEMM) on `el` elements;
     with matfree_too the solve is repeated with the fine-level operator applied matrix-free (OpenMP gather).  Returns a
     dict: n_dof, its, seconds (assembled), seconds_mf (matrix-free or None), levels, and the numbers the GPU step is
@@ -225,24 +227,40 @@ def cpu_step(orc, el, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, matfree_too
     while nlv > 1 and (ex % (1 << (nlv - 1)) or ey % (1 << (nlv - 1)) or ez % (1 << (nlv - 1))):
         nlv -= 1
     nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
+    problem = problem or {}
+    ftype, bc, rmin = int(problem.get("ftype", 1)), problem.get("bc", "cantilever"), float(problem.get("rmin") or 2.56 * h)
     x = orc.synth_density(ex, ey, ez, h)
     KE = orc.hex8_ke_box(h, h, h, 0.3)
-    N, R = orc.cantilever_bc(nx, ny, nz, h)
-    flt = orc.Filter(nx, ny, nz, h, 2.56 * h)
+    N, R = orc.mbb_bc(nx, ny, nz) if bc == "mbb" else orc.cantilever_bc(nx, ny, nz, h)
+    if ftype == 2:   # Helmholtz filter with the library's defaults (PDEFilter.cc:32, :280-283, :357; Chebyshev(2) smoothing)
+        class _PdeFilter:
+            def __init__(self):
+                self.f = orc.PDEFilter(nx, ny, nz, h, rmin, nlv=3, nsmooth=2, ncoarse=10)
+
+            def project(self, _ftype, x_):
+                import numpy as np_
+                xt_ = np_.clip(self.f.apply(x_)[0], 0.0, 1.0)     # Filter.cc:87-100
+                return xt_, xt_
+
+            def gradient(self, _ftype, _x, _xt, d):
+                return self.f.apply(d)[0]                          # Filter.cc:195-199
+        flt = _PdeFilter()
+    else:
+        flt = orc.Filter(nx, ny, nz, h, rmin)
     mg = orc.MG(nx, ny, nz, 3, nlv, nsmooth, ncoarse, fine_eig=fine_eig)
     mg.set_coarse_direct(coarse_direct)
     if cycles:
         mg.set_cycles([int(v) for v in cycles.split(",")][: max(nlv - 1, 0)])
     t0 = time.perf_counter()
-    xt, xp = flt.project(1, x)
+    xt, xp = flt.project(ftype, x)
     tf = time.perf_counter()
     mg.assemble(KE, orc.simp(xp), N)
     t1 = time.perf_counter()
     U, its, hist = mg.solve(R * N, rtol=rtol)
     t2 = time.perf_counter()
     fx, gx, df, dg = orc.compliance_sens(nx, ny, nz, KE, U, xp)
-    df = flt.gradient(1, x, xt, df)
-    dg = flt.gradient(1, x, xt, dg)
+    df = flt.gradient(ftype, x, xt, df)
+    dg = flt.gradient(ftype, x, xt, dg)
     t3 = time.perf_counter()
     t_mf = None
     if matfree_too:
@@ -257,7 +275,8 @@ def cpu_step(orc, el, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, matfree_too
            "fx": float(fx), "gx": float(gx), "rel_residual": float(hist[min(its, len(hist) - 1)] / hist[0]) if len(hist) else None,
            "hist": [float(v) for v in hist[:64]], "df_abs_sum": float(np.abs(df).sum()),
            "phase_seconds": {"filter": tf - t0, "assemble": t1 - tf, "solve": t2 - t1, "sensitivities+filter": t3 - t2}}
-    if extras_npz:
+    res["problem"] = {"ftype": ftype, "bc": bc, "rmin": rmin}
+    if extras_npz and ftype == 1:    # (a Helmholtz-filtered density is itself the result of a solve to rtol 1e-8: no 1e-10 to assert behind it)
         # ---- what the parity object of the line needs beyond the timed step (none of it is timed):
         # (1) the CONVERGED step: the same system solved to rtol 1e-12 from the zero guess -- compliance and raw
         #     sensitivities are then independent of the path the solver took;
@@ -330,7 +349,7 @@ def host_description():
     return {"cpu_model": model, "os_cpu_count": os.cpu_count(), "usable_cpus": usable}
 
 
-def cpu_baseline(sample, rtol, fine_eig, gpu_el, gpu_ndof, budget_s, nlv=4, nsmooth=4, ncoarse=30, cycles="", coarse_direct=False, extras_npz=None):
+def cpu_baseline(sample, rtol, fine_eig, gpu_el, gpu_ndof, budget_s, nlv=4, nsmooth=4, ncoarse=30, cycles="", coarse_direct=False, extras_npz=None, problem=None):
     """the oracle timed on the host cores beside the GPU line -- on the SAME mesh when the budget
     (--cpu-budget seconds) allows it, judged from a first run on the bounded sample mesh; both data paths: assembled
     CSR (the reference's) and matrix-free fine level.  OpenMP over ALL usable host cores (sched_getaffinity; an
@@ -344,13 +363,16 @@ def cpu_baseline(sample, rtol, fine_eig, gpu_el, gpu_ndof, budget_s, nlv=4, nsmo
     cores = int(os.environ["OMP_NUM_THREADS"])
     sel = tuple(int(v) for v in sample.split("x"))
     same0 = tuple(gpu_el) == sel
-    r = cpu_step(orc, sel, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, True, coarse_direct, extras_npz if same0 else None)
+    problem0 = problem
+    if problem and problem.get("rmin") and not same0:
+        problem = dict(problem, rmin=None)     # (an absolute radius belongs to the workload's element size; the sample mesh keeps 2.56 h)
+    r = cpu_step(orc, sel, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, True, coarse_direct, extras_npz if same0 else None, problem)
     est = (r["seconds"] + r["seconds_mf"]) * gpu_ndof / r["n_dof"]  # work per DOF and iteration count are close to mesh independent
     what = "%dx%dx%d elements (%d DOF -- NOT the GPU line's %d-DOF mesh: the same mesh was estimated at %.0f s, over the --cpu-budget of %.0f s)" % (
         sel + (r["n_dof"], gpu_ndof, est, budget_s))
     same = tuple(gpu_el) == sel
     if est <= budget_s and not same:
-        r = cpu_step(orc, tuple(gpu_el), rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, True, coarse_direct, extras_npz)
+        r = cpu_step(orc, tuple(gpu_el), rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, True, coarse_direct, extras_npz, problem0)
         same = True
     if same:
         what = "%dx%dx%d elements (%d DOF: the GPU line's mesh)" % (tuple(gpu_el) + (r["n_dof"],))
@@ -359,7 +381,7 @@ def cpu_baseline(sample, rtol, fine_eig, gpu_el, gpu_ndof, budget_s, nlv=4, nsmo
             "omp_num_threads": cores, "host": host,
             "sample_n_dof": nd, "gpu_line_n_dof": gpu_ndof, "seconds": t, "phase_seconds": r["phase_seconds"],
             "fx": r["fx"], "gx": r["gx"], "cg_its": r["its"], "rel_residual": r["rel_residual"], "hist": r["hist"],
-            "extras": r.get("extras") if same else None,
+            "extras": r.get("extras") if same else None, "problem": r.get("problem"),
             "matrix_free": {"value": nd / t_mf, "unit": "DOF-updates/s", "seconds": t_mf,
                             "what": "the same step with the fine-level operator of the solve applied from KE and the moduli (OpenMP gather over "
                                     "the 8 elements of a node) instead of the assembled CSR; Galerkin operators as before"},
@@ -458,6 +480,7 @@ def main():
         if not a.no_parity:
             extras_npz = cpu_json + ".extras.npz"
             cmd[-1] = extras_npz
+        cmd.append(json.dumps({"ftype": W.get("ftype", 1), "bc": W.get("bc", "cantilever"), "rmin": W.get("rmin")}))
         # How many threads, and where?  All hardware threads unbound is NOT the fastest way to run these memory-bound loops
         # (measured on the 2 x 64-core host of the GPU box, tools/r04_cpu_threads.sh: 256 threads 13.9 s, 128 bound to cores
         # 7.4 s, 64 spread over the cores 5.1 s per design iteration).  The baseline is the BEST of a short list, chosen on
@@ -485,7 +508,7 @@ def main():
                 if t < usable:
                     pe.update(OMP_PROC_BIND="spread", OMP_PLACES="cores")
                 pc = list(cmd)
-                pc[3], pc[11], pc[-1] = probe_json, "0", "-"      # (out file; budget 0: the sample mesh only; no parity extras)
+                pc[3], pc[11], pc[-2] = probe_json, "0", "-"      # (out file; budget 0: the sample mesh only; no parity extras)
                 try:
                     pp = subprocess.run(pc, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120, start_new_session=True, env=pe)
                     if pp.returncode == 0 and os.path.exists(probe_json):
@@ -692,13 +715,21 @@ def main():
                   "hist_compared": k, "bounds": dict(PARITY_BOUNDS)}
         breaches = []
         B = PARITY_BOUNDS
+        pde = ftype == 2
+        if pde:
+            # behind a Helmholtz filter the solver's input is itself the result of a solve to rtol 1e-8 (PDEFilter.cc:280): the
+            # two filtered densities agree to ~1e-9, and everything after them to what that leaves (tests/test_gpu_configs.py)
+            parity["note_pde"] = ("Helmholtz-filtered density: GPU and oracle each solve the filter equation to rtol 1e-8, the comparison "
+                                  "behind it is bounded by 'behind_pde_filter', not by the 1e-10 of the cone-filter workloads")
         if not parity["its_equal"]:
             breaches.append("its_equal")
-        if parity["gx_abs_err"] > B["gx_abs"]:
+        if parity["gx_abs_err"] > (B["behind_pde_filter"] if pde else B["gx_abs"]):
             breaches.append("gx_abs_err")
-        if parity["fx_rel_err"] > B["vs_oracle"]:
+        if parity["fx_rel_err"] > (B["behind_pde_filter"] if pde else B["vs_oracle"]):
             breaches.append("fx_rel_err")
-        if (parity["hist_max_rel_err_all"] or 0.0) > B["vs_oracle"]:
+        if pde and (parity["hist_max_rel_err_first10"] or 0.0) > B["behind_pde_filter"]:
+            breaches.append("hist_max_rel_err_first10")
+        if not pde and (parity["hist_max_rel_err_all"] or 0.0) > B["vs_oracle"]:
             breaches.append("hist_max_rel_err_all")
         ext = cpu_res.get("extras")
         if ext:
@@ -1010,7 +1041,7 @@ def main():
                    "solver_dof_its_per_s": ndof * info.get("solve_its", 0) / max(info.get("solve_s", 0.0), 1e-30),
                    "solve_ms_per_step": 1e3 * info.get("solve_s", 0.0) / max(a.steps, 1),
                    "mma_ms_per_update": mma_ms,
-                   "parallelism": "zslab%d" % world, "comm": grid.comm_kind, "comm_ranks": world,
+                   "parallelism": "zslab%d" % world, "comm": grid.comm_kind, "comm_ranks": world, "comm_report": grid.comm_report(),
                    "comm_calls": dict(zip(("halo_exchanges", "all_reduces"), grid.comm_stats())) if grid.comm_kind.startswith("rccl") else None,
                    "backend": (a.backend if world > 1 else None), "halo_overlap": grid.halo_overlap,
                    "scaling_note": "weak: %dx%dx%d elements per GPU" % (ex, ey, ezg) if a.scaling == "weak" else "strong: fixed %dx%dx%d mesh" % (ex, ey, ezg), "kernel_launches_per_step": launches / max(a.steps, 1),

@@ -126,6 +126,8 @@ int tp_grid_use_rccl(tp_grid *g, const void *id128);
  * does not order them behind the all-reduces of the solver's stream (one communicator = one queue) */
 int tp_grid_use_rccl2(tp_grid *g, const void *id128, const void *id128_halo);
 int tp_grid_comm_stats(const tp_grid *g, long *exchanges, long *reductions);   /* RCCL path only, else zeros */
+/* ranks the RCCL communicator itself reports (ncclCommCount; 0: no RCCL path, -1: unknown), second communicator in use */
+int tp_grid_comm_info(const tp_grid *g, int *rccl_ranks, int *two_communicators);
 /* The roofline kernel timed where it runs (bench.py): with on = 1 every launch of the fine level's fused operator +
  * Chebyshev step is bracketed by a pair of HIP events on the grid's stream; the read waits for the stream, returns
  * the summed elapsed time and the number of launches, and clears the list. */

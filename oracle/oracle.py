@@ -157,6 +157,22 @@ def cantilever_bc(nx, ny, nz, h):
     return N, R
 
 
+def mbb_bc(nx, ny, nz, load=-0.001):
+    """Half MBB beam (BASELINE config 4; SURVEY D5: the reference ships only the cantilever, this load case is data defined by
+    the build -- the same data as api.LinearElasticity.SetUpLoadAndBC_MBB): symmetry plane x = xmin (u_x = 0), roller along the
+    edge x = xmax, z = zmin (u_z = 0, one node also u_y = 0), line load in -z along the edge x = xmin, z = zmax with half loads
+    at the two end nodes.  -> (N, RHS)"""
+    N = np.ones((nz, ny, nx, 3))
+    R = np.zeros((nz, ny, nx, 3))
+    N[:, :, 0, 0] = 0.0
+    N[0, :, nx - 1, 2] = 0.0
+    N[0, 0, nx - 1, 1] = 0.0
+    R[nz - 1, :, 0, 2] = load
+    R[nz - 1, 0, 0, 2] = 0.5 * load
+    R[nz - 1, ny - 1, 0, 2] = 0.5 * load
+    return f64(N.reshape(-1)), f64(R.reshape(-1))
+
+
 def simp(x, Emin=1e-9, Emax=1.0, penal=3.0):
     x = f64(x)
     E = np.zeros_like(x)

@@ -45,7 +45,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert p["its_equal"] and p["its_gpu"] == cb["cg_its"], p
     assert p["gx_abs_err"] <= 1e-13, p
     # the bounds bench.py itself enforces (exit code 4 on a breach)
-    assert p["bounds"] == {"vs_arbiter_on_own_operator": 1e-10, "element_matrix": 1e-15, "vs_oracle": 1e-9, "gx_abs": 1e-13}
+    assert p["bounds"] == {"vs_arbiter_on_own_operator": 1e-10, "element_matrix": 1e-15, "vs_oracle": 1e-9, "gx_abs": 1e-13, "behind_pde_filter": 1e-6}
     # (2) the operator the kernels apply: the library's export is the restatement the arbiter ran on, and it is KE to 1e-15
     em = p["element_matrix"]
     assert em["library_export_equals_restatement"] is True and 0 < em["KE_eff_vs_KE"] <= 1e-15 and em["row_sum_defect_KE_eff"] == 0.0, em
@@ -88,6 +88,8 @@ def _check_two_rank_line(r, scaling):
     ez = 32 if scaling == "weak" else 16
     assert "32x16x%d elements" % ez in d["config"]["workload"]
     assert "cpu_baseline" not in d          # rank 0 of a 1-GPU job only
+    cr = d["config"]["comm_report"]         # (gloo + host staging here: no RCCL communicator to report ranks)
+    assert cr["ranks"] == 2 and cr["rccl_ranks_seen"] == 0 and "hooks" in cr["path"]
     # the complementary reading of the metric is timed in the same run
     o = d["other_scaling"]
     assert o["scaling"] == ("strong" if scaling == "weak" else "weak") and o["value"] > 0 and o["cg_its"] > 0

@@ -121,6 +121,14 @@ class Grid:
         self.L.tp_grid_comm_stats(self.handle, C.byref(ex), C.byref(red))
         return ex.value, red.value
 
+    def comm_report(self):
+        """what the slab exchange runs on, for the bench line: path, the ranks the RCCL communicator itself reports, whether
+        the in-library path passed its collective self-check (or why the grid went back to the host-staged hooks)"""
+        n, two = C.c_int(0), C.c_int(0)
+        self.L.tp_grid_comm_info(self.handle, C.byref(n), C.byref(two))
+        return {"path": self.comm_kind, "ranks": self.part.nranks, "rccl_ranks_seen": n.value, "two_communicators": bool(two.value),
+                "selfcheck": getattr(self, "_rccl_selfcheck", "not run (no in-library RCCL path requested)" if self.part.nranks > 1 else "one rank")}
+
     def reduction_selftest(self, n, reps):
         """`reps` back-to-back dot products over n doubles, in-kernel reduction tail against the two-launch form: mismatches"""
         bad = C.c_int(0)
@@ -155,6 +163,7 @@ class Grid:
         flag = torch.tensor([1 if ok else 0], device=self.device, dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
         if int(flag[0]) == 0:
+            self._rccl_selfcheck = "not run: librccl.so could not be loaded on some rank -> torch.distributed hooks"
             return
         obj = [idbuf.raw + idbuf2.raw if self.part.rank == 0 else None]
         src = 0 if group is None else dist.get_global_rank(group, 0)
@@ -173,6 +182,7 @@ class Grid:
         if int(flag[0]) == 0:   # some rank could not create its communicator: every rank goes back to the hooks
             self.L.tp_grid_drop_rccl(self.handle)
             print("topopt_amd: tp_grid_use_rccl failed on a rank; using the torch.distributed hooks", flush=True)
+            self._rccl_selfcheck = "not run: ncclCommInitRank failed on some rank -> torch.distributed hooks"
             return
         # trust, but verify: rank-tagged planes through the new path; any rank unhappy -> everybody back to the hooks
         ok = C.c_int(0)
@@ -182,7 +192,9 @@ class Grid:
         if int(flag[0]) == 0:
             self.L.tp_grid_drop_rccl(self.handle)
             print("topopt_amd: in-library RCCL exchange failed its self-check; using the torch.distributed hooks", flush=True)
+            self._rccl_selfcheck = "fail -> fallback to the torch.distributed hooks"
             return
+        self._rccl_selfcheck = "pass"
         self.comm_kind = "rccl (in-library)"
 
     def _adopt(self, child):

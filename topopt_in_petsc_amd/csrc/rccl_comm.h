@@ -23,6 +23,7 @@ struct RcclApi {
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;  // optional: what the communicator itself says it spans
 };
 inline RcclApi &rccl_api() {
     static RcclApi a;
@@ -125,6 +126,7 @@ inline int rccl_load(const char *path) {
     TP_SYM(AllGather, "ncclAllGather")
     TP_SYM(GetErrorString, "ncclGetErrorString")
 #undef TP_SYM
+    *(void **)(&A.CommCount) = dlsym(h, "ncclCommCount");  // (reporting only)
     A.handle = h;
     return TP_OK;
 }

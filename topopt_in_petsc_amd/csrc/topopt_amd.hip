@@ -240,6 +240,19 @@ extern "C" int tp_grid_comm_stats(const tp_grid *g, long *ex, long *red) {
     if (red) *red = g->rccl ? g->rccl->n_reductions : 0;
     return TP_OK;
 }
+// what the in-library RCCL path is made of, for the bench line: ranks the COMMUNICATOR reports (ncclCommCount; -1 if the
+// entry point is missing, 0 without RCCL), and whether the neighbour exchanges have a communicator of their own
+extern "C" int tp_grid_comm_info(const tp_grid *g, int *rccl_ranks, int *two_communicators) {
+    if (!g) return TP_ERR_ARG;
+    int n = 0;
+    if (g->rccl && g->rccl->comm) {
+        n = -1;
+        if (rccl_api().CommCount && rccl_api().CommCount(g->rccl->comm, &n) != ncclSuccess) n = -1;
+    }
+    if (rccl_ranks) *rccl_ranks = n;
+    if (two_communicators) *two_communicators = g->rccl && g->rccl->comm_halo ? 1 : 0;
+    return TP_OK;
+}
 __global__ void k_selftest_fill(double *p, long n, double base) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = base + (double)i;
 }

@@ -61,6 +61,7 @@ SYMBOLS = {
     "tp_grid_use_rccl": (_i, [_vp, _vp]),
     "tp_grid_use_rccl2": (_i, [_vp, _vp, _vp]),
     "tp_grid_comm_stats": (_i, [_vp, C.POINTER(_l), C.POINTER(_l)]),
+    "tp_grid_comm_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "tp_grid_kernel_timer": (_i, [_vp, _i]),
     "tp_grid_kernel_timer_read": (_i, [_vp, C.POINTER(_d), C.POINTER(_l)]),
     "tp_grid_kernel_timer_read2": (_i, [_vp, C.POINTER(_d), C.POINTER(_l), C.POINTER(_d)]),
