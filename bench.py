@@ -467,7 +467,12 @@ def main():
         import subprocess
         import tempfile
         ex0, ey0, ez0 = W["el"]
-        direct_guess = int(a.coarse == "direct")
+        # will the library solve the coarsest level exactly?  Its rule (csrc/mg.h: coarse_direct_ok with coarse_direct = 1): a stored
+        # stencil level of 449 .. 4096 rows whose half bandwidth fits 12 blocks of 32 -- the oracle must run the same cycle
+        cdiv = 1 << (nlv - 1)
+        cnx, cny, cnz = ex0 // cdiv + 1, ey0 // cdiv + 1, ez0 // cdiv + 1
+        crow, chb = 3 * cnx * cny * cnz, 3 * (cnx * cny + cnx + 1) + 2
+        direct_guess = int(a.coarse == "direct" and nlv >= 2 and 448 < crow <= 4096 and (chb + 31) // 32 <= 12)
         fd, cpu_json = tempfile.mkstemp(suffix=".json", prefix="tp_cpu_baseline_")
         os.close(fd)
         os.unlink(cpu_json)
