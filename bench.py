@@ -1058,8 +1058,9 @@ def main():
     if other is not None:
         out["other_scaling"] = other
     if parity is not None:
-        if bool(coarse_is_direct) != (a.coarse == "direct"):
-            parity["note"] = "the GPU fell back to the Chebyshev coarse run while the CPU baseline solved the coarsest level exactly: cycles differ"
+        if bool(coarse_is_direct) != bool(direct_guess):
+            parity["note"] = "the library's choice of the coarse solve (%s) is not what the CPU baseline was told to run (%s): cycles differ" % (
+                "exact" if coarse_is_direct else "Chebyshev run", "exact" if direct_guess else "Chebyshev run")
         out["parity"] = parity
     if cpu_res is not None:
         cpu_res.pop("hist", None)

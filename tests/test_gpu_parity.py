@@ -809,29 +809,3 @@ def test_effective_element_matrix(tp, orc):
     assert np.abs(yt).max() == 0.0
     assert np.abs(orc.matfree_apply(nx, ny, nz, 3, KE, None, None, t)).max() > 0.0
     grid.close()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("mesh", [(40, 24, 20), (64, 64, 32), (16, 8, 8)])
-def test_tiled_restriction_bits(tp, mesh):
-    """k_restrict_tiled (LDS-staged fine neighbourhood, csrc/operators.h; the V-cycle's form between the fine level and level 1 on
-    large meshes) == k_restrict bit for bit, on meshes whose coarse grids do not fill whole 16 x 4 x 4 tiles (both level pairs)."""
-    ex, ey, ez = mesh
-    nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
-    grid = tp.Grid(nx, ny, nz, h)
-    le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=3, rtol=1e-8, nsmooth=2, ncoarse=20))
-    le.SetUpLoadAndBC()
-    le.AssembleStiffnessMatrix(grid.synth_density(), 1e-9, 1.0, 3.0)
-    rf = grid.node_vec(3).normal_()
-    out = {}
-    try:
-        for form in ("0", "1"):
-            os.environ["TP_RESTRICT_TILED"] = form
-            r1 = le.restrict(0, rf).clone()
-            out[form] = [r1, le.restrict(1, r1).clone()]
-    finally:
-        os.environ.pop("TP_RESTRICT_TILED", None)
-    for l in range(2):
-        assert torch.equal(out["0"][l], out["1"][l]), l
-    assert float(out["1"][0].abs().max()) > 0
-    grid.close()

@@ -1390,19 +1390,9 @@ struct MGSolver {
                                 (l + 1 == nlv - 1 ? opt.ncoarse : opt.nsmooth) >= 1;
         double th = 1.0, de = 1.0;
         if (fuse_first) cheb_window(l + 1, &th, &de);
-        // large level pairs: the LDS-tiled form (operators.h; same bits) -- TP_RESTRICT_TILED=0 / 1 forces the choice
-        static const int rt_env = getenv("TP_RESTRICT_TILED") ? atoi(getenv("TP_RESTRICT_TILED")) : -1;
-        const bool tiled = DOF == 3 && (rt_env >= 0 ? rt_env != 0 : L.g.owned_nodes() >= 400000);
         auto restrict_planes = [&](int p0, int np) -> int {
-            if (tiled) {
-                const dim3 gd((C.g.nx + RT_CX - 1) / RT_CX, (C.g.ny + RT_CY - 1) / RT_CY, (np + RT_CZ - 1) / RT_CZ);
-                TP_LAUNCH((k_restrict_tiled<DOF>), gd, dim3(RT_CX * RT_CY * RT_CZ), 0, grid->stream, C.g, L.g, L.r, C.b,
-                          fuse_first ? C.dinv : nullptr, fuse_first ? C.x : nullptr, fuse_first && !three_term(C) ? C.d : nullptr,
-                          1.0 / th, p0, np);
-                return TP_OK;
-            }
             const long cpl = C.g.plane();
-                TP_LAUNCH((k_restrict<DOF>), dim3((int)((cpl * np + BLK - 1) / BLK)), dim3(BLK), 0, grid->stream, C.g, L.g, L.r, C.b,
+            TP_LAUNCH((k_restrict<DOF>), dim3((int)((cpl * np + BLK - 1) / BLK)), dim3(BLK), 0, grid->stream, C.g, L.g, L.r, C.b,
                       fuse_first ? C.dinv : nullptr, fuse_first ? C.x : nullptr, fuse_first && !three_term(C) ? C.d : nullptr,
                       1.0 / th, cpl * (p0 - C.g.own_lo), cpl * np);
             return TP_OK;

@@ -293,95 +293,11 @@ __global__ __launch_bounds__(BLK) void k_restrict(Geom gc, Geom gf, const double
     }
 }
 
-// The same restriction for the large level pairs (fine level -> level 1), LDS tiled (round 5).  k_restrict's 27 x DOF loads
-// per coarse node walk the fine vector with a 2-node stride across the lanes: every wave-wide load touches 24 cache lines for
-// 512 useful bytes, every fine value passes the L1 3.4 times, and the kernel ends up at 0.26 of the HBM rate (27.8 us for
-// 58 MB at 128^3).  Here a workgroup owns RT_CX x RT_CY x RT_CZ coarse nodes, stages their (2 RT_CX + 1) x (2 RT_CY + 1) x
-// (2 RT_CZ + 1) fine neighbourhood ONCE with row-contiguous loads (zeros outside the array), and every thread then sums its 27
-// neighbours out of LDS -- in the order of k_restrict, with its weights (a neighbour outside the array: weight 0 on a staged
-// zero): bit for bit the same result.  LDS rows of a y-pair are offset by one double so that the two J-rows a half wave reads
-// fall on the even and the odd double-banks (the x stride of 2 DOF doubles alone fills the even ones).
-constexpr int RT_CX = 16, RT_CY = 4, RT_CZ = 4;
-template <int DOF>
-__global__ __launch_bounds__(RT_CX * RT_CY * RT_CZ) void k_restrict_tiled(Geom gc, Geom gf, const double *__restrict__ rf,
-                                                                            double *__restrict__ bc, const double *__restrict__ dinv_c,
-                                                                            double *__restrict__ x_c, double *__restrict__ d_c,
-                                                                            double inv_theta, int K_first, int K_count) {
-    constexpr int FX = 2 * RT_CX + 1, FY = 2 * RT_CY + 1, FZ = 2 * RT_CZ + 1, ROW = FX * DOF, RS = ROW + 1;
-    constexpr int NT = RT_CX * RT_CY * RT_CZ, NW = NT / WAVE;
-    __shared__ double s_f[FZ * FY * RS + FY];
-    auto row_off = [](int z, int y) { return (z * FY + y) * RS + ((y >> 1) & 1); };
-    // coarse origin of this tile (x, y: whole plane; z: the owned planes [K_first, K_first + K_count) in chunks of RT_CZ)
-    const int I0 = blockIdx.x * RT_CX, J0 = blockIdx.y * RT_CY, K0 = K_first + blockIdx.z * RT_CZ;
-    const int fi0 = 2 * I0 - 1, fj0 = 2 * J0 - 1, fk0 = 2 * K0 - 1;
-    {  // stage: wave w takes the rows w, w + NW, ...; a lane takes the columns lane, lane + 64, ... of the row.  ALL loads of
-        // the thread are issued before the first LDS store (one memory round trip, not one per row: the first version of this
-        // kernel waited row by row and took 56 us)
-        constexpr int NR = (FZ * FY + NW - 1) / NW, NC = (ROW + WAVE - 1) / WAVE;
-        const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
-        double v[NR][NC];
-#pragma unroll
-        for (int q = 0; q < NR; q++) {
-            const int row = w + q * NW;
-            const int z = row / FY, y = row - z * FY;
-            const int k = fk0 + z, j = fj0 + y;
-            const bool okr = row < FZ * FY && k >= 0 && k < gf.nzl && j >= 0 && j < gf.ny;
-            const long base = ((long)gf.nx * (j + (long)gf.ny * k) + fi0) * DOF;
-#pragma unroll
-            for (int cc = 0; cc < NC; cc++) {
-                const int c = cc * WAVE + lane, i = fi0 + c / DOF;
-                v[q][cc] = (okr && c < ROW && i >= 0 && i < gf.nx) ? rf[base + c] : 0.0;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < NR; q++) {
-            const int row = w + q * NW;
-            const int z = row / FY, y = row - z * FY;
-#pragma unroll
-            for (int cc = 0; cc < NC; cc++) {
-                const int c = cc * WAVE + lane;
-                if (row < FZ * FY && c < ROW) s_f[row_off(z, y) + c] = v[q][cc];
-            }
-        }
-    }
-    __syncthreads();
-    const int ti = threadIdx.x % RT_CX, tj = (threadIdx.x / RT_CX) % RT_CY, tk = threadIdx.x / (RT_CX * RT_CY);
-    const int I = I0 + ti, J = J0 + tj, K = K0 + tk;
-    if (I >= gc.nx || J >= gc.ny || K >= K_first + K_count) return;
-    double s[DOF];
-#pragma unroll
-    for (int r = 0; r < DOF; r++) s[r] = 0.0;
-#pragma unroll
-    for (int dk = -1; dk <= 1; dk++) {
-        const int k = 2 * K + dk;
-        const bool okk = k >= 0 && k < gf.nzl;
-#pragma unroll
-        for (int dj = -1; dj <= 1; dj++) {
-            const int j = 2 * J + dj;
-            const bool okj = okk && j >= 0 && j < gf.ny;
-            const double *row = s_f + row_off(2 * tk + 1 + dk, 2 * tj + 1 + dj) + (2 * ti + 1) * DOF;
-#pragma unroll
-            for (int di = -1; di <= 1; di++) {
-                const int i = 2 * I + di;
-                const bool ok = okj && i >= 0 && i < gf.nx;
-                const double w = ok ? (di ? 0.5 : 1.0) * (dj ? 0.5 : 1.0) * (dk ? 0.5 : 1.0) : 0.0;
-#pragma unroll
-                for (int r = 0; r < DOF; r++) s[r] = fma(w, row[di * DOF + r], s[r]);
-            }
-        }
-    }
-    const long nc = (long)I + (long)gc.nx * (J + (long)gc.ny * K);
-#pragma unroll
-    for (int r = 0; r < DOF; r++) {
-        bc[nc * DOF + r] = s[r];
-        if (x_c) {
-            const double v = dinv_c[nc * DOF + r] * s[r] * inv_theta;
-            x_c[nc * DOF + r] = v;
-            if (d_c) d_c[nc * DOF + r] = v;
-        }
-    }
-}
-
+// (Round 5, measured and dropped: the same restriction LDS tiled -- a workgroup of 16 x 4 x 4 coarse nodes stages its
+// 33 x 9 x 9 fine neighbourhood with row-contiguous loads, all issued before the first LDS store, and sums out of LDS in this
+// kernel's order, bit-equal.  At 128^3: 42 us against this kernel's 27.8 us (56 us with the rows staged one round trip at a
+// time).  The gather's 3.4-fold re-reads are L1/L2 hits that overlap with each other; the tiled form pays a load phase, a
+// barrier and a compute phase in sequence on two workgroups per CU.)
 // fine x_f += P x_c ; owned fine nodes
 template <int DOF>
 __global__ __launch_bounds__(BLK) void k_prolong_add(Geom gc, Geom gf, const double *__restrict__ xc,

@@ -1320,16 +1320,7 @@ extern "C" int tp_elasticity_restrict(tp_elasticity *e, int l, const double *rf,
     MGSolver<3> &mg = e->mg;
     if (l < 0 || l + 1 >= mg.nlv) return TP_ERR_ARG;
     TP_TRY(mg.halo(l, const_cast<double *>(rf)));
-    // the form the V-cycle would pick for this level pair (mg.h: vcycle) -- TP_RESTRICT_TILED is read per call here, so that a
-    // test can put the two forms side by side in one process
-    const char *env = getenv("TP_RESTRICT_TILED");
     const Geom &C = mg.lv[l + 1].g;
-    if (env ? atoi(env) != 0 : mg.lv[l].g.owned_nodes() >= 400000) {
-        const int np = C.own_hi - C.own_lo + 1;
-        TP_LAUNCH((k_restrict_tiled<3>), dim3((C.nx + RT_CX - 1) / RT_CX, (C.ny + RT_CY - 1) / RT_CY, (np + RT_CZ - 1) / RT_CZ),
-                  dim3(RT_CX * RT_CY * RT_CZ), 0, e->grid->stream, C, mg.lv[l].g, rf, rc, nullptr, nullptr, nullptr, 0.0, C.own_lo, np);
-        return TP_OK;
-    }
     TP_LAUNCH((k_restrict<3>), dim3((int)((C.owned_nodes() + BLK - 1) / BLK)), dim3(BLK), 0,
                        e->grid->stream, C, mg.lv[l].g, rf, rc);
     return TP_OK;
