@@ -6,7 +6,7 @@ rows = con.execute("select name, start, end, grid_x, workgroup_x from kernels or
 obj = [i for i, r in enumerate(rows) if r[0].startswith("k_objective")]
 if len(obj) >= 2:
     rows = rows[obj[-2]:obj[-1]]
-xr = [i for i, r in enumerate(rows) if r[0].startswith("k_cg_update_xr")]
+xr = [i for i, r in enumerate(rows) if "k_cg_update_xr" in r[0][:40]]
 seg = rows[xr[-3]:xr[-2] + 1]
 t0 = seg[0][1]
 prev_end = seg[0][1]

@@ -5,7 +5,7 @@ import sqlite3, sys, collections
 con = sqlite3.connect(sys.argv[1])
 rows = con.execute("select name, start, end, stream_id from kernels order by start").fetchall()
 # the solve after the assemblies starts with k_cheb_first / k_cg...: take the last k_simp before the first CG kernel
-cg = next((i for i, r in enumerate(rows) if r[0].startswith("k_cg_") or r[0].startswith("k_cheb_first")), len(rows))
+cg = next((i for i, r in enumerate(rows) if ("k_cg_" in r[0][:20]) or r[0].startswith("k_cheb_first")), len(rows))
 simp = [i for i, r in enumerate(rows[:cg]) if r[0].startswith("k_simp")]
 i0 = simp[-1]
 seg = rows[i0:cg]
