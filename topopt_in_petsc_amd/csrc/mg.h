@@ -1565,10 +1565,7 @@ struct MGSolver {
                 if (!fused) TP_LAUNCH(k_pw_mult, dim3(grid_for(n)), dim3(BLK), 0, s, w + off, dis + off, w + off, n);
             }
             if (fused) {
-                // (one workgroup per 256 rows up to 2048 workgroups: the loop of a thread is a chain of dependent round trips,
-                // so the stage wants as many threads in flight as the partials buffer allows -- with 256 workgroups, as the
-                // separate dot kernels use per vector, the fused stages were 0.45 ms SLOWER per design iteration than those)
-                const int nbf = n <= 2048 ? 1 : grid_for(n, 2048);
+                const int nbf = n <= 65536 ? 1 : grid_for(n, 256);
                 const double *dsc = scaled_apply ? nullptr : dis;
                 TP_LAUNCH((k_lanczos_gs<0>), dim3(nbf), dim3(BLK), 0, s, V, nd, j + 1, w, off, n, dsc, nullptr, nullptr, nullptr, part, B.ticket, h1);
                 TP_TRY(allreduce_dev(h1, j + 1, L.no_comm));
