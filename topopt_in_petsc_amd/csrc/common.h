@@ -196,37 +196,6 @@ __device__ inline void reduce_tail(const double (&mine)[NV], double *__restrict_
     if (threadIdx.x == 0) __hip_atomic_store(ticket + 8 * TICKET_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// The same tail for a number of values known at run time only (the Gram-Schmidt coefficients of a Lanczos step): the NV
-// partials of this workgroup come from LDS (`mine`, written by thread 0 before the call).  Same hand-off, same summation order.
-__device__ inline void reduce_tail_rt(const double *mine, int nv, double *__restrict__ partials, int nb, int b, unsigned *ticket,
-                                      double *__restrict__ out) {
-    __shared__ int s_last_rt;
-    if (threadIdx.x == 0) {
-        for (int v = 0; v < nv; v++) __hip_atomic_store(&partials[(long)v * nb + b], mine[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int sh = b & 7;
-        const unsigned in_shard = (unsigned)((nb + 7 - sh) >> 3);
-        int last = 0;
-        unsigned *mine_t = ticket + sh * TICKET_STRIDE, *top_t = ticket + 8 * TICKET_STRIDE;
-        if (__hip_atomic_fetch_add(mine_t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1) {
-            __hip_atomic_store(mine_t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned shards = (unsigned)(nb < 8 ? nb : 8);
-            last = __hip_atomic_fetch_add(top_t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards - 1;
-        }
-        s_last_rt = last;
-    }
-    __syncthreads();
-    if (!s_last_rt) return;
-    for (int v = 0; v < nv; v++) {
-        double s = 0.0;
-        for (int i = threadIdx.x; i < nb; i += BLK)
-            s += __hip_atomic_load(&partials[(long)v * nb + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s = block_sum(s);
-        if (threadIdx.x == 0) out[v] = s;
-    }
-    if (threadIdx.x == 0) __hip_atomic_store(ticket + 8 * TICKET_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // partials laid out [value][block]; out[v] = sum_b partials[v*nblocks + b]
 template <int NV>
 __global__ __launch_bounds__(BLK) void k_reduce_final(const double *__restrict__ partials, int nblocks,

@@ -173,58 +173,6 @@ __global__ __launch_bounds__(BLK) void k_multi_axpy(const double *__restrict__ V
         w[off + i] = acc;
     }
 }
-// One Gram-Schmidt stage of a Lanczos step in ONE launch (round 5; was: axpy, dot products, their reduction -- three launches):
-//   STAGE 0:  w <- dis .* w (where the operator did not scale its output itself: `dis` non-null), h[q] = V_q . w      q < nv
-//   STAGE 1:  w <- w - sum_q hprev[q] V_q,                                             h[q] = V_q . w      q < nv
-//   STAGE 2:  w <- w - sum_q hprev[q] V_q,  alpha[nv-1] = hfirst[nv-1] + hprev[nv-1],   h[0] = w . w
-// Every V_q[i] is loaded once and used for the update and for the product; the sums are finished by the last workgroup to
-// arrive (reduce_tail_rt: fixed order, bit-reproducible run to run).  nv <= LGS_MAXV (the 10-step runs of the smoothing levels;
-// longer runs keep the separate kernels).
-constexpr int LGS_MAXV = 12;
-template <int STAGE>
-__global__ __launch_bounds__(BLK) void k_lanczos_gs(const double *__restrict__ V, long stride, int nv, double *__restrict__ w,
-                                                    long off, long n, const double *__restrict__ dis,
-                                                    const double *__restrict__ hprev, const double *__restrict__ hfirst,
-                                                    double *__restrict__ alpha, double *__restrict__ partials, unsigned *ticket,
-                                                    double *__restrict__ hout) {
-    __shared__ double s_mine[LGS_MAXV];
-    double hp[LGS_MAXV], acc[LGS_MAXV];
-#pragma unroll
-    for (int q = 0; q < LGS_MAXV; q++) {
-        hp[q] = (STAGE >= 1 && q < nv) ? hprev[q] : 0.0;
-        acc[q] = 0.0;
-    }
-    if (STAGE == 2 && blockIdx.x == 0 && threadIdx.x == 0) alpha[nv - 1] = hfirst[nv - 1] + hprev[nv - 1];
-    for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
-        double wi = w[off + i];
-        double vq[LGS_MAXV];
-#pragma unroll
-        for (int q = 0; q < LGS_MAXV; q++) vq[q] = q < nv ? V[(long)q * stride + off + i] : 0.0;
-        if (STAGE == 0) {
-            if (dis) wi *= dis[off + i];
-        } else {
-#pragma unroll
-            for (int q = 0; q < LGS_MAXV; q++) wi = fma(-hp[q], vq[q], wi);
-        }
-        if (STAGE != 0 || dis) w[off + i] = wi;
-        if (STAGE == 2) {
-            acc[0] = fma(wi, wi, acc[0]);
-        } else {
-#pragma unroll
-            for (int q = 0; q < LGS_MAXV; q++) acc[q] = fma(vq[q], wi, acc[q]);
-        }
-    }
-    const int nout = STAGE == 2 ? 1 : nv;
-#pragma unroll
-    for (int q = 0; q < LGS_MAXV; q++) {
-        if (q < nout) {   // (uniform)
-            const double t = block_sum(acc[q]);
-            if (threadIdx.x == 0) s_mine[q] = t;
-        }
-    }
-    __syncthreads();
-    reduce_tail_rt(s_mine, nout, partials, gridDim.x, blockIdx.x, ticket, hout);
-}
 // alpha[j] = h1[j] + h2[j]
 __global__ void k_lanczos_alpha(const double *__restrict__ h1, const double *__restrict__ h2, int j,
                                 double *__restrict__ alpha) {
@@ -587,7 +535,6 @@ struct MGSolver {
             (void)hipFree(b.V);
             (void)hipFree(b.coef);
             (void)hipFree(b.part);
-            (void)hipFree(b.ticket);
             (void)hipHostFree(b.hc);
             b = LanBuf();
         }
@@ -612,7 +559,6 @@ struct MGSolver {
     // host copy of the coefficients; the runs of different levels are independent and may share the device
     struct LanBuf {
         double *V = nullptr, *coef = nullptr, *part = nullptr, *hc = nullptr;
-        unsigned *ticket = nullptr;   // arrival counters of this chain's own reduction tails (the chains of the levels run side by side)
         size_t cap = 0;
         int m = 0;
     };
@@ -1525,15 +1471,6 @@ struct MGSolver {
         if (!B.coef) TP_HIP(hipMalloc((void **)&B.coef, sizeof(double) * 520));
         if (!B.part) TP_HIP(hipMalloc((void **)&B.part, sizeof(double) * 256 * 130));
         if (!B.hc) TP_HIP(hipHostMalloc((void **)&B.hc, sizeof(double) * 520));
-        if (!B.ticket) {
-            TP_HIP(hipMalloc((void **)&B.ticket, sizeof(unsigned) * TICKET_WORDS));
-            TP_HIP(hipMemset(B.ticket, 0, sizeof(unsigned) * TICKET_WORDS));
-        }
-        // round 5: the Gram-Schmidt stages as one launch each (k_lanczos_gs) -- 12 -> 6 launches per step on level 1, 10 -> 5 on
-        // the stencil levels; TP_LANCZOS_FUSED=0: the separate kernels (also taken for runs longer than LGS_MAXV - 1 steps and
-        // when the in-kernel reduction tails are switched off)
-        static const bool fused_env = !(getenv("TP_LANCZOS_FUSED") && atoi(getenv("TP_LANCZOS_FUSED")) == 0);
-        const bool fused = fused_env && steps + 1 <= LGS_MAXV && tail_ticket(grid) != nullptr;
         double *V = B.V, *coef = B.coef, *part = B.part;
         auto multi_dot = [&](const double *A, int nv, const double *wv, double *out) -> int {
             TP_LAUNCH(k_multi_dot, dim3(nb, nv), dim3(BLK), 0, s, A, nd, nv, wv, off, n, nb == 1 ? out : part);
@@ -1562,20 +1499,7 @@ struct MGSolver {
                 TP_TRY(op<EPI_APPLY>(l, a));
             } else {
                 TP_TRY(apply(l, t, w));
-                if (!fused) TP_LAUNCH(k_pw_mult, dim3(grid_for(n)), dim3(BLK), 0, s, w + off, dis + off, w + off, n);
-            }
-            if (fused) {
-                const int nbf = n <= 65536 ? 1 : grid_for(n, 256);
-                const double *dsc = scaled_apply ? nullptr : dis;
-                TP_LAUNCH((k_lanczos_gs<0>), dim3(nbf), dim3(BLK), 0, s, V, nd, j + 1, w, off, n, dsc, nullptr, nullptr, nullptr, part, B.ticket, h1);
-                TP_TRY(allreduce_dev(h1, j + 1, L.no_comm));
-                TP_LAUNCH((k_lanczos_gs<1>), dim3(nbf), dim3(BLK), 0, s, V, nd, j + 1, w, off, n, nullptr, h1, nullptr, nullptr, part, B.ticket, h2);
-                TP_TRY(allreduce_dev(h2, j + 1, L.no_comm));
-                TP_LAUNCH((k_lanczos_gs<2>), dim3(nbf), dim3(BLK), 0, s, V, nd, j + 1, w, off, n, nullptr, h2, h1, al, part, B.ticket, bb);
-                TP_TRY(allreduce_dev(bb, 1, L.no_comm));
-                TP_LAUNCH(k_lanczos_next, dim3(grid_for(n)), dim3(BLK), 0, s, w, bb, j, be, V + (size_t)(j + 1) * nd, off, n, dis, t);
-                grid->launches += 4;
-                continue;
+                TP_LAUNCH(k_pw_mult, dim3(grid_for(n)), dim3(BLK), 0, s, w + off, dis + off, w + off, n);
             }
             for (int pass = 0; pass < 2; pass++) {
                 double *h = pass ? h2 : h1;
