@@ -809,3 +809,59 @@ def test_effective_element_matrix(tp, orc):
     assert np.abs(yt).max() == 0.0
     assert np.abs(orc.matfree_apply(nx, ny, nz, 3, KE, None, None, t)).max() > 0.0
     grid.close()
+
+
+@pytest.mark.gpu
+def test_bench_cycle_against_the_arbiter_on_the_operator_the_kernels_apply(tp, orc):
+    """DESIGN 2.1 as a test of the suite (the bench line asserts the same at 128^3): a 64 x 32 x 32 cantilever with the bench's
+    cycle (4 levels, Chebyshev(2), level 2 cycled three times, exact coarse solve).  Against the oracle rebuilt in 80-bit
+    arithmetic (oracle/arbiter.py) ON KE_eff -- the element matrix the fine-level kernels apply, as the library exports it --
+    the residual history, the compliance at rtol 1e-5 and the converged compliance / raw sensitivities agree to 1e-11; against
+    the same arbiter on the reference's KE the agreement is set by what that change of operator does to the arbiter itself."""
+    from oracle import arbiter as arb
+    ex, ey, ez, nlv, cyc = 64, 32, 32, 4, [1, 3, 1]
+    nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
+    grid = tp.Grid(nx, ny, nz, h)
+    x = grid.synth_density()
+    flt = tp.Filter(grid, 1, 2.56 * h)
+    xt, xp = grid.elem_vec(), grid.elem_vec()
+    flt.FilterProject(x, xt, xp)
+    xpn = xp.cpu().numpy()
+    out = {}
+    for rtol in (1e-5, 1e-12):
+        le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=nlv, rtol=rtol, nsmooth=2, ncoarse=20, coarse_direct=2))
+        le.set_cycles(cyc)
+        le.SetUpLoadAndBC()
+        df, dg = grid.elem_vec(), grid.elem_vec()
+        fx, _ = le.ComputeObjectiveConstraintsSensitivities(df, dg, xp, 1e-9, 1.0, 3.0, 0.12, hist_cap=200)
+        out[rtol] = (le.last_its, np.array(le.last_hist), fx, df.cpu().numpy())
+        kf, KE = le.KE_effective(), le.KE
+        le.close()
+    N, R = orc.cantilever_bc(nx, ny, nz, h)
+    E = orc.simp(xpn)
+
+    def arbiter(K):
+        mg = arb.MG(nx, ny, nz, 3, nlv, 2, 20)
+        mg.set_coarse_direct(True)
+        mg.set_cycles(cyc)
+        mg.assemble(K, E, N)
+        res = {}
+        for rtol in (1e-5, 1e-12):
+            U, its, hist = mg.solve(arb.f64(R * N), rtol=rtol)
+            fx, _, df, _ = arb.compliance_sens(nx, ny, nz, KE, U, xpn)
+            res[rtol] = (its, np.asarray(hist, dtype=np.float64), float(fx), np.asarray(df, dtype=np.float64))
+        return res
+
+    a_eff, a_ke = arbiter(kf), arbiter(KE)
+    for rtol in (1e-5, 1e-12):
+        its, hist, fx, df = out[rtol]
+        assert its == a_eff[rtol][0] == a_ke[rtol][0]
+        assert abs(fx / a_eff[rtol][2] - 1) <= 1e-11, (rtol, fx, a_eff[rtol][2])
+    assert np.abs(out[1e-5][1] / a_eff[1e-5][1] - 1).max() <= 1e-11
+    scale = np.abs(a_eff[1e-12][3]).max()
+    assert np.abs(out[1e-12][3] - a_eff[1e-12][3]).max() <= 1e-11 * scale
+    # the operator's share: GPU vs arbiter on KE == arbiter on KE_eff vs arbiter on KE (to the 1e-11 above), and it is there
+    gap_gpu = abs(out[1e-12][2] / a_ke[1e-12][2] - 1)
+    gap_arb = abs(a_eff[1e-12][2] / a_ke[1e-12][2] - 1)
+    assert gap_arb > 1e-13 and abs(gap_gpu - gap_arb) <= 1e-11 and gap_gpu <= 1e-10
+    grid.close()
