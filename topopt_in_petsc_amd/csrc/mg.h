@@ -746,23 +746,51 @@ struct MGSolver {
             flops = 2.0 * (8 * DOF) * (8 * DOF) * (double)L.g.own_elems();
         } else {
             DiaOp<DOF> o{L.S, L.ndof(), L.g};
-            int nbr = (int)((nown * DOF + BLK - 1) / BLK);
+            const long rows_all = nown * DOF;
+            // the row split (how many threads share a row) follows the size of the LEVEL, not of the launch: the boundary-first
+            // launches below must sum every row in the order the single launch would
+            const int nbr_all = (int)((rows_all + BLK - 1) / BLK);
             static const int split_env = getenv("TP_DIA_SPLIT") ? atoi(getenv("TP_DIA_SPLIT")) : -1;
-            const int split = split_env >= 0 ? split_env : (nbr < 128 ? 9 : (nbr < 512 ? 3 : 1));
-            if (split == 9) {
-                nbr = (int)((nown * DOF + BLK / 9 - 1) / (BLK / 9));
-                TP_LAUNCH((k_dia_row_split<DOF, EPI, 9>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
-            } else if (split == 3) {
-                nbr = (int)((nown * DOF + BLK / 3 - 1) / (BLK / 3));
-                static const bool sym = getenv("TP_NO_DIA_SYM") == nullptr;
-                if (sym)
-                    TP_LAUNCH((k_dia_row_split<DOF, EPI, 3, true>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
-                else
-                    TP_LAUNCH((k_dia_row_split<DOF, EPI, 3>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
+            const int rsplit = split_env >= 0 ? split_env : (nbr_all < 128 ? 9 : (nbr_all < 512 ? 3 : 1));
+            static const bool sym = getenv("TP_NO_DIA_SYM") == nullptr;
+            auto launch_rows = [&](long t0, long tn, long t1, long tn1) -> int {
+                o.t0 = t0, o.tn = tn, o.t1 = t1, o.tn1 = tn1;
+                const long rows = tn < 0 ? rows_all : tn + tn1;
+                int nbr;
+                if (rsplit == 9) {
+                    nbr = (int)((rows + BLK / 9 - 1) / (BLK / 9));
+                    TP_LAUNCH((k_dia_row_split<DOF, EPI, 9>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
+                } else if (rsplit == 3) {
+                    nbr = (int)((rows + BLK / 3 - 1) / (BLK / 3));
+                    if (sym)
+                        TP_LAUNCH((k_dia_row_split<DOF, EPI, 3, true>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
+                    else
+                        TP_LAUNCH((k_dia_row_split<DOF, EPI, 3>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
+                } else {
+                    nbr = (int)((rows + BLK - 1) / BLK);
+                    TP_LAUNCH((k_dia_row<DOF, EPI>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
+                }
+                last_nblocks = nbr;
+                return TP_OK;
+            };
+            // Halo overlap on the stencil levels (round 5; slabs): the rows of the one or two boundary planes in ONE launch
+            // first, their exchange on the second stream, then the interior rows -- as on the tile levels, bitwise the same
+            // result (a row's sum does not depend on the launch it is computed in).  TP_STENCIL_OVERLAP=0: one launch, the
+            // consumer's halo() exchanges.
+            static const bool st_ovl = !(getenv("TP_STENCIL_OVERLAP") && atoi(getenv("TP_STENCIL_OVERLAP")) == 0);
+            const int planes = L.g.own_hi - L.g.own_lo + 1;
+            const bool split_dia = st_ovl && out_halo && EPI != EPI_APPLY_DOT && !L.no_comm && n_bnd > 0 && halo_can_overlap(grid) &&
+                                   planes > n_bnd && !sg_capturing;
+            if (split_dia) {
+                const long pr = (long)DOF * L.g.plane();
+                const bool both = L.g.has_lo && L.g.has_hi;
+                TP_TRY(launch_rows(L.g.has_lo ? 0 : rows_all - pr, pr, both ? rows_all - pr : 0, both ? pr : 0));
+                TP_TRY(after_boundary());
+                TP_TRY(launch_rows(L.g.has_lo ? pr : 0, rows_all - pr * n_bnd, 0, 0));
+                grid->launches++;
             } else {
-                TP_LAUNCH((k_dia_row<DOF, EPI>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
+                TP_TRY(launch_rows(0, -1, 0, 0));
             }
-            last_nblocks = nbr;
             bytes = (27.0 * DOF * DOF + 2.0 * DOF) * 8.0 * nown;
             flops = 2.0 * 27 * DOF * DOF * (double)nown;
         }

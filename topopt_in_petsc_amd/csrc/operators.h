@@ -97,6 +97,11 @@ struct DiaOp {
     const double *__restrict__ S;
     long nrows;  // DOF * local nodes
     Geom g;
+    // rows of this launch, counted from the first owned row: [t0, t0 + tn) followed by [t1, t1 + tn1); tn < 0: all owned rows.
+    // Two ranges: the launch that produces the two boundary planes of a slab first (halo overlap on the stencil levels, mg.h)
+    long t0 = 0, tn = -1, t1 = 0, tn1 = 0;
+    __device__ inline long rows_here() const { return tn < 0 ? g.owned_nodes() * DOF : tn + tn1; }
+    __device__ inline long row_of(long tl) const { return tn < 0 ? tl : (tl < tn ? t0 + tl : t1 + (tl - tn)); }
 
     __device__ inline void apply(const double *__restrict__ u, int i, int j, int k, long n, double y[DOF]) const {
 #pragma unroll
@@ -344,9 +349,10 @@ template <int DOF, int EPI>
 __global__ __launch_bounds__(BLK) void k_dia_row(DiaOp<DOF> op, NodeArgs a) {
     const Geom &g = op.g;
     const long plane = g.plane();
-    const long t = blockIdx.x * (long)BLK + threadIdx.x;
+    const long tl = blockIdx.x * (long)BLK + threadIdx.x;
     double pdot = 0.0;
-    if (t < g.owned_nodes() * DOF) {
+    if (tl < op.rows_here()) {
+        const long t = op.row_of(tl);
         const long q = t + plane * g.own_lo * DOF;  // row
         const long n = q / DOF;
         const int k = (int)(n / plane);
@@ -408,8 +414,9 @@ __global__ __launch_bounds__(BLK) void k_dia_row_split(DiaOp<DOF> op, NodeArgs a
     // workgroups are dealt round-robin to the 8 XCDs: give every XCD a contiguous run of rows
     const int nbk = gridDim.x, x8 = blockIdx.x & 7;
     const int bid = SYM ? x8 * (nbk >> 3) + min(x8, nbk & 7) + (blockIdx.x >> 3) : blockIdx.x;
-    const long t = bid * (long)RPB + r;
-    const bool valid = part < SPLIT && t < g.owned_nodes() * DOF;
+    const long tl = bid * (long)RPB + r;
+    const bool valid = part < SPLIT && tl < op.rows_here();
+    const long t = valid ? op.row_of(tl) : 0;
     const long q = t + plane * g.own_lo * DOF;  // row
     const double *__restrict__ u = a.x;
     // epilogue operands of the row: requested BEFORE the stencil loads, not after the barrier (these kernels run at
