@@ -86,3 +86,33 @@ def test_lambda_bound(orc):
     d = np.sqrt(np.diag(K))
     ref = np.linalg.eigvalsh(0.5 * (K + K.T) / np.outer(d, d)).max()
     assert abs(orc.elem_lambda_bound(ke) - ref) < 1e-12
+
+
+def test_effective_element_matrix_restatement():
+    """oracle/ke_effective.py (the element matrix the HIP fine-level kernels apply, restated on the host): for the
+    reference's KE of a cube and of a box it is symmetric, annihilates rigid translations EXACTLY (KE itself leaves 7e-16 of its
+    largest entry), stays within 1e-15 max|KE| of KE entrywise -- as close to KE as KE is to its own formula evaluated in 80-bit
+    arithmetic (oracle/arbiter.py) -- and keeps KE's energy on strain modes."""
+    import numpy as np
+    from oracle import arbiter as arb
+    from oracle import oracle as orc
+    from oracle.ke_effective import ke_effective
+    for dims in ((1.0 / 128,) * 3, (0.5, 0.25, 0.125)):
+        KE = orc.hex8_ke_box(*dims, 0.3)
+        kf = ke_effective(KE)
+        assert kf.dtype == np.longdouble and kf.shape == (576,)
+        K2, F2 = KE.reshape(24, 24), kf.reshape(24, 24)
+        mx = np.abs(KE).max()
+        assert float(np.abs(F2 - F2.T).max()) == 0.0
+        assert float(np.abs(F2.sum(axis=1)).max()) == 0.0 and np.abs(K2.sum(axis=1)).max() > 1e-17 * mx
+        for c in range(3):                      # one component translated: zero force (to the round-off of summing the 80-bit
+            t = np.zeros(24, dtype=np.longdouble)   # restatement; the kernels, working in the transformed basis, give exact zeros:
+            t[c::3] = 1000.0                        # tests/test_gpu_parity.py::test_effective_element_matrix), KE: ~1e-16
+            assert float(np.abs(F2 @ t).max()) <= 1e-18 * mx * 1000.0
+            assert float(np.abs(K2 @ t.astype(np.float64)).max()) >= 1e-17 * mx * 1000.0
+        d_eff = float(np.abs(kf - KE).max()) / mx
+        d_ref = float(np.abs(KE - arb.hex8_ke_box(*dims, 0.3)).max()) / mx
+        assert 0 < d_eff <= 1e-15 and d_ref <= 1e-15 and d_eff <= 4 * d_ref + 2e-16
+        rng = np.random.default_rng(3)
+        u = rng.standard_normal(24)
+        assert abs(float(u @ (F2 @ u)) / (u @ K2 @ u) - 1) <= 1e-14
