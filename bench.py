@@ -948,9 +948,9 @@ def main():
     kname = "k_fine_u4" if gen3 else "k_fine_tile"
     roofline = {"bound": "hbm", "kernel": "%s<EPI_CHEB> / <EPI_CHEB_DOT> (fine-level matrix-free hex8 operator fused with the Chebyshev-Jacobi "
                                           "update, without / with the fused r.z: ONE loop, 34 launches per step; the largest kernel of the step by time and by "
-                                          "bytes: profiles/r04_bench_step_shares.txt -- 1.22 + 0.59 ms of 12.7; next: the level-2 block stencil, 121 launches "
-                                          "of 12 us = 1.50 ms out of the Infinity Cache (`level2_stencil` below), and the once-per-step factorisation of the "
-                                          "coarsest level, k_cd_factor, one latency-bound launch of 1.5 ms on a side stream: DESIGN 4.5)" % kname,
+                                          "bytes: profiles/r05_bench_step_shares.txt -- 1.17 + 0.60 ms of 12.2; next: the level-2 block stencil, 121 launches "
+                                          "of 12 us = 1.5 ms out of the Infinity Cache (`level2_stencil` below), and the once-per-step factorisation of the "
+                                          "coarsest level, k_cd_factor, one latency-bound launch of 1.4 ms on a side stream beside the head of the solve: DESIGN 4.5)" % kname,
                 "share_of_step": cheb_step_share,
                 "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                 "traffic": roof_traffic,
