@@ -54,6 +54,7 @@ def lib():
         L.orc_mg_fine_matfree.argtypes = [C.c_void_p] * 4
         L.orc_mg_set_cycles.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_mg_assemble.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_mg_reassemble_fine.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_mg_precond.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_mg_solve.restype = C.c_int
         L.orc_mg_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, c_real, c_real, c_real, C.c_int,
@@ -232,6 +233,12 @@ class MG:
         self.L.orc_mg_fine_matfree(None, None, None, None)
         self._keep = (f64(KE), None if E is None else f64(E), None if N is None else f64(N))
         self.L.orc_mg_assemble(self.h, *[_p(a) for a in self._keep])
+
+    def reassemble_fine(self, KE):
+        """diagnostic: only the fine-level operator (and its Jacobi diagonal) from another element matrix; the hierarchy of the
+        last assemble() stays"""
+        self._keep2 = (f64(KE), self._keep[1], self._keep[2])
+        self.L.orc_mg_reassemble_fine(self.h, *[_p(a) for a in self._keep2])
 
     def fine_matfree(self, on=True):
         """CPU baseline variant: apply the fine-level operator of the solve matrix-free (OpenMP gather over the 8

@@ -950,6 +950,25 @@ ORC_API void orc_mg_destroy(orc_mg_t *s) {
     free(s);
 }
 
+/* Diagnostic: replace ONLY the fine-level operator and its Jacobi diagonal by the one assembled from another
+ * element matrix; the coarse operators, their diagonals and every Chebyshev window stay those of the last orc_mg_assemble.
+ * Separates what a change of the element matrix does through the operator of the Krylov method from what it does through
+ * the preconditioner's hierarchy. */
+ORC_API void orc_mg_reassemble_fine(orc_mg_t *s, const double *KE, const double *E, const double *N) {
+    csr_free(s->A[0]);
+    free(s->dinv[0]);
+    s->A[0] = assemble_csr(s->nx[0], s->ny[0], s->nz[0], s->dof, KE, E, N);
+    csr_t *A   = s->A[0];
+    s->dinv[0] = (double *)xmalloc(sizeof(double) * (size_t)A->nrow);
+#pragma omp parallel for schedule(static) if (A->nrow > PFOR_MIN)
+    for (long r = 0; r < A->nrow; r++) {
+        double dg = 0.0;
+        for (long p = A->rp[r]; p < A->rp[r + 1]; p++)
+            if (A->ci[p] == r) dg = A->v[p];
+        s->dinv[0][r] = 1.0 / dg;
+    }
+}
+
 /* "KSPSetOperators + KSPSetUp": assemble the fine matrix, Galerkin coarse
  * operators, Jacobi diagonals and Chebyshev windows (LinearElasticity.cc:190-200) */
 ORC_API void orc_mg_assemble(orc_mg_t *s, const double *KE, const double *E, const double *N) {
