@@ -294,8 +294,10 @@ def cpu_step(orc, el, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, matfree_too
         if cycles:
             amg.set_cycles([int(v) for v in cycles.split(",")][: max(nlv - 1, 0)])
 
-        def arbiter_run(K):
+        def arbiter_run(K, K_fine=None):
             amg.assemble(K, E, N)
+            if K_fine is not None:
+                amg.reassemble_fine(K_fine)
             Ua, its_a, hist_a = amg.solve(arb.f64(R * N), rtol=rtol)
             fx_a = arb.compliance_sens(nx, ny, nz, KE, Ua, xp)[0]       # (the objective is evaluated with KE itself, as on the GPU)
             Uat, its_at, _ = amg.solve(arb.f64(R * N), rtol=TIGHT_RTOL)
@@ -303,13 +305,16 @@ def cpu_step(orc, el, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, matfree_too
             return ({"its": int(its_a), "fx": float(fx_a), "hist": [float(v) for v in hist_a[:64]], "its_tight": int(its_at),
                      "fx_tight": float(fx_at)}, np.asarray(df_at, dtype=np.float64))
 
-        # (2a) on the reference's element matrix KE; (2b) on KE_eff, the element matrix the HIP fine-level kernels apply
-        # (oracle/ke_effective.py: KE with the rounding residue of its box symmetry removed, 5e-16 max|KE| away from KE)
+        # (2a) on the reference's element matrix KE; (2b) on the operators the library applies: the fine-level operator of the
+        # Krylov method and of the smoother from KE_eff (the element matrix the HIP fine-level kernels apply, oracle/ke_effective.py:
+        # KE with the rounding residue of its box symmetry removed, 5e-16 max|KE| away from KE), the Galerkin hierarchy below it
+        # from KE (csrc/galerkin.h builds it from KE's own tensors) -- tools/r05_hist_diag.py: with the hierarchy from KE_eff as
+        # well the GPU's history is 5.9e-11 from the arbiter's, with this split 7.7e-13
         from oracle.ke_effective import ke_effective
         arb_ke, df_at = arbiter_run(KE)
         te2 = time.perf_counter()
         KEf = ke_effective(KE)
-        arb_eff, df_eff = arbiter_run(KEf)
+        arb_eff, df_eff = arbiter_run(KE, KEf)
         te3 = time.perf_counter()
         KEx = arb.hex8_ke_box(h, h, h, 0.3)      # the reference's formula evaluated in 80-bit arithmetic
         mx = float(np.abs(KE).max())

@@ -815,8 +815,9 @@ def test_effective_element_matrix(tp, orc):
 def test_bench_cycle_against_the_arbiter_on_the_operator_the_kernels_apply(tp, orc):
     """DESIGN 2.1 as a test of the suite (the bench line asserts the same at 128^3): a 64 x 32 x 32 cantilever with the bench's
     cycle (4 levels, Chebyshev(2), level 2 cycled three times, exact coarse solve).  Against the oracle rebuilt in 80-bit
-    arithmetic (oracle/arbiter.py) ON KE_eff -- the element matrix the fine-level kernels apply, as the library exports it --
-    the residual history, the compliance at rtol 1e-5 and the converged compliance / raw sensitivities agree to 1e-11; against
+    arithmetic (oracle/arbiter.py) ON THE OPERATORS THE LIBRARY APPLIES -- fine level from KE_eff, the element matrix the tile
+    kernels apply, as the library exports it; Galerkin hierarchy from KE, as csrc/galerkin.h builds it -- the residual history,
+    the compliance at rtol 1e-5 and the converged compliance / raw sensitivities agree to 1e-11 (128^3: 8e-13); against
     the same arbiter on the reference's KE the agreement is set by what that change of operator does to the arbiter itself."""
     from oracle import arbiter as arb
     ex, ey, ez, nlv, cyc = 64, 32, 32, 4, [1, 3, 1]
@@ -840,11 +841,13 @@ def test_bench_cycle_against_the_arbiter_on_the_operator_the_kernels_apply(tp, o
     N, R = orc.cantilever_bc(nx, ny, nz, h)
     E = orc.simp(xpn)
 
-    def arbiter(K):
+    def arbiter(K, K_fine=None):
         mg = arb.MG(nx, ny, nz, 3, nlv, 2, 20)
         mg.set_coarse_direct(True)
         mg.set_cycles(cyc)
         mg.assemble(K, E, N)
+        if K_fine is not None:     # the operators the library applies: fine level from KE_eff, Galerkin hierarchy from KE
+            mg.reassemble_fine(K_fine)
         res = {}
         for rtol in (1e-5, 1e-12):
             U, its, hist = mg.solve(arb.f64(R * N), rtol=rtol)
@@ -852,7 +855,7 @@ def test_bench_cycle_against_the_arbiter_on_the_operator_the_kernels_apply(tp, o
             res[rtol] = (its, np.asarray(hist, dtype=np.float64), float(fx), np.asarray(df, dtype=np.float64))
         return res
 
-    a_eff, a_ke = arbiter(kf), arbiter(KE)
+    a_eff, a_ke = arbiter(KE, kf), arbiter(KE)
     for rtol in (1e-5, 1e-12):
         its, hist, fx, df = out[rtol]
         assert its == a_eff[rtol][0] == a_ke[rtol][0]
