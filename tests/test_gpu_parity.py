@@ -868,3 +868,29 @@ def test_bench_cycle_against_the_arbiter_on_the_operator_the_kernels_apply(tp, o
     gap_arb = abs(a_eff[1e-12][2] / a_ke[1e-12][2] - 1)
     assert gap_arb > 1e-13 and abs(gap_gpu - gap_arb) <= 1e-11 and gap_gpu <= 1e-10
     grid.close()
+
+
+@pytest.mark.gpu
+def test_pde_filter_against_the_arbiter_converged(tp, orc):
+    """The Helmholtz filter (PDEFilter.cc:189-216) at 64 x 32 x 32, both sides solved to rtol 1e-13: the filtered density of the
+    HIP path against the oracle rebuilt in 80-bit arithmetic (oracle/arbiter.py) -- 1e-11 of its maximum; the scalar operator
+    is applied from KF itself on the device (no packed form: nothing like KE_eff here), and its iteration count equals the
+    arbiter's at the reference's own tolerance 1e-8 as well."""
+    from oracle import arbiter as arb
+    ex, ey, ez = 64, 32, 32
+    nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
+    rmin = 2.56 * h
+    grid = tp.Grid(nx, ny, nz, h)
+    x = grid.synth_density()
+    xn = x.cpu().numpy()
+    af = arb.PDEFilter(nx, ny, nz, h, rmin, nlv=3, nsmooth=2, ncoarse=10)
+    for rtol, tol in ((1e-8, 1e-7), (1e-13, 1e-11)):
+        f = tp.Filter(grid, 2, rmin, tp.SolverOptions(nlvls=3, rtol=rtol, dtol=1e3, max_it=200, nsmooth=2, ncoarse=10))
+        xt, xp = grid.elem_vec(), grid.elem_vec()
+        f.FilterProject(x, xt, xp)
+        xa, its_a, _ = af.apply(arb.f64(xn), rtol=rtol, maxit=200)
+        xa = np.clip(np.asarray(xa, dtype=np.float64), 0.0, 1.0)
+        assert f.last_pde_solve()[0] == its_a, (rtol, f.last_pde_solve(), its_a)
+        assert np.abs(xt.cpu().numpy() - xa).max() <= tol * np.abs(xa).max(), rtol
+        f.close()
+    grid.close()
