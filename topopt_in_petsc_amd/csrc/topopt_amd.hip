@@ -688,7 +688,7 @@ extern "C" int tp_elasticity_get_ke_effective(const tp_elasticity *e, double *hi
     }
     SymKE sk;
     (void)make_sym_ke(e->KE, &sk);
-    static long double D[24][24];
+    long double D[24][24];
     for (int i = 0; i < 24; i++)
         for (int j = 0; j < 24; j++) D[i][j] = 0.0L;
     for (int q = 0; q < 8; q++)
