@@ -331,8 +331,18 @@ struct MGSolver {
     tp_grid *grid = nullptr;
     void *refksp = nullptr;  // RefKsp<DOF>: work space of the ksp_mode 1 solver
     int nlv = 0;
-    Level<DOF> lv[TP_MAX_LEVELS + 1];  // [nlv] = replicated global copy of the coarsest level (nranks > 1)
+    // lv[0 .. nlv-1]: the levels of this rank's slab.  Several ranks: the coarse levels rep0 .. nlv-1 also exist as REPLICATED
+    // global copies at lv[nlv + (l - rep0)] (no halo, no reductions over ranks: every rank runs them redundantly from one
+    // all-gather of the right-hand side per visit).  rep0 = nlv - 1 (the coarsest level only) unless the slabs are thin or
+    // TP_REPLICATE_FROM says otherwise (round 5: the agglomeration of the coarse levels, taken to its end).
+    static constexpr int LV_SLOTS = 2 * (TP_MAX_LEVELS + 1);
+    Level<DOF> lv[LV_SLOTS];
     bool replicate = false;
+    int rep0 = -1;                       // first replicated level (valid if replicate)
+    int rix(int l) const { return nlv + (l - rep0); }                  // slot of the replicated copy of level l >= rep0
+    int base(int i) const { return i < nlv ? i : rep0 + (i - nlv); }   // level number of slot i
+    bool coarsest(int i) const { return base(i) == nlv - 1; }
+    bool is_rep(int i) const { return i >= nlv; }
     bool allow_replicate = false;  // set by the owner when the coarsest level is a stored stencil (elasticity)
     tp_solver_opts opt;
     double *cg_r = nullptr, *cg_p = nullptr, *cg_w = nullptr, *cg_p2 = nullptr;
@@ -456,20 +466,19 @@ struct MGSolver {
             return TP_OK;
         }
         for (int l = first_level; l < nlv; l++) {
+            const bool rep = replicate && l >= rep0;   // the level's estimate comes from its replicated copy: same operator, same
+            const int r = rep ? rix(l) : l;             // hashed start vector, no communication
             if (l == nlv - 1 && l > 0 && direct) {
                 TP_TRY(coarse_direct_factor());
                 lv[l].lam = lv[l].lam_min = 1.0;
-                if (replicate) lv[nlv].lam = lv[nlv].lam_min = 1.0;
+                if (rep) lv[r].lam = lv[r].lam_min = 1.0;
             } else if (l == nlv - 1 && l > 0) {
-                if (replicate) {  // same operator, same hashed start vector, no communication
-                    TP_TRY(lanczos(nlv, NLANCZOS_COARSE, &lv[nlv].lam, &lv[nlv].lam_min));
-                    lv[l].lam = lv[nlv].lam;
-                    lv[l].lam_min = lv[nlv].lam_min;
-                } else {
-                    TP_TRY(lanczos(l, NLANCZOS_COARSE, &lv[l].lam, &lv[l].lam_min));
-                }
+                TP_TRY(lanczos(r, NLANCZOS_COARSE, &lv[r].lam, &lv[r].lam_min));
+                lv[l].lam = lv[r].lam;
+                lv[l].lam_min = lv[r].lam_min;
             } else {
-                TP_TRY(lanczos(l, opt.nlanczos, &lv[l].lam));
+                TP_TRY(lanczos(r, opt.nlanczos, &lv[r].lam));
+                lv[l].lam = lv[r].lam;
             }
         }
         return TP_OK;
@@ -485,29 +494,48 @@ struct MGSolver {
                 TP_HIP(hipMemsetAsync(*p, 0, nb, grid->stream));
             }
         }
-        lv[nlv] = Level<DOF>();
-        lv[nlv].b = lv[nlv].x = lv[nlv].x2 = lv[nlv].r = lv[nlv].d = lv[nlv].dinv = lv[nlv].S = lv[nlv].Kel = nullptr;
+        for (int i = nlv; i < LV_SLOTS; i++) {
+            lv[i] = Level<DOF>();
+            lv[i].b = lv[i].x = lv[i].x2 = lv[i].r = lv[i].d = lv[i].dinv = lv[i].S = lv[i].Kel = nullptr;
+        }
         static const bool no_rep = getenv("TP_NO_REPLICATE") != nullptr;
         replicate = allow_replicate && grid->has_comm && nlv > 1 && !no_rep;
+        rep0 = nlv - 1;
         if (replicate) {
-            Level<DOF> &R = lv[nlv];
-            const Geom &c = lv[nlv - 1].g;
-            R.g = c;
-            R.g.nzl = c.nz_glob;
-            R.g.ez_own = R.g.ezl = c.nz_glob - 1;
-            R.g.own_lo = 0;
-            R.g.own_hi = c.nz_glob - 1;
-            R.g.gz0 = 0;
-            R.g.has_lo = R.g.has_hi = 0;
-            R.kind = LV_DIA;
-            R.no_comm = true;
-            size_t rb = sizeof(double) * (size_t)R.ndof();
-            for (double **p : {&R.b, &R.x, &R.x2, &R.r, &R.d, &R.dinv}) {
-                TP_HIP(hipMalloc((void **)p, rb));
-                TP_HIP(hipMemsetAsync(*p, 0, rb, grid->stream));
+            // Which coarse levels are replicated?  Always the coarsest one; from the first stored-stencil level (>= 2) on whose
+            // slab holds at most two element layers -- there a level's kernels are at their launch floor and every operator
+            // application is followed by a halo exchange that costs more than the kernel --; TP_REPLICATE_FROM=l (2 .. nlv - 1)
+            // fixes it, TP_REPLICATE_FROM=0 keeps the coarsest level only.
+            static const int from_env = getenv("TP_REPLICATE_FROM") ? atoi(getenv("TP_REPLICATE_FROM")) : -1;
+            if (from_env >= 2 && from_env <= nlv - 1) {
+                rep0 = from_env;
+            } else if (from_env < 0) {
+                for (int l = 2; l < nlv - 1; l++)
+                    if (lv[l].g.ez_own <= 2) {
+                        rep0 = l;
+                        break;
+                    }
             }
-            TP_HIP(hipMalloc((void **)&R.S, rb * 27 * DOF));
-            TP_HIP(hipMemsetAsync(R.S, 0, rb * 27 * DOF, grid->stream));
+            for (int l = rep0; l < nlv; l++) {
+                Level<DOF> &R = lv[rix(l)];
+                const Geom &c = lv[l].g;
+                R.g = c;
+                R.g.nzl = c.nz_glob;
+                R.g.ez_own = R.g.ezl = c.nz_glob - 1;
+                R.g.own_lo = 0;
+                R.g.own_hi = c.nz_glob - 1;
+                R.g.gz0 = 0;
+                R.g.has_lo = R.g.has_hi = 0;
+                R.kind = LV_DIA;
+                R.no_comm = true;
+                size_t rb = sizeof(double) * (size_t)R.ndof();
+                for (double **p : {&R.b, &R.x, &R.x2, &R.r, &R.d, &R.dinv}) {
+                    TP_HIP(hipMalloc((void **)p, rb));
+                    TP_HIP(hipMemsetAsync(*p, 0, rb, grid->stream));
+                }
+                TP_HIP(hipMalloc((void **)&R.S, rb * 27 * DOF));
+                TP_HIP(hipMemsetAsync(R.S, 0, rb * 27 * DOF, grid->stream));
+            }
         }
         size_t nb = sizeof(double) * (size_t)lv[0].ndof();
         for (double **p : {&cg_r, &cg_p, &cg_w, &cg_p2}) {
@@ -519,8 +547,9 @@ struct MGSolver {
     void free_levels() {
         smooth_graphs_free();
         refksp_free(*this);
-        for (int l = 0; l <= nlv; l++) {
+        for (int l = 0; l < LV_SLOTS; l++) {
             Level<DOF> &L = lv[l];
+            if (l >= nlv && !(replicate && l < nlv + (nlv - rep0))) continue;   // unused slots
             for (double *p : {L.b, L.x, L.x2, L.r, L.d, L.dinv, L.S, L.Kel}) (void)hipFree(p);
         }
         for (double *p : {cg_r, cg_p, cg_w, cg_p2}) (void)hipFree(p);
@@ -538,7 +567,7 @@ struct MGSolver {
             (void)hipHostFree(b.hc);
             b = LanBuf();
         }
-        for (int i = 0; i <= TP_MAX_LEVELS; i++) {
+        for (int i = 0; i < LV_SLOTS; i++) {
             if (lan_graph[i]) (void)hipGraphExecDestroy(lan_graph[i]);
             lan_graph[i] = nullptr;
             lan_graph_state[i] = 0;
@@ -549,7 +578,7 @@ struct MGSolver {
         }
         if (lan_fork) (void)hipEventDestroy(lan_fork);
         lan_fork = nullptr;
-        for (int i = 0; i <= TP_MAX_LEVELS; i++) {
+        for (int i = 0; i < LV_SLOTS; i++) {
             if (pend_ev[i]) (void)hipEventDestroy(pend_ev[i]);
             pend_ev[i] = nullptr;
             pend[i].ptr = nullptr;
@@ -562,15 +591,15 @@ struct MGSolver {
         size_t cap = 0;
         int m = 0;
     };
-    LanBuf lan[TP_MAX_LEVELS + 1];
+    LanBuf lan[LV_SLOTS];
     // the run of a level is a static chain of ~400-1000 small launches: captured once into a hipGraph and replayed
     // every design iteration (host cost: one launch); rebuilt when the captured pointers may have changed
-    hipGraphExec_t lan_graph[TP_MAX_LEVELS + 1] = {};
-    const void *lan_graph_key[TP_MAX_LEVELS + 1][5] = {};
+    hipGraphExec_t lan_graph[LV_SLOTS] = {};
+    const void *lan_graph_key[LV_SLOTS][5] = {};
     long topology_epoch = 0;  // bumped by the owner whenever lists/buffers referenced by the operators are rebuilt
-    int lan_graph_state[TP_MAX_LEVELS + 1] = {};  // 0: not tried, 1: valid, -1: capture failed -> direct launches
-    hipStream_t lan_stream[TP_MAX_LEVELS + 1] = {};
-    hipEvent_t lan_fork = nullptr, lan_done[TP_MAX_LEVELS + 1] = {};
+    int lan_graph_state[LV_SLOTS] = {};  // 0: not tried, 1: valid, -1: capture failed -> direct launches
+    hipStream_t lan_stream[LV_SLOTS] = {};
+    hipEvent_t lan_fork = nullptr, lan_done[LV_SLOTS] = {};
 
     // ---- operator application with one of the epilogues -------------------
     // out_halo: the ghost planes of a.out will be read next (another operator application, a grid transfer).  On the
@@ -807,8 +836,8 @@ struct MGSolver {
     struct PendingHalo {
         const double *ptr = nullptr;
     };
-    PendingHalo pend[TP_MAX_LEVELS + 1];
-    hipEvent_t pend_ev[TP_MAX_LEVELS + 1] = {};
+    PendingHalo pend[LV_SLOTS];
+    hipEvent_t pend_ev[LV_SLOTS] = {};
     int drain_halo(int l) {  // DMGlobalToLocalEnd
         if (pend[l].ptr) {
             TP_HIP(hipStreamWaitEvent(grid->stream, pend_ev[l], 0));
@@ -817,7 +846,7 @@ struct MGSolver {
         return TP_OK;
     }
     int drain_halos() {
-        for (int l = 0; l <= nlv; l++) TP_TRY(drain_halo(l));
+        for (int l = 0; l < LV_SLOTS; l++) TP_TRY(drain_halo(l));
         return TP_OK;
     }
     // A kernel that writes whole owned planes of `out` one node at a time (vector updates, grid transfers), issued so
@@ -994,7 +1023,7 @@ struct MGSolver {
         int level = -1;       // the level the factor belongs to (nlv - 1, or nlv: the replicated copy)
         bool factored = false;
     } cd;
-    int cd_level() const { return replicate ? nlv : nlv - 1; }
+    int cd_level() const { return replicate ? rix(nlv - 1) : nlv - 1; }
     bool cd_early = false;              // this assembly's factorisation is already under way (coarse_direct_early)
     hipStream_t side_stream = nullptr;  // owner's spare stream (idle during estimate_spectra): a second one for the chains
     // Called by the owner as soon as the coarsest level's stencil is enqueued (before the other levels are finished): the
@@ -1157,7 +1186,7 @@ struct MGSolver {
     }
     // after an assembly that failed half way: no chain of a side stream may still be running when the next one starts
     void join_side_streams() {
-        for (int i = 0; i <= TP_MAX_LEVELS; i++)
+        for (int i = 0; i < LV_SLOTS; i++)
             if (lan_stream[i]) (void)hipStreamSynchronize(lan_stream[i]);
         if (side_stream) (void)hipStreamSynchronize(side_stream);
         cd_early = false;
@@ -1189,7 +1218,7 @@ struct MGSolver {
     // device)
     int coarse_run_mode(int l, int nsteps) const {
         const Level<DOF> &L = lv[l];
-        if (sg_capturing || DOF != 3 || L.kind != LV_DIA || !(l == nlv - 1 || l == nlv)) return 0;
+        if (sg_capturing || DOF != 3 || L.kind != LV_DIA || !coarsest(l)) return 0;
         if (!(L.no_comm || !grid->has_comm) || nsteps < 4 || nsteps > RUN_MAXK) return 0;
         int wgs;
         const int R = run_rows_per_thread(L.own_n(), &wgs);
@@ -1262,9 +1291,10 @@ struct MGSolver {
         if (replicate && l == nlv - 1) {
             // coarsest level replicated on every rank: one all-gather of the right-hand side instead of a
             // halo exchange per Chebyshev step; the result comes back with its ghost planes filled
-            Level<DOF> &R = lv[nlv];
+            // (the V-cycle itself enters the replicated levels in vcycle(); this branch serves direct calls on the slab's level)
+            Level<DOF> &R = lv[rix(l)];
             TP_TRY(gather_owned(lv[l], b, R, R.b, 1));
-            TP_TRY(smooth(nlv, R.b, k, zero_guess));  // (first_done never holds here: vcycle does not fuse on this path)
+            TP_TRY(smooth(rix(l), R.b, k, zero_guess));  // (first_done never holds here: vcycle does not fuse on this path)
             Level<DOF> &L = lv[l];
             TP_HIP(hipMemcpyAsync(L.x, R.x + (long)DOF * L.g.plane() * L.g.gz0, sizeof(double) * (size_t)L.ndof(),
                                   hipMemcpyDeviceToDevice, grid->stream));
@@ -1329,8 +1359,8 @@ struct MGSolver {
     // LinearElasticity.cc:720-731): its window spans the whole spectrum
     void cheb_window(int l, double *theta, double *delta) const {
         const Level<DOF> &L = lv[l];
-        const bool coarsest = (l == nlv - 1 && l > 0) || l == nlv;
-        const double lmin = coarsest ? L.lam_min : opt.cheb_lo * L.lam, lmax = opt.cheb_hi * L.lam;
+        const bool solve_level = coarsest(l) && base(l) > 0;
+        const double lmin = solve_level ? L.lam_min : opt.cheb_lo * L.lam, lmax = opt.cheb_hi * L.lam;
         *theta = 0.5 * (lmax + lmin);
         *delta = 0.5 * (lmax - lmin);
     }
@@ -1371,9 +1401,12 @@ struct MGSolver {
     // (re)build the replicated coarsest level from the ranks' owned stencil rows
     int setup_replicated() {
         if (!replicate) return TP_OK;
-        Level<DOF> &L = lv[nlv - 1], &R = lv[nlv];
-        TP_TRY(gather_owned(L, L.S, R, R.S, 27 * DOF, L.ndof(), R.ndof()));
-        TP_TRY(gather_owned(L, L.dinv, R, R.dinv, 1));
+        for (int l = rep0; l < nlv; l++) {
+            Level<DOF> &L = lv[l], &R = lv[rix(l)];
+            if (L.kind != LV_DIA) return TP_ERR_STATE;   // (only stored-stencil levels have rows to gather)
+            TP_TRY(gather_owned(L, L.S, R, R.S, 27 * DOF, L.ndof(), R.ndof()));
+            TP_TRY(gather_owned(L, L.dinv, R, R.dinv, 1));
+        }
         return TP_OK;
     }
 
@@ -1398,7 +1431,7 @@ struct MGSolver {
     int cycles[TP_MAX_LEVELS + 1] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
     int vcycle(int l, const double *b, int dot_slot = -1, bool first_done = false, bool zero_guess = true) {
         Level<DOF> &L = lv[l];
-        if (l == nlv - 1) return smooth(l, b, opt.ncoarse, zero_guess, -1, first_done);
+        if (coarsest(l)) return smooth(l, b, opt.ncoarse, zero_guess, -1, first_done);
         if (l == 0 && head_for == b) head_for = nullptr;  // pre-smoothed already (vcycle_head)
         else TP_TRY(smooth(l, b, opt.nsmooth, zero_guess, -1, first_done));
         {
@@ -1409,13 +1442,17 @@ struct MGSolver {
             TP_TRY(halo(l, L.x));
             TP_TRY(op<EPI_RESID>(l, a, true));
         }
-        Level<DOF> &C = lv[l + 1];
+        Level<DOF> &C = lv[l + 1];   // (slab levels and replicated slots alike: the next coarser level sits in the next slot)
         TP_TRY(halo(l, L.r));
+        // from here down the levels are the replicated copies: restriction into the slab's part of the right-hand side, one
+        // all-gather, the coarser levels on every rank without any exchange, the slab's window of the result back
+        const bool enter_rep = replicate && !is_rep(l) && l + 1 == rep0;
+        const int cyc = coarsest(l + 1) ? 1 : cycles[base(l)];
         // the restriction also takes the coarse level's first Chebyshev step from the zero guess (one launch less per
         // level and V-cycle); not when the coarse level is the replicated copy, whose right-hand side is gathered first
         static const bool no_fuse_first = getenv("TP_NO_FUSE_FIRST") != nullptr;
-        const bool fuse_first = !no_fuse_first && !(replicate && l + 1 == nlv - 1) && !(cd.factored && l + 1 == nlv - 1) &&
-                                (l + 1 == nlv - 1 ? opt.ncoarse : opt.nsmooth) >= 1;
+        const bool fuse_first = !no_fuse_first && !enter_rep && !(cd.factored && coarsest(l + 1)) &&
+                                (coarsest(l + 1) ? opt.ncoarse : opt.nsmooth) >= 1;
         double th = 1.0, de = 1.0;
         if (fuse_first) cheb_window(l + 1, &th, &de);
         auto restrict_planes = [&](int p0, int np) -> int {
@@ -1428,9 +1465,19 @@ struct MGSolver {
         if (fuse_first) TP_TRY(planes_split(l + 1, C.x, restrict_planes));  // the coarse level's first iterate is read with ghosts next
         else TP_TRY(restrict_planes(C.g.own_lo, C.g.own_hi - C.g.own_lo + 1));
         count_launch(grid, 8.0 * DOF * (L.g.owned_nodes() + C.g.owned_nodes()), 2.0 * 27 * DOF * C.g.owned_nodes());
-        TP_TRY(vcycle(l + 1, C.b, -1, fuse_first));
-        for (int c = 1; c < (l + 1 == nlv - 1 ? 1 : cycles[l]); c++) TP_TRY(vcycle(l + 1, C.b, -1, false, false));
-        if (!(replicate && l + 1 == nlv - 1)) TP_TRY(halo(l + 1, C.x));  // the replicated solve returns its ghosts
+        if (enter_rep) {
+            const int r = rix(l + 1);
+            Level<DOF> &R = lv[r];
+            TP_TRY(gather_owned(C, C.b, R, R.b, 1));
+            TP_TRY(vcycle(r, R.b, -1, false));
+            for (int c = 1; c < cyc; c++) TP_TRY(vcycle(r, R.b, -1, false, false));
+            TP_HIP(hipMemcpyAsync(C.x, R.x + (long)DOF * C.g.plane() * C.g.gz0, sizeof(double) * (size_t)C.ndof(),
+                                  hipMemcpyDeviceToDevice, grid->stream));   // (own planes and ghosts)
+        } else {
+            TP_TRY(vcycle(l + 1, C.b, -1, fuse_first));
+            for (int c = 1; c < cyc; c++) TP_TRY(vcycle(l + 1, C.b, -1, false, false));
+            TP_TRY(halo(l + 1, C.x));
+        }
         TP_TRY(planes_split(l, L.x, [&](int p0, int np) -> int {
             const long fpl = L.g.plane();
             TP_LAUNCH((k_prolong_add<DOF>), dim3((int)((fpl * np + BLK - 1) / BLK)), dim3(BLK), 0, grid->stream, C.g, L.g, C.x,
@@ -1552,7 +1599,7 @@ struct MGSolver {
     XcdRunCtrl *lan_ctl = nullptr;
     bool lanczos_xcd_ok(int l, int steps) const {
         if (getenv("TP_NO_LANCZOS_XCD") || tp_xcd_disabled() || steps > LAN_MAXS || steps < 2) return false;
-        if (!(replicate ? l == nlv : (l == nlv - 1 && l > 0))) return false;
+        if (!(l == cd_level() && base(l) > 0)) return false;
         return xcd_eligible(l, LAN_XS, 4);  // (8 rows per thread: the basis no longer fits the LDS)
     }
     int lanczos_xcd(int l, int steps) {
