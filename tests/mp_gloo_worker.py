@@ -186,8 +186,8 @@ def gpu_mode(rank, world):
     assert grid0.halo_overlap == 0
     assert np.array_equal(le0.last_hist, hh), "overlapped and blocking halos differ"
     assert torch.equal(le0.U[own_t], le.U[own_t])
-    print("rank %d gpu OK its=%d exchanges=%d allreduces=%d overlapped=%d" %
-          (rank, its, grid.comm.n_exchanges, grid.comm.n_allreduces, grid.halo_overlap), flush=True)
+    print("rank %d gpu OK its=%d exchanges=%d allreduces=%d overlapped=%d direct=%d allgathers=%d" %
+          (rank, its, grid.comm.n_exchanges, grid.comm.n_allreduces, grid.halo_overlap, grid.comm.n_direct, grid.comm.n_allgathers), flush=True)
 
 
 def gpu_randbc_mode(rank, world):
