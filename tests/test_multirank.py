@@ -157,7 +157,7 @@ def test_replicated_levels_take_their_halo_exchanges_out():
     n = {}
     for rep in ("0", "2"):
         out = _launch("gpu", nproc=2, timeout=600, extra=mesh, env_extra={"TP_REPLICATE_FROM": rep})
-        m = re.search(r"rank 0 gpu OK its=(\d+) exchanges=(\d+) allreduces=(\d+)", out)
-        n[rep] = (int(m.group(1)), int(m.group(2)))
+        m = re.search(r"rank 0 gpu OK its=(\d+) exchanges=(\d+) allreduces=(\d+) overlapped=(\d+) direct=(\d+) allgathers=(\d+)", out)
+        n[rep] = (int(m.group(1)), int(m.group(2)) + int(m.group(5)), int(m.group(6)))    # its, halo exchanges (staged + in place), all-gathers
     assert n["0"][0] == n["2"][0]
-    assert n["2"][1] < 0.6 * n["0"][1], n
+    assert n["2"][1] < 0.7 * n["0"][1] and n["2"][2] >= n["0"][2], n
