@@ -506,7 +506,7 @@ struct MGSolver {
             // slab holds at most two element layers -- there a level's kernels are at their launch floor and every operator
             // application is followed by a halo exchange that costs more than the kernel --; TP_REPLICATE_FROM=l (2 .. nlv - 1)
             // fixes it, TP_REPLICATE_FROM=0 keeps the coarsest level only.
-            static const int from_env = getenv("TP_REPLICATE_FROM") ? atoi(getenv("TP_REPLICATE_FROM")) : -1;
+            static const int from_env = (getenv("TP_REPLICATE_FROM") && *getenv("TP_REPLICATE_FROM")) ? atoi(getenv("TP_REPLICATE_FROM")) : -1;
             if (from_env >= 2 && from_env <= nlv - 1) {
                 rep0 = from_env;
             } else if (from_env < 0) {
