@@ -575,6 +575,27 @@ def main():
         raise SystemExit("strong scaling: %d element layers do not split into %d slabs of whole coarse layers of a %d-level "
                          "hierarchy (try --nlvls %d)" % (ezg, world, nlv, max(1, (ezg // max(world, 1)).bit_length() - 1)))
     ez = ezg * world if a.scaling == "weak" else ezg  # weak: fixed slab per GPU; strong: fixed mesh
+
+    def depth_for(ez_glob, n0, cyc0):
+        """N > 1: the multigrid depth follows the GLOBAL mesh -- coarsen until the coarsest level fits the exact solve (<= 4096
+        rows), as the workload's own depth does for its one-GPU mesh; V-cycles on the added levels.  Weak scaling of the metric
+        mesh: 5 levels leave 4131 / 8019 / 15 795 rows at N = 2 / 4 / 8 (Chebyshev(20) coarse runs, at N = 8 as 20 launches per
+        visit plus a 40-step Lanczos chain of launches per assembly), 6 levels 675 / 1275 / 2475 (exact); both 13 iterations
+        (tools/r05_slabs_its2.sh).  Not with an explicit --nlvls, --coarse cheb or a workload without a cycle pattern."""
+        n, cyc = n0, cyc0
+        if world == 1 or a.nlvls or a.coarse != "direct" or not cyc0:
+            return n, cyc
+        while n < 10:
+            d = 1 << (n - 1)
+            if 3 * (ex // d + 1) * (ey // d + 1) * (ez_glob // d + 1) <= 4096:
+                break
+            if ex % (2 * d) or ey % (2 * d) or (ez_glob // world) % (2 * d):
+                break
+            n, cyc = n + 1, cyc + ",1"
+        return n, cyc
+
+    nlv0, cycles0 = nlv, a.cycles
+    nlv, a.cycles = depth_for(ez, nlv0, cycles0)
     nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
     ndof = 3 * nx * ny * nz
     Emin, Emax, penal, volfrac = 1e-9, 1.0, 3.0, 0.12
@@ -858,14 +879,15 @@ def main():
     other = None
     if world > 1 and not a.no_other_scaling:
         o_scal = "strong" if a.scaling == "weak" else "weak"
-        ok = not (o_scal == "strong" and (ezg % world or (ezg // world) % (1 << (nlv - 1))))
+        ok = not (o_scal == "strong" and (ezg % world or (ezg // world) % (1 << (nlv0 - 1))))
         used = max_over_ranks(time.time() - t_start)      # (the same decision on every rank)
         if ok and used > 0.5 * a.budget_s:
             other = {"scaling": o_scal, "skipped": "the %s case used %.0f s, over half of --budget-s %.0f" % (a.scaling, used, a.budget_s)}
         elif ok:
             wd.phase("set-up of the %s case" % o_scal, 300)
             ez2 = ezg if o_scal == "strong" else ezg * world
-            case2 = Case(ez2 + 1, 2.56 * h, nlv, a.ncoarse, a.nsmooth, a.coarse == "direct", a.cycles)
+            nlv2, cycles2 = depth_for(ez2, nlv0, cycles0)
+            case2 = Case(ez2 + 1, 2.56 * h, nlv2, a.ncoarse, a.nsmooth, a.coarse == "direct", cycles2)
             wd.phase("%s case" % o_scal, 300 + 60 * (a.warmup + a.steps))
             for _ in range(a.warmup):
                 case2.step()
@@ -880,7 +902,7 @@ def main():
             other = {"scaling": o_scal, "value": ndof2 / (dt2 / a.steps), "unit": "DOF-updates/s", "ms_per_step": 1e3 * dt2 / a.steps,
                      "n_dof": ndof2, "mesh": "%dx%dx%d elements over %d GPUs" % (ex, ey, ez2, world), "cg_its": le2.last_its,
                      "rel_residual": le2.last_rnorm / le2.last_bnorm, "halo_overlap": grid2.halo_overlap, "comm": grid2.comm_kind,
-                     "coarse_solve": "direct" if le2.coarse_direct_active() else "chebyshev(%d)" % a.ncoarse}
+                     "coarse_solve": "direct" if le2.coarse_direct_active() else "chebyshev(%d)" % a.ncoarse, "levels": nlv2, "cycles": cycles2}
             le2 = grid2 = None
             wd.phase("teardown of the %s case" % o_scal, 120)
             barrier()
@@ -1046,7 +1068,8 @@ def main():
                                                                          ("exact (banded Cholesky + explicit triangular inverse per assembly)" if coarse_is_direct else "Chebyshev(%d)" % a.ncoarse),
                                                                          ", cycles per level %s" % a.cycles if a.cycles else "", a.rtol,
                                                                          "Lanczos(10)" if a.fine_eig else "element bound"),
-                   "n_dof": ndof, "coarse_solve": "direct (%d rows)" % le.coarse_direct_active() if coarse_is_direct else "chebyshev(%d)" % a.ncoarse,
+                   "n_dof": ndof, "levels": nlv, "cycles": a.cycles or None,
+                   "coarse_solve": "direct (%d rows)" % le.coarse_direct_active() if coarse_is_direct else "chebyshev(%d)" % a.ncoarse,
                    "cg_its": info.get("its"), "rel_residual": info.get("rel_res"), "fx": info.get("fx"),
                    # SURVEY 8(d) secondary metrics: Krylov work rate (KSPSolve only, assembly/setup excluded) and the
                    # MMA update that follows the measured path in the optimisation loop (not part of `value`)
