@@ -531,7 +531,7 @@ __global__ __launch_bounds__(WAVE) void k_cd_dc_w(CdGeom c, int lv, const double
 }
 
 // y[i] = sum_{j <= i} W[i][j] b[j]   (UPPER: x[i] = sum_{j >= i} Wt[i][j] y[j]); one wave per row, fixed order
-template <bool UPPER, bool NT = false>
+template <bool UPPER>
 __global__ __launch_bounds__(CD_T) void k_cd_tri(CdGeom c, const double *__restrict__ M, const double *__restrict__ v, double *__restrict__ out) {
     const int row = blockIdx.x * (CD_T / WAVE) + threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
     if (row >= c.n) return;
@@ -539,14 +539,13 @@ __global__ __launch_bounds__(CD_T) void k_cd_tri(CdGeom c, const double *__restr
     const int lo = UPPER ? (row & ~(CD_NB - 1)) : 0, hi = UPPER ? c.n : row + 1;  // (the diagonal tile holds zeros below the diagonal)
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int j = lo + lane;
-    auto ld = [&](int q) { return NT ? __builtin_nontemporal_load(mr + q) : mr[q]; };   // (experiment TP_CD_TRI_NT: the matrix streamed past the caches)
     for (; j + 3 * WAVE < hi; j += 4 * WAVE) {
-        s0 = fma(ld(j), v[j], s0);
-        s1 = fma(ld(j + WAVE), v[j + WAVE], s1);
-        s2 = fma(ld(j + 2 * WAVE), v[j + 2 * WAVE], s2);
-        s3 = fma(ld(j + 3 * WAVE), v[j + 3 * WAVE], s3);
+        s0 = fma(mr[j], v[j], s0);
+        s1 = fma(mr[j + WAVE], v[j + WAVE], s1);
+        s2 = fma(mr[j + 2 * WAVE], v[j + 2 * WAVE], s2);
+        s3 = fma(mr[j + 3 * WAVE], v[j + 3 * WAVE], s3);
     }
-    for (; j < hi; j += WAVE) s0 = fma(ld(j), v[j], s0);
+    for (; j < hi; j += WAVE) s0 = fma(mr[j], v[j], s0);
     const double s = wave_sum((s0 + s1) + (s2 + s3));
     if (lane == 0) out[row] = s;
 }

@@ -1157,14 +1157,8 @@ struct MGSolver {
         Level<DOF> &L = lv[l];
         TP_TRY(join_pending_factor());
         const int rows_per = CD_T / WAVE, nb = (cd.g.n + rows_per - 1) / rows_per;
-        static const bool tri_nt = getenv("TP_CD_TRI_NT") != nullptr && atoi(getenv("TP_CD_TRI_NT")) != 0;
-        if (tri_nt) {
-            TP_LAUNCH((k_cd_tri<false, true>), dim3(nb), dim3(CD_T), 0, grid->stream, cd.g, cd.W, b, cd.y);
-            TP_LAUNCH((k_cd_tri<true, true>), dim3(nb), dim3(CD_T), 0, grid->stream, cd.g, cd.Wt, cd.y, L.x);
-        } else {
-            TP_LAUNCH(k_cd_tri<false>, dim3(nb), dim3(CD_T), 0, grid->stream, cd.g, cd.W, b, cd.y);
-            TP_LAUNCH(k_cd_tri<true>, dim3(nb), dim3(CD_T), 0, grid->stream, cd.g, cd.Wt, cd.y, L.x);
-        }
+        TP_LAUNCH(k_cd_tri<false>, dim3(nb), dim3(CD_T), 0, grid->stream, cd.g, cd.W, b, cd.y);
+        TP_LAUNCH(k_cd_tri<true>, dim3(nb), dim3(CD_T), 0, grid->stream, cd.g, cd.Wt, cd.y, L.x);
         grid->launches += 2;
         grid->alg_bytes += 8.0 * ((double)cd.g.n * cd.g.n + 4.0 * cd.g.n);
         grid->flops += 2.0 * (double)cd.g.n * cd.g.n;
