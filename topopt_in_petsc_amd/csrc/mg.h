@@ -1802,7 +1802,7 @@ struct MGSolver {
                 double th0 = 1.0, de0 = 1.0;
                 if (fuse_first) cheb_window(0, &th0, &de0);
                 static const bool cg_nt = !(getenv("TP_CG_NT") != nullptr && atoi(getenv("TP_CG_NT")) == 0);  // on (TP_CG_NT=0: plain loads / stores)
-                if (cg_nt)
+                if (cg_nt && n >= (1L << 22))   // (below ~32 MB a vector lives in the caches anyway: the hint costs 0.5 % at C1 / C2)
                     TP_LAUNCH(k_cg_update_xr<true>, dim3(nb), dim3(BLK), 0, s, x, r, p, w, grid->scal, rz_cur, off, n,
                               grid->partials, tail_ticket(grid), grid->scal + S_RR, direct_rr ? grid->h_scal_dev : nullptr,
                               fuse_first ? L.x : nullptr, L.dinv, 1.0 / th0);
