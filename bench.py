@@ -34,10 +34,14 @@ WORKLOADS = {
     # against 15.0 / 12 for round 2's 1,2,2,1 -- tools/cycle_scan5.sh, cycle_scan6.sh); ncoarse: only with --coarse cheb
     "cantilever128": dict(el=(128, 128, 128), nlvls=5, nsmooth=2, ncoarse=20, cycles="1,3,1,1"),
     "c2": dict(el=(128, 64, 64), nlvls=3, nsmooth=2, ncoarse=45),               # configs[1] ("3-level GMG")
-    "c1": dict(el=(48, 24, 24), nlvls=4, nsmooth=2, ncoarse=22),                # configs[0]
-    "cube256": dict(el=(256, 256, 256), nlvls=6, nsmooth=2, ncoarse=45),        # north-star SpMV target mesh
+    # configs[0]; round 5: 3 levels -- the coarsest level (13 x 7 x 7 nodes, 1911 rows) is solved exactly: 4.44 -> 3.6 ms, 17 -> 14 its
+    # (tools/r05_c4_scan.sh; round 2-4: 4 levels, Chebyshev(22) coarse run)
+    "c1": dict(el=(48, 24, 24), nlvls=3, nsmooth=2, ncoarse=22),
+    "cube256": dict(el=(256, 256, 256), nlvls=6, nsmooth=2, ncoarse=45, cycles="1,3,1,1,1"),   # north-star SpMV target mesh; round 5: the metric mesh's pattern, 89.9 -> 75.2 ms, 18 -> 11 its
     "c3": dict(el=(256, 128, 128), nlvls=6, nsmooth=2, ncoarse=20, cycles="1,3,1,1,1"),  # configs[2] on ONE GPU (12.8 M DOF); with --gpus 8: 256x128x(128*8)
-    "c4": dict(el=(192, 64, 64), nlvls=6, nsmooth=2, ncoarse=45, ftype=2, bc="mbb"),  # configs[3]: MBB beam, Helmholtz (PDE) filter
+    # configs[3]: MBB beam, Helmholtz (PDE) filter; round 5: 5 levels (coarsest 13 x 5 x 5 nodes = 975 rows, solved exactly), level 2
+    # cycled twice: 25.2 -> 18.9 ms, 43 -> 24 its (round 2-4: 6 levels, V, Chebyshev(45) run in one workgroup; 1,3,1,1: 19.0 ms / 21 its)
+    "c4": dict(el=(192, 64, 64), nlvls=5, nsmooth=2, ncoarse=45, cycles="1,2,1,1", ftype=2, bc="mbb"),
     "c5": dict(el=(512, 256, 256), nlvls=4, nsmooth=2, ncoarse=60),             # configs[4] ("4-level GMG") on ONE GPU (101.7 M DOF, ~35 GB of the 288 GB); with --gpus 8 --scaling strong: its slabs
     # configs[1] with the reference's own absolute filter radius (TopOpt.cc:121 rmin = 0.08: ElemConn 5, 1331-tap cone)
     "c2_rmin008": dict(el=(128, 64, 64), nlvls=3, nsmooth=2, ncoarse=45, rmin=0.08),
