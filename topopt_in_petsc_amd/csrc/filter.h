@@ -279,7 +279,7 @@ struct tp_filter {
     // PDE filter
     MGSolver<1> *pde;
     std::vector<double> KF;  // per level 64
-    double *d_KF, *xe, *rhs, *u;
+    double *d_KF, *d_wtab = nullptr, *xe, *rhs, *u;
     double elemVol;
     int last_its;
     double last_rnorm;
@@ -503,6 +503,12 @@ extern "C" int tp_filter_create(tp_filter **out, tp_grid *g, int filterType, dou
                 }
         TP_HIP(hipMalloc((void **)&f->d_KF, sizeof(double) * f->KF.size()));
         TP_HIP(hipMemcpy(f->d_KF, f->KF.data(), sizeof(double) * f->KF.size(), hipMemcpyHostToDevice));
+        {   // the levels' operators as 27-point stencils (operators.h: ScalarStencilOp): one 27 x 27 table per level
+            std::vector<double> Wt((size_t)729 * o.nlvls);
+            for (int l = 0; l < o.nlvls; l++) pde_stencil_table(f->KF.data() + (size_t)64 * l, Wt.data() + (size_t)729 * l);
+            TP_HIP(hipMalloc((void **)&f->d_wtab, sizeof(double) * Wt.size()));
+            TP_HIP(hipMemcpy(f->d_wtab, Wt.data(), sizeof(double) * Wt.size(), hipMemcpyHostToDevice));
+        }
         f->pde = new MGSolver<1>();
         MGSolver<1> &mg = *f->pde;
         mg.grid = g;
@@ -513,6 +519,7 @@ extern "C" int tp_filter_create(tp_filter **out, tp_grid *g, int filterType, dou
             Level<1> &L = mg.lv[l];
             L.kind = LV_MATFREE;
             L.KE = f->d_KF + 64 * l;
+            L.wtab = f->d_wtab + 729 * l;
             L.E = nullptr;
             L.mask = nullptr;
             L.S = L.Kel = nullptr;
@@ -539,7 +546,7 @@ extern "C" int tp_filter_create(tp_filter **out, tp_grid *g, int filterType, dou
 extern "C" int tp_filter_destroy(tp_filter *f) {
     if (!f) return TP_OK;
     (void)hipStreamSynchronize(f->grid->stream);
-    for (double *p : {f->wtab, f->Hs, f->xg, f->tmp, f->d_KF, f->xe, f->rhs, f->u}) (void)hipFree(p);
+    for (double *p : {f->wtab, f->Hs, f->xg, f->tmp, f->d_KF, f->d_wtab, f->xe, f->rhs, f->u}) (void)hipFree(p);
     if (f->pde) {
         f->pde->free_levels();
         delete f->pde;

@@ -90,6 +90,55 @@ struct MatfreeOp {
 };
 
 // ---------------------------------------------------------------------------
+// A CONSTANT-COEFFICIENT scalar operator (the Helmholtz filter's K_f, PDEFilter.cc:251-264: one 8 x 8 element matrix for
+// the whole level, no moduli, no Dirichlet rows) as the 27-point stencil it is (round 5): a node's row depends only on
+// which of its 8 adjacent elements exist -- per axis "no lower element" / both / "no upper element", 27 classes -- so the
+// 27 x 27 weights are tabulated once per level on the host (pde_stencil_table) and a thread does 27 loads and 27 fma
+// instead of the gather form's 64 + 64 (k_node<1, MatfreeOp<1>>: 11.4 us per launch at 0.8 M nodes, 14 % of config 4's
+// busy time).  Same operator, other summation order: equal to the gather form to rounding.
+struct ScalarStencilOp {
+    const double *__restrict__ W;   // [27 classes][27 offsets], class = (cz*3 + cy)*3 + cx, offset = (dz+1)*9 + (dy+1)*3 + (dx+1)
+    Geom g;
+    __device__ inline void apply(const double *__restrict__ u, int i, int j, int k, long n, double y[1]) const {
+        // element (i-1 .. i) x (j-1 .. j) x (k-1 .. k) existence, as MatfreeOp tests it (local layers [0, ezl))
+        const int cx = i == 0 ? 0 : (i >= g.ex ? 2 : 1), cy = j == 0 ? 0 : (j >= g.ey ? 2 : 1), cz = k == 0 ? 0 : (k >= g.ezl ? 2 : 1);
+        const double *__restrict__ w = W + ((cz * 3 + cy) * 3 + cx) * 27;
+        double s = 0.0;
+#pragma unroll
+        for (int dz = -1; dz <= 1; dz++)
+#pragma unroll
+            for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                for (int dx = -1; dx <= 1; dx++) {
+                    const bool ok = !((dx < 0 && cx == 0) || (dx > 0 && cx == 2) || (dy < 0 && cy == 0) || (dy > 0 && cy == 2) ||
+                                      (dz < 0 && cz == 0) || (dz > 0 && cz == 2));
+                    const long nb = ok ? n + dx + (long)g.nx * (dy + (long)g.ny * dz) : n;   // (weight 0 there)
+                    s = fma(w[(dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)], u[nb], s);
+                }
+        y[0] = s;
+    }
+};
+// the table of ScalarStencilOp from an 8 x 8 element matrix (reference corner order): W[class][offset] = sum over the
+// existing elements around the node, in corner order a = 0 .. 7, of KF[a][b] for the neighbour b of that element at the offset
+inline void pde_stencil_table(const double *KF, double *W /* 27 * 27 */) {
+    for (int q = 0; q < 27 * 27; q++) W[q] = 0.0;
+    for (int cz = 0; cz < 3; cz++)
+        for (int cy = 0; cy < 3; cy++)
+            for (int cx = 0; cx < 3; cx++) {
+                double *w = W + ((cz * 3 + cy) * 3 + cx) * 27;
+                for (int a = 0; a < 8; a++) {   // the node is corner a of the element at (i - LX[a], j - LY[a], k - LZ[a])
+                    const int lx = h_LX[a], ly = h_LY[a], lz = h_LZ[a];
+                    // that element is the LOWER one along an axis if l = 1 (needs class != 0), the upper one if l = 0 (class != 2)
+                    if ((lx ? cx == 0 : cx == 2) || (ly ? cy == 0 : cy == 2) || (lz ? cz == 0 : cz == 2)) continue;
+                    for (int b = 0; b < 8; b++) {
+                        const int dx = h_LX[b] - lx, dy = h_LY[b] - ly, dz = h_LZ[b] - lz;
+                        w[(dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)] += KF[a * 8 + b];
+                    }
+                }
+            }
+}
+
+// ---------------------------------------------------------------------------
 // Block 27-point stencil by diagonals: S[(blk*DOF + c) * nrows + row],
 // row = node*DOF + r, blk = (dk+1)*9 + (dj+1)*3 + (di+1), column dof c.
 template <int DOF>
