@@ -47,6 +47,10 @@ WORKLOADS = {
     "c2_rmin008": dict(el=(128, 64, 64), nlvls=3, nsmooth=2, ncoarse=45, rmin=0.08),
     # the metric mesh with the reference's own absolute filter radius (rmin = 0.08: ElemConn 10, 9261-tap cone, z-streamed kernel)
     "cantilever128_rmin008": dict(el=(128, 128, 128), nlvls=5, nsmooth=2, ncoarse=20, cycles="1,3,1,1", rmin=0.08),
+    # configs[1] and configs[4] BESIDE their BASELINE-stated depths ("3-level GMG", "4-level GMG"): the metric mesh's recipe -- coarsen
+    # until the coarsest level fits the exact solve, level 2 cycled three times (tools/r05_c5_deep.sh: 18.3 -> 7.7 ms, 481 -> 176 ms)
+    "c2_deep": dict(el=(128, 64, 64), nlvls=5, nsmooth=2, ncoarse=45, cycles="1,3,1,1"),
+    "c5_deep": dict(el=(512, 256, 256), nlvls=7, nsmooth=2, ncoarse=60, cycles="1,3,1,1,1,1"),
     "tiny": dict(el=(32, 16, 16), nlvls=3, nsmooth=2, ncoarse=30),
 }
 
