@@ -13,7 +13,7 @@ h = 1.0 / ey
 grid = tp.Grid(ex + 1, ey + 1, ez + 1, h)
 x = grid.synth_density()
 xt, xp = grid.elem_vec(), grid.elem_vec()
-for nlv, nsm, nco in ((3, 2, 10), (4, 2, 10), (5, 2, 10), (4, 2, 20), (5, 2, 20), (4, 1, 10), (4, 3, 10), (3, 2, 20), (3, 2, 40), (6, 2, 10)):
+for nlv, nsm, nco in ((3, 2, 10), (3, 2, 6), (3, 2, 4), (3, 2, 2), (2, 2, 10), (2, 2, 4), (3, 3, 4), (3, 1, 4), (2, 3, 4), (1, 2, 2)):
     try:
         f = tp.Filter(grid, 2, 2.56 * h, tp.SolverOptions(nlvls=nlv, rtol=1e-8, dtol=1e3, max_it=60, nsmooth=nsm, ncoarse=nco))
     except Exception as e:
