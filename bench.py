@@ -41,7 +41,10 @@ WORKLOADS = {
     "c3": dict(el=(256, 128, 128), nlvls=6, nsmooth=2, ncoarse=20, cycles="1,3,1,1,1"),  # configs[2] on ONE GPU (12.8 M DOF); with --gpus 8: 256x128x(128*8)
     # configs[3]: MBB beam, Helmholtz (PDE) filter; round 5: 5 levels (coarsest 13 x 5 x 5 nodes = 975 rows, solved exactly), level 2
     # cycled twice: 25.2 -> 18.9 ms, 43 -> 24 its (round 2-4: 6 levels, V, Chebyshev(45) run in one workgroup; 1,3,1,1: 19.0 ms / 21 its)
-    "c4": dict(el=(192, 64, 64), nlvls=5, nsmooth=2, ncoarse=45, cycles="1,2,1,1", ftype=2, bc="mbb"),
+    # pde: the Helmholtz filter's own solver.  At this radius (R = rmin / (2 sqrt 3) = 0.74 h) the operator is mass dominated: CG
+    # preconditioned by two Chebyshev-Jacobi steps converges in 9 iterations without any coarse level (0.89 ms per filter
+    # application against 1.62 for the reference's 3-level hierarchy with 10 coarse steps, PDEFilter.cc:32, :357; tools/r05_pde_scan.py)
+    "c4": dict(el=(192, 64, 64), nlvls=5, nsmooth=2, ncoarse=45, cycles="1,2,1,1", ftype=2, bc="mbb", pde=dict(nlvls=1, nsmooth=2, ncoarse=2)),
     "c5": dict(el=(512, 256, 256), nlvls=4, nsmooth=2, ncoarse=60),             # configs[4] ("4-level GMG") on ONE GPU (101.7 M DOF, ~35 GB of the 288 GB); with --gpus 8 --scaling strong: its slabs
     # configs[1] with the reference's own absolute filter radius (TopOpt.cc:121 rmin = 0.08: ElemConn 5, 1331-tap cone)
     "c2_rmin008": dict(el=(128, 64, 64), nlvls=3, nsmooth=2, ncoarse=45, rmin=0.08),
@@ -243,7 +246,8 @@ def cpu_step(orc, el, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, matfree_too
     if ftype == 2:   # Helmholtz filter with the library's defaults (PDEFilter.cc:32, :280-283, :357; Chebyshev(2) smoothing)
         class _PdeFilter:
             def __init__(self):
-                self.f = orc.PDEFilter(nx, ny, nz, h, rmin, nlv=3, nsmooth=2, ncoarse=10)
+                po = dict(dict(nlvls=3, nsmooth=2, ncoarse=10), **(problem.get("pde") or {}))
+                self.f = orc.PDEFilter(nx, ny, nz, h, rmin, nlv=po["nlvls"], nsmooth=po["nsmooth"], ncoarse=po["ncoarse"])
 
             def project(self, _ftype, x_):
                 import numpy as np_
@@ -283,7 +287,7 @@ def cpu_step(orc, el, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, matfree_too
            "fx": float(fx), "gx": float(gx), "rel_residual": float(hist[min(its, len(hist) - 1)] / hist[0]) if len(hist) else None,
            "hist": [float(v) for v in hist[:64]], "df_abs_sum": float(np.abs(df).sum()),
            "phase_seconds": {"filter": tf - t0, "assemble": t1 - tf, "solve": t2 - t1, "sensitivities+filter": t3 - t2}}
-    res["problem"] = {"ftype": ftype, "bc": bc, "rmin": rmin}
+    res["problem"] = {"ftype": ftype, "bc": bc, "rmin": rmin, "pde": problem.get("pde")}
     if extras_npz and ftype == 1:    # (a Helmholtz-filtered density is itself the result of a solve to rtol 1e-8: no 1e-10 to assert behind it)
         # ---- what the parity object of the line needs beyond the timed step (none of it is timed):
         # (1) the CONVERGED step: the same system solved to rtol 1e-12 from the zero guess -- compliance and raw
@@ -498,7 +502,7 @@ def main():
         if not a.no_parity:
             extras_npz = cpu_json + ".extras.npz"
             cmd[-1] = extras_npz
-        cmd.append(json.dumps({"ftype": W.get("ftype", 1), "bc": W.get("bc", "cantilever"), "rmin": W.get("rmin")}))
+        cmd.append(json.dumps({"ftype": W.get("ftype", 1), "bc": W.get("bc", "cantilever"), "rmin": W.get("rmin"), "pde": W.get("pde")}))
         # How many threads, and where?  All hardware threads unbound is NOT the fastest way to run these memory-bound loops
         # (measured on the 2 x 64-core host of the GPU box, tools/r04_cpu_threads.sh: 256 threads 13.9 s, 128 bound to cores
         # 7.4 s, 64 spread over the cores 5.1 s per design iteration).  The baseline is the BEST of a short list, chosen on
@@ -615,7 +619,8 @@ def main():
         def __init__(self, nz_nodes, rmin, nlv_, ncoarse_, nsmooth_, direct, cycles):
             self.grid = tp.Grid(nx, ny, nz_nodes, h, rank=rank, nranks=world)
             self.le = self.solver(nlv_, ncoarse_, nsmooth_, direct, cycles)
-            self.flt = tp.Filter(self.grid, ftype, rmin)
+            pde = W.get("pde")
+            self.flt = tp.Filter(self.grid, ftype, rmin, tp.SolverOptions(**dict(dict(rtol=1e-8, dtol=1e3, max_it=60), **pde)) if (pde and ftype == 2) else None)
             g = self.grid
             self.x = g.synth_density(12345)
             self.xt, self.xp, self.df, self.dg = g.elem_vec(), g.elem_vec(), g.elem_vec(), g.elem_vec()
