@@ -73,6 +73,7 @@ def parse():
                    help="coarsest level: exact solve (banded Cholesky + explicit triangular inverse per assembly, where the level has <= 4096 rows; else falls back) or the Chebyshev run of --ncoarse steps")
     p.add_argument("--cheb-lo", type=float, default=0.1, help="lower end of the Chebyshev windows as a fraction of the eigenvalue estimate (PETSc: -mg_levels_ksp_chebyshev_esteig 0,LO,0,HI)")
     p.add_argument("--cheb-hi", type=float, default=1.1)
+    p.add_argument("--nlanczos", type=int, default=0, help="Lanczos steps of the smoothing levels' eigenvalue estimates (0: the library's 10, PETSc's -mg_levels_esteig_ksp_max_it default)")
     p.add_argument("--cycles", default="", help="cycles of the next coarser level per level, finest first, e.g. 1,2,2 (1 = V, 2 = W)")
     p.add_argument("--spmv-reps", type=int, default=50)
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -628,6 +629,7 @@ def main():
 
         def solver(self, nlv_, ncoarse_, nsmooth_, direct, cycles, rtol=None):
             le_ = tp.LinearElasticity(self.grid, tp.SolverOptions(nlvls=nlv_, rtol=a.rtol if rtol is None else rtol, fine_eig=a.fine_eig, ncoarse=ncoarse_,
+                                                                  nlanczos=a.nlanczos or 10,
                                                                   nsmooth=nsmooth_, coarse_direct=int(direct), cheb_lo=a.cheb_lo, cheb_hi=a.cheb_hi))
             if cycles:
                 le_.set_cycles([int(v) for v in cycles.split(",")])
