@@ -261,6 +261,7 @@ def cpu_step(orc, el, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, matfree_too
     else:
         flt = orc.Filter(nx, ny, nz, h, rmin)
     mg = orc.MG(nx, ny, nz, 3, nlv, nsmooth, ncoarse, fine_eig=fine_eig)
+    mg.set_nlanczos(problem.get("nlanczos") or 10)
     mg.set_coarse_direct(coarse_direct)
     if cycles:
         mg.set_cycles([int(v) for v in cycles.split(",")][: max(nlv - 1, 0)])
@@ -303,6 +304,7 @@ def cpu_step(orc, el, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, matfree_too
         del mg, U, Ut
         from oracle import arbiter as arb
         amg = arb.MG(nx, ny, nz, 3, nlv, nsmooth, ncoarse, fine_eig=fine_eig)
+        amg.set_nlanczos(problem.get("nlanczos") or 10)
         amg.set_coarse_direct(coarse_direct)
         if cycles:
             amg.set_cycles([int(v) for v in cycles.split(",")][: max(nlv - 1, 0)])
@@ -503,7 +505,7 @@ def main():
         if not a.no_parity:
             extras_npz = cpu_json + ".extras.npz"
             cmd[-1] = extras_npz
-        cmd.append(json.dumps({"ftype": W.get("ftype", 1), "bc": W.get("bc", "cantilever"), "rmin": W.get("rmin"), "pde": W.get("pde")}))
+        cmd.append(json.dumps({"ftype": W.get("ftype", 1), "bc": W.get("bc", "cantilever"), "rmin": W.get("rmin"), "pde": W.get("pde"), "nlanczos": a.nlanczos or None}))
         # How many threads, and where?  All hardware threads unbound is NOT the fastest way to run these memory-bound loops
         # (measured on the 2 x 64-core host of the GPU box, tools/r04_cpu_threads.sh: 256 threads 13.9 s, 128 bound to cores
         # 7.4 s, 64 spread over the cores 5.1 s per design iteration).  The baseline is the BEST of a short list, chosen on

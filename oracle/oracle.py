@@ -50,6 +50,7 @@ def lib():
         L.orc_mg_create.argtypes = [C.c_int] * 7 + [c_real] * 2
         L.orc_mg_destroy.argtypes = [C.c_void_p]
         L.orc_mg_set_fine_eig.argtypes = [C.c_void_p, C.c_int]
+        L.orc_mg_set_nlanczos.argtypes = [C.c_void_p, C.c_int]
         L.orc_mg_set_coarse_direct.argtypes = [C.c_void_p, C.c_int]
         L.orc_mg_fine_matfree.argtypes = [C.c_void_p] * 4
         L.orc_mg_set_cycles.argtypes = [C.c_void_p, C.c_void_p]
@@ -219,6 +220,10 @@ class MG:
         if getattr(self, "h", None):
             self.L.orc_mg_destroy(self.h)
             self.h = None
+
+    def set_nlanczos(self, n):
+        """Lanczos steps of the smoothing levels' eigenvalue estimates (10 = PETSc's default); takes effect at the next assemble()"""
+        self.L.orc_mg_set_nlanczos(self.h, int(n))
 
     def set_coarse_direct(self, on=True):
         """coarsest level solved exactly (banded Cholesky) instead of the Chebyshev run; takes effect at the next assemble()"""

@@ -866,6 +866,8 @@ ORC_API orc_mg_t *orc_mg_create(int nx, int ny, int nz, int dof, int nlv, int ns
     return s;
 }
 
+/* Lanczos steps of the smoothing levels' eigenvalue estimates (default 10 = PETSc's -mg_levels_esteig_ksp_max_it) */
+ORC_API void orc_mg_set_nlanczos(orc_mg_t *s, int n) { s->nlanczos = n > 0 ? n : 10; }
 ORC_API void orc_mg_set_fine_eig(orc_mg_t *s, int mode) { s->fine_eig = mode; }
 /* coarsest level: 0 = Chebyshev run of ncoarse steps, 1 = exact solve (takes effect at the next orc_mg_assemble) */
 ORC_API void orc_mg_set_coarse_direct(orc_mg_t *s, int on) { s->coarse_direct = on; }
