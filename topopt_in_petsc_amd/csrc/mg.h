@@ -771,19 +771,22 @@ struct MGSolver {
             flops = 2.0 * 576 * 8.0 * (double)L.g.own_elems();
         } else if (L.kind == LV_MATFREE) {
             static const bool no_st = getenv("TP_NO_PDE_STENCIL") != nullptr;
+            bool as_stencil = false;
             if constexpr (DOF == 1) {
                 if (L.wtab && !L.E && !L.mask && !no_st) {   // constant-coefficient scalar operator: its 27-point stencil form
                     ScalarStencilOp so{L.wtab, L.g};
                     TP_LAUNCH((k_node<1, ScalarStencilOp, EPI>), dim3(nb), dim3(BLK), 0, grid->stream, so, a);
                     bytes = 16.0 * nown;
                     flops = 2.0 * 27 * (double)nown;
-                    goto op_done;
+                    as_stencil = true;
                 }
             }
-            MatfreeOp<DOF> o{L.KE, L.E, L.mask, L.g};
-            TP_LAUNCH((k_node<DOF, MatfreeOp<DOF>, EPI>), dim3(nb), dim3(BLK), 0, grid->stream, o, a);
-            bytes = 16.0 * DOF * nown + (L.E ? 8.0 * L.g.own_elems() : 0.0);
-            flops = 2.0 * (8 * DOF) * (8 * DOF) * (double)L.g.own_elems();
+            if (!as_stencil) {
+                MatfreeOp<DOF> o{L.KE, L.E, L.mask, L.g};
+                TP_LAUNCH((k_node<DOF, MatfreeOp<DOF>, EPI>), dim3(nb), dim3(BLK), 0, grid->stream, o, a);
+                bytes = 16.0 * DOF * nown + (L.E ? 8.0 * L.g.own_elems() : 0.0);
+                flops = 2.0 * (8 * DOF) * (8 * DOF) * (double)L.g.own_elems();
+            }
         } else {
             DiaOp<DOF> o{L.S, L.ndof(), L.g};
             const long rows_all = nown * DOF;
@@ -834,7 +837,6 @@ struct MGSolver {
             bytes = (27.0 * DOF * DOF + 2.0 * DOF) * 8.0 * nown;
             flops = 2.0 * 27 * DOF * DOF * (double)nown;
         }
-    op_done:
         if (EPI == EPI_RESID) bytes += 8.0 * DOF * nown;
         // d (r/w), b, dinv -- the fine tile kernel instead reads b and the previous iterate (3-term form, diagonal on the fly)
         // (3-term form: the first step of a sweep -- c1 = 0 or the zero guess -- does not read a previous iterate)
