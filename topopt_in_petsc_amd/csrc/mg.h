@@ -613,7 +613,7 @@ struct MGSolver {
         Level<DOF> &L = lv[l];
         const long nown = L.g.owned_nodes();
         const int nb = (int)((nown + BLK - 1) / BLK);
-        double bytes, flops;
+        double bytes = 0.0, flops = 0.0;
         last_nblocks = nb;
         if (pend[l].ptr && (pend[l].ptr == a.out || pend[l].ptr != a.x)) TP_TRY(drain_halo(l));  // stale / about to be overwritten
         const int n_bnd = (L.g.has_lo ? 1 : 0) + (L.g.has_hi ? 1 : 0);
