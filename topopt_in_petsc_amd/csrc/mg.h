@@ -1748,7 +1748,17 @@ struct MGSolver {
         count_launch(grid, 16.0 * n, 4.0 * n);
         TP_TRY(reduce_partials<2>(grid, nb, S_BB));
         double v2[2];
-        TP_TRY(read_scal(grid, S_BB, 2, v2));
+        // the first V-cycle's fine pre-smoothing goes out BEFORE the host waits for the two norms (as the loop does for every
+        // later iteration): the device has work while the host wakes up; wasted only when the warm start is converged already
+        static const bool spec_head0 = getenv("TP_NO_SPEC_HEAD") == nullptr;
+        head_for = nullptr;
+        if (spec_head0 && opt.ksp_mode == 0 && nlv >= 2 && !sg_capturing) {
+            TP_TRY(read_scal_begin(grid, S_BB, 2));
+            TP_TRY(vcycle_head(r));
+            TP_TRY(read_scal_end(grid, 2, v2));
+        } else {
+            TP_TRY(read_scal(grid, S_BB, 2, v2));
+        }
         const double bnorm = sqrt(v2[0]);
         double rnorm = sqrt(v2[1]);
         const double ttol = fmax(opt.rtol * bnorm, opt.atol);
@@ -1758,7 +1768,6 @@ struct MGSolver {
         int rz_cur = S_RZ0, rz_old = S_RZ1;
         static const bool spec_head = getenv("TP_NO_SPEC_HEAD") == nullptr;
         static const bool fuse_cg = getenv("TP_NO_CG_FUSE") == nullptr;
-        head_for = nullptr;
         if (rnorm > ttol) {
             for (its = 1; its <= opt.max_it; its++) {
                 double *z;
