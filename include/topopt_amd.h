@@ -254,6 +254,11 @@ double tp_elasticity_level_lambda_min(const tp_elasticity *e, int level);
 /* rows of the coarsest level if the last assembly factored it for the exact coarse solve (tp_solver_opts.coarse_direct),
  * 0 if the Chebyshev run is in use (option off, level too large or distributed) */
 int tp_elasticity_coarse_direct_active(const tp_elasticity *e);
+/* Process-wide state of the recovery from one-XCD persistent kernels that gave up (their workgroups not co-resident: a
+ * shared device): how many recoveries so far, whether the one-XCD forms are off, whether the coarse factorisation is no
+ * longer deferred into the head of the solve (the softer first answer when only that chain gave up).  No reference
+ * counterpart: PETSc's KSPSolve (LinearElasticity.cc:204) has no persistent kernels. */
+int tp_xcd_status(int *giveups, int *xcd_forms_off, int *defer_off);
 int tp_elasticity_level_apply(tp_elasticity *e, int level, const double *u, double *y); /* [dev, level local dofs] */
 int tp_elasticity_level_diag(tp_elasticity *e, int level, double *d);
 int tp_elasticity_precond(tp_elasticity *e, const double *r, double *z); /* one V-cycle */

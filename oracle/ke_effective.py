@@ -18,17 +18,20 @@ import numpy as np
 M2A = [0, 1, 3, 2, 4, 5, 7, 6]
 
 
-def symke_nz(q, r, s):
+def symke_nz(q, r, s, translation_residue=True):
     if q in (0, 7):
         return True
     if q in (1, 2, 4):
         b = {1: 0, 2: 1, 4: 2}[q]
-        return r != b and s != b
+        # (b, b) of a single-bit class is the element's answer to a rigid translation along b: zero for an exact box
+        # element, the mean of the 64 rounding residues of the reference's KE otherwise -- kept since round 6
+        return (r != b and s != b) or (translation_residue and r == b and s == b)
     m = {6: 0, 5: 1, 3: 2}[q]
     return (r != m and s != m) or (r == m and s == m)
 
 
-def ke_effective(KE):
+def ke_effective(KE, translation_residue=True):
+    """translation_residue=False: the packed form of rounds 1-5 (33 values; rows sum to exactly 0)"""
     KE = np.asarray(KE, dtype=np.float64).reshape(24, 24)
     pc = lambda v: bin(v).count("1")
     # D = T KE T / 64 in double, term by term as the library's make_sym_ke accumulates it
@@ -43,11 +46,20 @@ def ke_effective(KE):
                             v = KE[3 * M2A[m] + r, 3 * M2A[m2] + s]
                             acc += -v if (pc(p & m) + pc(p2 & m2)) & 1 else v
                     D[p * 3 + r, p2 * 3 + s] = acc / 64.0
+    if translation_residue:
+        # the three translation residues are sums of 64 entries that cancel to ~1e-16 of their size: accumulated in 80-bit
+        # arithmetic (exact for 64 doubles of one magnitude), then rounded once -- make_sym_ke does the same in `long double`
+        for r in range(3):
+            acc = np.longdouble(0)
+            for m in range(8):
+                for m2 in range(8):
+                    acc += np.longdouble(KE[3 * M2A[m] + r, 3 * M2A[m2] + r])
+            D[r, r] = float(acc / np.longdouble(64))
     Dp = np.zeros((24, 24), dtype=np.longdouble)
     for q in range(8):
         for r in range(3):
             for s in range(r, 3):
-                if not symke_nz(q, r, s):
+                if not symke_nz(q, r, s, translation_residue):
                     continue
                 i, j = (q ^ (1 << r)) * 3 + r, (q ^ (1 << s)) * 3 + s
                 Dp[i, j] = Dp[j, i] = np.longdouble(0.5 * (D[i, j] + D[j, i]))

@@ -18,6 +18,7 @@ if ROOT not in sys.path:
 #   2. a per-test watchdog (SIGALRM): stacks of all threads to stderr, then the test FAILS and the session goes on;
 #   3. collection order: the HIP-vs-oracle parity files first, the subprocess / bench files last.
 SUBPROCESS_CAP_S = float(os.environ.get("TP_TEST_SUBPROCESS_CAP", "240"))
+SUBPROCESS_CEILING_S = float(os.environ.get("TP_TEST_SUBPROCESS_CEILING", "900"))   # upper bound of any explicit timeout
 PER_TEST_LIMIT_S = int(os.environ.get("TP_TEST_LIMIT", "300"))
 
 _ORDER = ["test_harness", "test_gpu_parity", "test_golden", "test_gpu_configs", "test_gpu_fine_generations", "test_gpu_refksp", "test_mma",
@@ -29,10 +30,11 @@ _plain_run = subprocess.run
 
 def hardened_run(cmd, *args, timeout=None, input=None, **kw):
     """subprocess.run with a process group per child and a killpg on expiry.  Semantics of subprocess.run are kept:
-    an explicit `timeout` is honoured as given -- the cap SUBPROCESS_CAP_S only applies to calls that pass none --, expiry
+    an explicit `timeout` is honoured up to SUBPROCESS_CEILING_S -- the cap SUBPROCESS_CAP_S only applies to calls that pass none --, expiry
     raises subprocess.TimeoutExpired (after the group is dead; .output / .stderr carry what was captured, and the tail is
     printed so that an uncaught expiry still shows where the child was), `input=` goes through communicate()."""
-    limit = timeout if timeout is not None else SUBPROCESS_CAP_S
+    # an explicit timeout is honoured up to a global ceiling (ADVICE r5: one test with a huge timeout must not stall the suite)
+    limit = min(timeout, SUBPROCESS_CEILING_S) if timeout is not None else SUBPROCESS_CAP_S
     capture = kw.pop("capture_output", False)
     check = kw.pop("check", False)
     if capture:

@@ -678,6 +678,47 @@ def test_one_xcd_kernels_give_up_path(tmp_path, where):
     assert np.abs(f["U"] - n["U"]).max() <= 1e-12 * np.abs(n["U"]).max()
 
 
+@pytest.mark.gpu
+def test_deferred_factorisation_give_up_costs_the_deferral_only(tmp_path):
+    """the coarse factorisation runs on a side stream beside the head of the solve; if THAT chain alone gives up, the
+    first answer is to stop deferring (join it at the end of the set-up, round 4's behaviour) -- the one-XCD forms stay on and the
+    exact coarse solve stays active.  TP_TEST_FORCE_GIVEUP=3 takes that branch without a real give-up: one recovery, the same
+    iteration count and solution as an undisturbed process, factorisation active in every solve."""
+    import subprocess, sys
+    worker = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import topopt_in_petsc_amd as tp\n"
+        "tp.load_library()\n"
+        "grid = tp.Grid(65, 65, 65, 1.0 / 64)\n"
+        "le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=4, nsmooth=2, ncoarse=20, rtol=1e-5, coarse_direct=1))\n"
+        "le.SetUpLoadAndBC()\n"
+        "x = grid.synth_density(12345)\n"
+        "res = []\n"
+        "for it in range(3):\n"
+        "    le.U.zero_()\n"
+        "    le.SolveState(x, 1e-9, 1.0, 3.0, hist_cap=64)\n"
+        "    res.append((le.last_its, le.last_rnorm / le.last_bnorm, le.coarse_direct_active()))\n"
+        "np.savez(sys.argv[1], U=le.U.cpu().numpy(), its=[r[0] for r in res], rel=[r[1] for r in res], cd=[r[2] for r in res], st=le.xcd_status())\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env in (("forced", {"TP_TEST_FORCE_GIVEUP": "3"}), ("plain", {})):
+        e = dict(os.environ)
+        e.pop("TP_TEST_FORCE_GIVEUP", None)
+        e.update(env)
+        out = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", worker, out], env=e, capture_output=True, text=True, timeout=200)
+        assert r.returncode == 0, r.stderr[-2000:]
+        if tag == "forced":
+            assert r.stderr.count("gave up") == 1 and "one-XCD forms stay on" in r.stderr
+        res[tag] = np.load(out)
+    f, n = res["forced"], res["plain"]
+    assert list(f["st"]) == [1, 0, 1] and list(n["st"]) == [0, 0, 0]
+    assert all(v > 0 for v in f["cd"]) and list(f["cd"]) == list(n["cd"])
+    assert list(f["its"]) == list(n["its"]) and max(f["rel"]) <= 1e-5
+    assert np.abs(f["U"] - n["U"]).max() <= 1e-12 * np.abs(n["U"]).max()
+
+
 @pytest.mark.parametrize("rfac", [9.5, 10.24])
 def test_conv_filter_streamed_radius(tp, orc, rfac):
     """ElemConn 9 and 10 (k_conv_filter_zring: the reference's default rmin = 0.08 gives 10 at 128^3 and on C3, TopOpt.cc:121,
@@ -781,8 +822,10 @@ def test_exact_coarse_solve_inverse_forms_agree(tmp_path):
 def test_effective_element_matrix(tp, orc):
     """The element matrix the fine-level kernels apply (KE in its Walsh-Hadamard block form, csrc/matfree_tile.h) as the
     library exports it (double-double) == the host restatement the parity checks hand to the arbiter (oracle/ke_effective.py),
-    bit for bit; it is KE to 1e-15 max|KE| entrywise, exactly translation invariant (KE itself: 7e-16), and the kernels really
-    apply it: on a free mesh of unit moduli the HIP operator agrees with the operator assembled from it to rounding."""
+    bit for bit; it is KE to 1e-15 max|KE| entrywise, and the kernels really apply it: on a free mesh of unit moduli the HIP
+    operator agrees with the operator assembled from it to rounding.  Round 6: a rigid translation is answered with the MEAN of
+    what the reference's KE answers (the three translation residues of T KE T / 64 are kept) -- on a free mesh of
+    unit moduli an interior node sees 8 x that mean x 8 nodal values, where rounds 1-5 gave exact zeros."""
     from oracle.ke_effective import ke_effective
     ex, ey, ez = 8, 6, 4
     nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / 128
@@ -793,7 +836,7 @@ def test_effective_element_matrix(tp, orc):
     assert kf.dtype == np.longdouble and np.array_equal(kf, ke_effective(KE))
     mx = np.abs(KE).max()
     assert 0 < float(np.abs(kf - KE).max()) <= 1e-15 * mx
-    assert float(np.abs(kf.reshape(24, 24).sum(1)).max()) == 0.0 and np.abs(KE.reshape(24, 24).sum(1)).max() > 1e-16 * mx
+    assert np.abs(KE.reshape(24, 24).sum(1)).max() > 1e-16 * mx
     # the operator: no Dirichlet dofs, E = 1 everywhere
     le.SetBC(torch.ones(3 * nx * ny * nz, dtype=torch.float64, device="cuda"), torch.zeros(3 * nx * ny * nz, dtype=torch.float64, device="cuda"))
     le.AssembleStiffnessMatrix(grid.elem_vec(1.0), 0.0, 1.0, 3.0)
@@ -802,11 +845,18 @@ def test_effective_element_matrix(tp, orc):
     y = le.MatMult(torch.from_numpy(u).cuda()).cpu().numpy()
     yo = orc.matfree_apply(nx, ny, nz, 3, np.asarray(kf, dtype=np.float64), None, None, u)
     assert np.abs(y - yo).max() <= 1e-13 * np.abs(yo).max()
-    # ... and a rigid translation is annihilated EXACTLY by it (every term of the sum cancels in the transformed basis),
-    # where the reference's KE leaves its rounding residue
-    t = np.tile(np.array([1000.0, -2000.0, 500.0]), nx * ny * nz)
-    yt = le.MatMult(torch.from_numpy(t).cuda()).cpu().numpy()
-    assert np.abs(yt).max() == 0.0
+    # ... and a rigid translation: every strain term cancels exactly in the transformed basis, what is left is the kept residue --
+    # per element and component c the same force (sum of KE's (c, c) block / 64) . (8 t_c) / 8 at each of its 8 nodes; an
+    # interior node collects it from 8 elements.  The reference's KE leaves a residue of the same size, node by node different.
+    tv = np.array([1000.0, -2000.0, 500.0])
+    t = np.tile(tv, nx * ny * nz)
+    yt = le.MatMult(torch.from_numpy(t).cuda()).cpu().numpy().reshape(nz, ny, nx, 3)
+    K2 = KE.reshape(24, 24)
+    for c in range(3):
+        d_c = float(K2[c::3, c::3].astype(np.longdouble).sum() / np.longdouble(64))
+        assert d_c != 0.0 and abs(d_c) <= 1e-15 * mx
+        inner = yt[1:-1, 1:-1, 1:-1, c]
+        assert np.abs(inner - 8.0 * d_c * tv[c]).max() <= 1e-14 * abs(8.0 * d_c * tv[c])
     assert np.abs(orc.matfree_apply(nx, ny, nz, 3, KE, None, None, t)).max() > 0.0
     grid.close()
 
@@ -863,10 +913,14 @@ def test_bench_cycle_against_the_arbiter_on_the_operator_the_kernels_apply(tp, o
     assert np.abs(out[1e-5][1] / a_eff[1e-5][1] - 1).max() <= 1e-11
     scale = np.abs(a_eff[1e-12][3]).max()
     assert np.abs(out[1e-12][3] - a_eff[1e-12][3]).max() <= 1e-11 * scale
-    # the operator's share: GPU vs arbiter on KE == arbiter on KE_eff vs arbiter on KE (to the 1e-11 above), and it is there
+    # the operator's share: GPU vs arbiter on KE == arbiter on KE_eff vs arbiter on KE (to the 1e-11 above).  Rounds 1-5: 7e-12
+    # on this mesh, 1.6e-10 at 128^3; with the translation residues kept (round 6) the packed form follows KE itself to 1e-12
     gap_gpu = abs(out[1e-12][2] / a_ke[1e-12][2] - 1)
     gap_arb = abs(a_eff[1e-12][2] / a_ke[1e-12][2] - 1)
-    assert gap_arb > 1e-13 and abs(gap_gpu - gap_arb) <= 1e-11 and gap_gpu <= 1e-10
+    assert abs(gap_gpu - gap_arb) <= 1e-11 and gap_arb <= 2e-12 and gap_gpu <= 1e-11
+    for rtol in (1e-5, 1e-12):       # ... and so does the whole residual history
+        k = min(len(out[rtol][1]), len(a_ke[rtol][1]))
+        assert np.abs(out[rtol][1][:k] / a_ke[rtol][1][:k] - 1).max() <= 1e-11
     grid.close()
 
 

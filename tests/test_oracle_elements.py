@@ -90,26 +90,35 @@ def test_lambda_bound(orc):
 
 def test_effective_element_matrix_restatement():
     """oracle/ke_effective.py (the element matrix the HIP fine-level kernels apply, restated on the host): for the
-    reference's KE of a cube and of a box it is symmetric, annihilates rigid translations EXACTLY (KE itself leaves 7e-16 of its
-    largest entry), stays within 1e-15 max|KE| of KE entrywise -- as close to KE as KE is to its own formula evaluated in 80-bit
-    arithmetic (oracle/arbiter.py) -- and keeps KE's energy on strain modes."""
+    reference's KE of a cube and of a box it is symmetric, stays within 1e-15 max|KE| of KE entrywise -- as close to KE as KE is
+    to its own formula evaluated in 80-bit arithmetic (oracle/arbiter.py) -- keeps KE's energy on strain modes, and (round 6)
+    answers a rigid translation with KE's own MEAN answer: the energy of a translation, sum of the 64 entries of a component
+    block (~1e-16 max|KE| of rounding residue in the reference's KE, LinearElasticity.cc:841-998), is reproduced to the rounding of
+    one double, spread evenly over the 8 nodes.  The packed form of rounds 1-5 (translation_residue=False) gave exact zeros."""
     import numpy as np
     from oracle import arbiter as arb
     from oracle import oracle as orc
     from oracle.ke_effective import ke_effective
+    LD = np.longdouble
     for dims in ((1.0 / 128,) * 3, (0.5, 0.25, 0.125)):
         KE = orc.hex8_ke_box(*dims, 0.3)
         kf = ke_effective(KE)
         assert kf.dtype == np.longdouble and kf.shape == (576,)
         K2, F2 = KE.reshape(24, 24), kf.reshape(24, 24)
+        F0 = ke_effective(KE, translation_residue=False).reshape(24, 24)
         mx = np.abs(KE).max()
-        assert float(np.abs(F2 - F2.T).max()) == 0.0
-        assert float(np.abs(F2.sum(axis=1)).max()) == 0.0 and np.abs(K2.sum(axis=1)).max() > 1e-17 * mx
-        for c in range(3):                      # one component translated: zero force (to the round-off of summing the 80-bit
-            t = np.zeros(24, dtype=np.longdouble)   # restatement; the kernels, working in the transformed basis, give exact zeros:
-            t[c::3] = 1000.0                        # tests/test_gpu_parity.py::test_effective_element_matrix), KE: ~1e-16
-            assert float(np.abs(F2 @ t).max()) <= 1e-18 * mx * 1000.0
-            assert float(np.abs(K2 @ t.astype(np.float64)).max()) >= 1e-17 * mx * 1000.0
+        assert float(np.abs(F2 - F2.T).max()) == 0.0 and float(np.abs(F0 - F0.T).max()) == 0.0
+        assert float(np.abs(F0.sum(axis=1)).max()) == 0.0 and np.abs(K2.sum(axis=1)).max() > 1e-17 * mx
+        for c in range(3):
+            t = np.zeros(24, dtype=LD)
+            t[c::3] = 1.0
+            assert float(np.abs(F0 @ t).max()) <= 1e-18 * mx          # rounds 1-5: zero force
+            e_ke = K2[c::3, c::3].astype(LD).sum()                     # KE's translation energy (exact in 80 bits)
+            assert abs(float(e_ke)) >= 1e-17 * mx                      # ... is rounding residue, not zero
+            f = (F2 @ t)[c::3]                                         # the packed form's answer along c: the same at every node
+            assert float(np.abs(f - f[0]).max()) <= 1e-19 * mx
+            assert abs(float(t @ (F2 @ t) - LD(float(e_ke / 64)) * 64)) <= 1e-19 * mx   # one rounding to double of e / 64
+            assert abs(float(t @ (F2 @ t) / e_ke - 1)) <= 2.3e-16
         d_eff = float(np.abs(kf - KE).max()) / mx
         d_ref = float(np.abs(KE - arb.hex8_ke_box(*dims, 0.3)).max()) / mx
         assert 0 < d_eff <= 1e-15 and d_ref <= 1e-15 and d_eff <= 4 * d_ref + 2e-16

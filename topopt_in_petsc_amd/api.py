@@ -383,6 +383,13 @@ class LinearElasticity:
         """rows of the coarsest level if the last assembly factored it (SolverOptions.coarse_direct), else 0"""
         return self.L.tp_elasticity_coarse_direct_active(self.handle)
 
+    def xcd_status(self):
+        """process-wide: (recoveries from one-XCD kernels that gave up, one-XCD forms off, factorisation no longer deferred)"""
+        import ctypes as C
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self.L.tp_xcd_status(C.byref(a), C.byref(b), C.byref(c))
+        return a.value, bool(b.value), bool(c.value)
+
     def level_vec(self, l):
         return torch.zeros(3 * self.level_nodes(l), dtype=torch.float64, device=self.grid.device)
 

@@ -34,6 +34,19 @@ inline bool &tp_xcd_disabled() {
     static bool off = false;
     return off;
 }
+// Round 6: the coarse factorisation, a chain of one-XCD kernels, runs on a side stream BESIDE the head of the
+// solve (mg.h: cd_pending) -- full-device kernels are queued while its later kernels start, so their co-residency is a
+// little less certain than on an idle device.  A give-up of THAT chain alone first costs the deferral (the factorisation is
+// joined at the end of the set-up again, round 4's behaviour), not the one-XCD forms; only a give-up without the deferral
+// switches them off.  Every recovery is counted (tp_xcd_status).
+inline bool &tp_defer_disabled() {
+    static bool off = false;
+    return off;
+}
+inline int &tp_giveup_count() {
+    static int n = 0;
+    return n;
+}
 // test switch TP_TEST_FORCE_GIVEUP = "<mode>" or "<mode>:<rank>": does it ask rank `rank` for recovery branch `mode`?
 // rank < 0: does it ask ANY rank (the collective agreement must then be reached by all of them)
 inline bool tp_test_force_giveup(int mode, int rank) {

@@ -28,12 +28,25 @@
 // full; a single-bit class only couples the two components other than that bit
 // (the third is a rigid translation / pure shear pattern with zero energy);
 // a two-bit class couples the two components of its bits and leaves the third
-// one alone on the diagonal).  33 distinct values -> they live in SGPRs.
+// one alone on the diagonal).  33 structural values -> they live in SGPRs.
+//
+// Round 6: + 3.  The (b, b) entry of the single-bit class q = 1 << b is the element's answer to a rigid translation
+// along b, D[(0,b),(0,b)] = sum of the 64 entries KE[(m,b),(m2,b)] / 64: exactly 0 for an exact box element, ~1e-16 max|KE|
+// for the reference's KE (LinearElasticity.cc:841-998, a Gauss sum in double whose rows do not quite sum to 0).  The
+// translation mode of an element has amplitude ~1e3 against strains ~1e-2, and in uniform-modulus regions this mean residue
+// is the only part of KE's rounding residue that survives assembly: dropping it moved the compliance of the 128^3 cantilever
+// by 1.59e-10 (1e-10 is the contract); with the three values kept the packed form follows KE to 5e-13 (DESIGN 2.1;
+// tools/r06_ke_residue.py ranks all 576 entries of the residue by their share).  -DSYMKE_NO_TRANSLATION_RESIDUE: rounds 1-5.
+#ifdef SYMKE_NO_TRANSLATION_RESIDUE
+constexpr bool SYMKE_TRANSL = false;
+#else
+constexpr bool SYMKE_TRANSL = true;
+#endif
 __host__ __device__ constexpr bool symke_nz(int q, int r, int s) {
     if (q == 0 || q == 7) return true;
     if (q == 1 || q == 2 || q == 4) {
         const int b = q == 1 ? 0 : (q == 2 ? 1 : 2);
-        return r != b && s != b;
+        return (r != b && s != b) || (SYMKE_TRANSL && r == b && s == b);
     }
     const int m = q == 6 ? 0 : (q == 5 ? 1 : 2);  // the component whose bit is NOT in q
     return (r != m && s != m) || (r == m && s == m);
@@ -52,7 +65,7 @@ __host__ __device__ constexpr int symke_idx(int q, int r, int s) {
             }
     return -1;
 }
-constexpr int SYMKE_N = 33;
+constexpr int SYMKE_N = SYMKE_TRANSL ? 36 : 33;
 static_assert(symke_idx(7, 2, 2) == SYMKE_N - 1, "packed size");
 
 constexpr int SYMKE_NTOT = SYMKE_N + 3;  // + 1 / KE[c][c]: the nodal diagonal is KE[c][c] * (sum of the 8 adjacent moduli)
@@ -97,6 +110,16 @@ inline double make_sym_ke(const double *KE, SymKE *out) {
                 const double b = D[(q ^ (1 << s)) * 3 + s][(q ^ (1 << r)) * 3 + r];
                 out->a[id] = 0.5 * (a + b);  // KE itself is symmetric only to rounding
             }
+    if (SYMKE_TRANSL)
+        for (int r = 0; r < 3; r++) {
+            // 64 entries that cancel to ~1e-16 of their size: summed in 80-bit arithmetic (exact here), rounded once --
+            // the double-precision sum above carries a rounding error of 10-20 % of the value (the host restatement the
+            // parity checks use does the same)
+            long double acc = 0.0L;
+            for (int m = 0; m < 8; m++)
+                for (int m2 = 0; m2 < 8; m2++) acc += (long double)KE[(3 * h_M2A[m] + r) * 24 + 3 * h_M2A[m2] + r];
+            out->a[symke_idx(1 << r, r, r)] = (double)(acc / 64.0L);
+        }
     for (int c = 0; c < 3; c++) {
         out->a[SYMKE_N + c] = 1.0 / KE[c * 24 + c];
         for (int m = 1; m < 8; m++)  // equal at all 8 corners for a box element

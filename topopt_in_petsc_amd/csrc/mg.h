@@ -448,13 +448,13 @@ struct MGSolver {
             // first triangular product (coarse_direct_apply); until then the factorisation (ONE workgroup column on one
             // XCD, 1.4 ms) runs beside the head of the solve.  TP_NO_DEFER_FACTOR=1: joined here, as in round 4.
             static const bool no_defer = getenv("TP_NO_DEFER_FACTOR") != nullptr;
-            const bool defer = direct && !no_defer && lan_done[nlv - 1] && rc == TP_OK;
+            const bool defer = direct && !no_defer && !tp_defer_disabled() && lan_done[nlv - 1] && rc == TP_OK;
             for (int l = first_level; l < nlv; l++)
                 if (lan_done[l] && !(defer && l == nlv - 1)) (void)hipStreamWaitEvent(main, lan_done[l], 0);
             for (int l = first_level; l < nlv; l++)
                 if (lan_stream[l] && !(defer && l == nlv - 1)) (void)hipStreamSynchronize(lan_stream[l]);
             if (side_stream) (void)hipStreamSynchronize(side_stream);
-            cd_pending = defer;
+            cd_pending = cd_deferred_last = defer;
             if (rc) return rc;
             for (int l = first_level; l < nlv; l++) {
                 if (direct && l == nlv - 1)
@@ -509,7 +509,19 @@ struct MGSolver {
             // fixes it, TP_REPLICATE_FROM=0 keeps the coarsest level only.
             static const int from_env = (getenv("TP_REPLICATE_FROM") && *getenv("TP_REPLICATE_FROM")) ? atoi(getenv("TP_REPLICATE_FROM")) : -1;
             if (from_env >= 2 && from_env <= nlv - 1) {
+                // a forced level must fit: one padded slab of it in the communicator's staging buffer (gather_owned), and its
+                // replicated stencil (27 DOF^2 doubles per row, on EVERY rank) within 2 GiB -- else the next thinner level
                 rep0 = from_env;
+                while (rep0 < nlv - 1) {
+                    const Geom &c = lv[rep0].g;
+                    const long pad = (long)DOF * c.plane() * (c.ez_own + 1);
+                    const double rep_bytes = 8.0 * 27 * DOF * DOF * (double)c.plane() * c.nz_glob;
+                    if (pad <= grid->comm.cap && rep_bytes <= 2147483648.0) break;
+                    fprintf(stderr, "topopt_amd: TP_REPLICATE_FROM=%d: level %d does not fit (one slab of it: %ld doubles against a staging "
+                                    "buffer of %ld; replicated stencil %.2f GB per rank, limit 2): replicating from level %d\n",
+                            from_env, rep0, pad, (long)grid->comm.cap, rep_bytes / 1e9, rep0 + 1);
+                    rep0++;
+                }
             } else if (from_env < 0) {
                 for (int l = 2; l < nlv - 1; l++)
                     if (lv[l].g.ez_own <= 2) {
@@ -1159,6 +1171,7 @@ struct MGSolver {
     // the factorisation enqueued by this assembly is still running on its side stream: the solver's stream waits for it
     // (device-side; the host does not block)
     bool cd_pending = false;
+    bool cd_deferred_last = false;  // the last assembly's factorisation ran beside the head of the solve (give-up severity)
     int join_pending_factor() {
         if (cd_pending) {
             cd_pending = false;
@@ -1190,8 +1203,10 @@ struct MGSolver {
         for (int q = 0; q < 3; q++)
             if (blocks[q]) (void)hipMemcpyAsync(&f[q], &blocks[q]->gaveup[0], sizeof(unsigned long long), hipMemcpyDeviceToHost, grid->stream);
         (void)hipStreamSynchronize(grid->stream);
-        return (f[0] | f[1] | f[2]) != 0ull;
+        gaveup_mask = (f[0] ? 1 : 0) | (f[1] ? 2 : 0) | (f[2] ? 4 : 0);
+        return gaveup_mask != 0;
     }
+    int gaveup_mask = 0;  // which control block raised the flag xcd_gaveup() found: 1 Chebyshev run, 2 Lanczos run, 4 factorisation
     void xcd_reset_controls() {
         for (XcdRunCtrl *b : {run_ctl, lan_ctl, cd.ctl})
             if (b) (void)hipMemsetAsync(b, 0, sizeof(XcdRunCtrl), grid->stream);
@@ -1752,7 +1767,9 @@ struct MGSolver {
         // later iteration): the device has work while the host wakes up; wasted only when the warm start is converged already
         static const bool spec_head0 = getenv("TP_NO_SPEC_HEAD") == nullptr;
         head_for = nullptr;
-        if (spec_head0 && opt.ksp_mode == 0 && nlv >= 2 && !sg_capturing) {
+        fine_first_done = false;  // (a previous solve that returned through TP_TRY inside its loop may have left it set)
+        // on slabs a wasted head also wastes its halo exchanges: not when max_it = 0 or the previous solve needed no iteration
+        if (spec_head0 && opt.ksp_mode == 0 && nlv >= 2 && !sg_capturing && opt.max_it > 0 && !(grid->has_comm && last_solve_its == 0)) {
             TP_TRY(read_scal_begin(grid, S_BB, 2));
             TP_TRY(vcycle_head(r));
             TP_TRY(read_scal_end(grid, 2, v2));
@@ -1872,6 +1889,8 @@ struct MGSolver {
         if (rc == TP_ERR_DIVERGED && cd.ctl) TP_HIP(hipMemsetAsync(cd.ctl, 0, sizeof(XcdRunCtrl), s));
         if (its_out) *its_out = its;
         if (rnorm_out) *rnorm_out = rnorm;
+        last_solve_its = its;
         return rc;
     }
+    int last_solve_its = -1;  // iteration count of the previous solve (-1: none yet)
 };

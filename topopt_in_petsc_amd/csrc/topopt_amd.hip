@@ -901,16 +901,46 @@ static int agree_any(tp_grid *g, bool mine, bool *any) {
     *any = v > 0.0;
     return TP_OK;
 }
-// A one-XCD persistent kernel gave up (common.h: tp_xcd_disabled): switch those forms off for the rest of the process,
-// hand their control blocks back zeroed and build the hierarchy again from the moduli with the launch-per-step forms.
-static int redo_without_xcd(tp_elasticity *e, const char *where) {
-    fprintf(stderr, "topopt_amd: a one-XCD persistent kernel gave up during %s (workgroups not co-resident: shared device?); "
-                    "redoing it with separate launches, one-XCD forms off for the rest of this process\n", where);
-    tp_xcd_disabled() = true;
+// The same agreement with a severity: 0 none, 1 soft (only the DEFERRED factorisation gave up: stop deferring), 2 hard
+// (one-XCD forms off).  The ranks take the hardest one any of them saw (sum of 1 / 4096 per rank: no rank count reaches 4096).
+static int agree_giveup(tp_grid *g, int mine, int *agreed) {
+    *agreed = mine;
+    if (!g->has_comm) return TP_OK;
+    double v = mine == 2 ? 4096.0 : (mine == 1 ? 1.0 : 0.0);
+    TP_HIP(hipMemcpyAsync(g->comm.red, &v, sizeof(double), hipMemcpyHostToDevice, g->stream));
+    TP_HIP(hipStreamSynchronize(g->stream));
+    if (g->comm.allreduce_sum(g->comm.user, 1)) return TP_ERR_COMM;
+    TP_HIP(hipMemcpyAsync(&v, g->comm.red, sizeof(double), hipMemcpyDeviceToHost, g->stream));
+    TP_HIP(hipStreamSynchronize(g->stream));
+    *agreed = v >= 4096.0 ? 2 : (v > 0.0 ? 1 : 0);
+    return TP_OK;
+}
+// A one-XCD persistent kernel gave up (common.h: tp_xcd_disabled).  Hard: switch those forms off for the rest of the process.
+// Soft (round 6): only the factorisation chain gave up, and it ran deferred beside the head of the solve -- keep the
+// one-XCD forms, join the factorisation at the end of the set-up from now on (what TP_NO_DEFER_FACTOR does).  Either way hand the
+// control blocks back zeroed and build the hierarchy again from the moduli.
+static int redo_without_xcd(tp_elasticity *e, const char *where, bool soft = false) {
+    tp_giveup_count()++;
+    if (soft) {
+        fprintf(stderr, "topopt_amd: the coarse factorisation (one-XCD kernels, deferred beside the head of the solve) gave up during %s; "
+                        "redoing it, the factorisation is joined at the end of the set-up from now on (one-XCD forms stay on)\n", where);
+        tp_defer_disabled() = true;
+    } else {
+        fprintf(stderr, "topopt_amd: a one-XCD persistent kernel gave up during %s (workgroups not co-resident: shared device?); "
+                        "redoing it with separate launches, one-XCD forms off for the rest of this process\n", where);
+        tp_xcd_disabled() = true;
+    }
     e->mg.join_side_streams();
     e->mg.xcd_reset_controls();
     TP_HIP(hipStreamSynchronize(e->grid->stream));
     return elasticity_setup_from_E(e);
+}
+// give-ups recovered from so far in this process, and what they switched off
+extern "C" int tp_xcd_status(int *giveups, int *xcd_forms_off, int *defer_off) {
+    if (giveups) *giveups = tp_giveup_count();
+    if (xcd_forms_off) *xcd_forms_off = tp_xcd_disabled() ? 1 : 0;
+    if (defer_off) *defer_off = tp_defer_disabled() ? 1 : 0;
+    return TP_OK;
 }
 extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, double Emin, double Emax, double penal) {
     if (!e->have_bc) return TP_ERR_STATE;
@@ -934,7 +964,9 @@ extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, dou
         // a Lanczos run on one XCD that gave up poisons its Ritz values with NaN (a factorisation that gave up shows in
         // the solve: tp_elasticity_solve)
         bool bad = false;
-        for (int l = 0; l <= mg.nlv; l++) bad = bad || mg.lv[l].lam != mg.lv[l].lam || mg.lv[l].lam_min != mg.lv[l].lam_min;
+        // the levels, and the slots of their replicated copies (mg.h: rix -- slot nlv + (l - rep0) holds the copy of level l >= rep0)
+        const int nslots = mg.nlv + (mg.replicate ? mg.nlv - mg.rep0 : 0);
+        for (int l = 0; l < nslots && l < MGSolver<3>::LV_SLOTS; l++) bad = bad || mg.lv[l].lam != mg.lv[l].lam || mg.lv[l].lam_min != mg.lv[l].lam_min;
         // TP_TEST_FORCE_GIVEUP=2 / =1 (tests/test_gpu_parity.py::test_one_xcd_kernels_give_up_path): take the recovery branch of
         // the set-up / of the solve once without a real give-up; "=2:R" / "=1:R" on rank R only (the multi-rank agreement)
         static const bool force = tp_test_force_giveup(2, g->rank);
@@ -1118,11 +1150,19 @@ extern "C" int tp_elasticity_solve(tp_elasticity *e, const double *RHS, double *
     // Several ranks: a divergence is seen by all of them (the residual norm is a sum over ranks), the give-up flag behind it
     // by one -- they agree on it before any of them rebuilds (agree_any is reached on every rank: rc and the test switch are
     // the same everywhere).  The reported iteration count and history are those of the SECOND solve.
-    if (!tp_xcd_disabled() && (rc == TP_ERR_DIVERGED || (force_any && rc == TP_OK))) {
-        bool any = false;
-        TP_TRY(agree_any(g, (rc == TP_ERR_DIVERGED && e->mg.gaveup_seen) || (force && rc == TP_OK), &any));
-        if (any) {
-            TP_TRY(redo_without_xcd(e, "the solve"));
+    // TP_TEST_FORCE_GIVEUP=3: the soft branch (as if the deferred factorisation alone had given up)
+    static const bool force3 = tp_test_force_giveup(3, g->rank), force3_any = tp_test_force_giveup(3, -1);
+    if (!tp_xcd_disabled() && (rc == TP_ERR_DIVERGED || ((force_any || (force3_any && !tp_defer_disabled())) && rc == TP_OK))) {
+        int mine = 0, sev = 0;
+        if (rc == TP_ERR_DIVERGED && e->mg.gaveup_seen)
+            mine = (e->mg.gaveup_mask == 4 && e->mg.cd_deferred_last && !tp_defer_disabled()) ? 1 : 2;
+        else if (rc == TP_OK && force)
+            mine = 2;
+        else if (rc == TP_OK && force3 && !tp_defer_disabled())
+            mine = 1;
+        TP_TRY(agree_giveup(g, mine, &sev));
+        if (sev) {
+            TP_TRY(redo_without_xcd(e, "the solve", sev == 1));
             TP_HIP(hipMemsetAsync(U, 0, sizeof(double) * (size_t)n, g->stream));
             rc = e->mg.solve(e->d_bN, U, its, rnorm, bnorm, hist, hist_cap);
             fprintf(stderr, "topopt_amd: the solve was repeated from a zero guess: iteration count and residual history are the second solve's\n");

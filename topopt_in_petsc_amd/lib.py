@@ -103,6 +103,7 @@ SYMBOLS = {
     "tp_elasticity_level_lambda": (_d, [_vp, _i]),
     "tp_elasticity_level_lambda_min": (_d, [_vp, _i]),
     "tp_elasticity_coarse_direct_active": (_i, [_vp]),
+    "tp_xcd_status": (_i, [C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "tp_elasticity_level_apply": (_i, [_vp, _i, _vp, _vp]),
     "tp_elasticity_level_diag": (_i, [_vp, _i, _vp]),
     "tp_elasticity_set_cycles": (_i, [_vp, _vp, _i]),
