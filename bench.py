@@ -55,6 +55,8 @@ WORKLOADS = {
     "c2_deep": dict(el=(128, 64, 64), nlvls=5, nsmooth=2, ncoarse=45, cycles="1,3,1,1"),
     "c5_deep": dict(el=(512, 256, 256), nlvls=7, nsmooth=2, ncoarse=60, cycles="1,3,1,1,1,1"),
     "tiny": dict(el=(32, 16, 16), nlvls=3, nsmooth=2, ncoarse=30),
+    # the mesh of the design-loop parity test (tests/test_bench_line.py: --design-loop against the oracle's loop), the metric mesh's recipe
+    "cant64": dict(el=(64, 32, 32), nlvls=4, nsmooth=2, ncoarse=20, cycles="1,3,1"),
 }
 
 
@@ -91,6 +93,14 @@ def parse():
                    help="wall-clock budget of the whole run: N > 1 skips the complementary scaling case when the main case took over "
                         "half of it, and a self-spawned run (python bench.py --gpus N) kills its ranks at this limit")
     p.add_argument("--no-parity", action="store_true", help="skip the comparison of the GPU step with the CPU baseline's numbers")
+    p.add_argument("--pde-rtol", type=float, default=0.0,
+                   help="workloads with the Helmholtz filter: rtol of the filter's own solve on BOTH sides (0: the reference's 1e-8, PDEFilter.cc:280); "
+                        "at <= 1e-12 the filtered densities agree to rounding and the parity object holds fx / ||r_k|| to the 1e-10 of the cone-filter workloads")
+    p.add_argument("--design-loop", type=int, default=-1,
+                   help="N > 0: after the synthetic-field measurement, run N REAL design iterations (main.cc:54-123: solve with warm start, "
+                        "sensitivities, filter, device MMA, filter) from the uniform start and report their times and CG iteration counts in "
+                        "config.design_loop; -1: 60 for the default workload on one GPU, else 0")
+    p.add_argument("--design-loop-records", action="store_true", help="keep every iteration's record (fx, gx, ch, its, ms) in config.design_loop")
     p.add_argument("--no-dense-check", action="store_true", help="parity object without the step on the dense-KE kernels (TP_NO_TILE / TP_NO_MACRO)")
     return p.parse_args()
 
@@ -252,13 +262,15 @@ def cpu_step(orc, el, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, matfree_too
                 po = dict(dict(nlvls=3, nsmooth=2, ncoarse=10), **(problem.get("pde") or {}))
                 self.f = orc.PDEFilter(nx, ny, nz, h, rmin, nlv=po["nlvls"], nsmooth=po["nsmooth"], ncoarse=po["ncoarse"])
 
+                self.kw = dict(rtol=float(problem["pde_rtol"]), maxit=300) if problem.get("pde_rtol") else {}
+
             def project(self, _ftype, x_):
                 import numpy as np_
-                xt_ = np_.clip(self.f.apply(x_)[0], 0.0, 1.0)     # Filter.cc:87-100
+                xt_ = np_.clip(self.f.apply(x_, **self.kw)[0], 0.0, 1.0)     # Filter.cc:87-100
                 return xt_, xt_
 
             def gradient(self, _ftype, _x, _xt, d):
-                return self.f.apply(d)[0]                          # Filter.cc:195-199
+                return self.f.apply(d, **self.kw)[0]                          # Filter.cc:195-199
         flt = _PdeFilter()
     else:
         flt = orc.Filter(nx, ny, nz, h, rmin)
@@ -291,7 +303,7 @@ def cpu_step(orc, el, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, matfree_too
            "fx": float(fx), "gx": float(gx), "rel_residual": float(hist[min(its, len(hist) - 1)] / hist[0]) if len(hist) else None,
            "hist": [float(v) for v in hist[:64]], "df_abs_sum": float(np.abs(df).sum()),
            "phase_seconds": {"filter": tf - t0, "assemble": t1 - tf, "solve": t2 - t1, "sensitivities+filter": t3 - t2}}
-    res["problem"] = {"ftype": ftype, "bc": bc, "rmin": rmin, "pde": problem.get("pde")}
+    res["problem"] = {"ftype": ftype, "bc": bc, "rmin": rmin, "pde": problem.get("pde"), "pde_rtol": problem.get("pde_rtol")}
     if extras_npz and ftype == 1:    # (a Helmholtz-filtered density is itself the result of a solve to rtol 1e-8: no 1e-10 to assert behind it)
         # ---- what the parity object of the line needs beyond the timed step (none of it is timed):
         # (1) the CONVERGED step: the same system solved to rtol 1e-12 from the zero guess -- compliance and raw
@@ -311,10 +323,13 @@ def cpu_step(orc, el, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, matfree_too
         if cycles:
             amg.set_cycles([int(v) for v in cycles.split(",")][: max(nlv - 1, 0)])
 
-        def arbiter_run(K, K_fine=None):
+        def arbiter_run(K, K_fine=None, K_krylov=None):
             amg.assemble(K, E, N)
+            amg.set_krylov_operator(None)
             if K_fine is not None:
                 amg.reassemble_fine(K_fine)
+            if K_krylov is not None:
+                amg.set_krylov_operator(K_krylov)
             Ua, its_a, hist_a = amg.solve(arb.f64(R * N), rtol=rtol)
             fx_a = arb.compliance_sens(nx, ny, nz, KE, Ua, xp)[0]       # (the objective is evaluated with KE itself, as on the GPU)
             Uat, its_at, _ = amg.solve(arb.f64(R * N), rtol=TIGHT_RTOL)
@@ -327,24 +342,34 @@ def cpu_step(orc, el, rtol, fine_eig, nlv, nsmooth, ncoarse, cycles, matfree_too
         # KE with the rounding residue of its box symmetry removed, 5e-16 max|KE| away from KE), the Galerkin hierarchy below it
         # from KE (csrc/galerkin.h builds it from KE's own tensors) -- tools/r05_hist_diag.py: with the hierarchy from KE_eff as
         # well the GPU's history is 5.9e-11 from the arbiter's, with this split 7.7e-13
-        from oracle.ke_effective import ke_effective
+        # Round 6: the library's KRYLOV operator (A p, initial residual) is KE_krylov = KE_eff + the translation mode's column and row
+        # of T KE T / 64 as KE has them (oracle/ke_effective.py: ke_krylov); the preconditioner's fine level stays KE_eff
+        from oracle.ke_effective import ke_effective, ke_krylov
         arb_ke, df_at = arbiter_run(KE)
         te2 = time.perf_counter()
-        KEf = ke_effective(KE)
-        arb_eff, df_eff = arbiter_run(KE, KEf)
+        KEf, KEk = ke_effective(KE), ke_krylov(KE)
+        arb_eff, df_eff = arbiter_run(KE, KEf, KEk)
         te3 = time.perf_counter()
         KEx = arb.hex8_ke_box(h, h, h, 0.3)      # the reference's formula evaluated in 80-bit arithmetic
         mx = float(np.abs(KE).max())
         arb_ke["arithmetic"] = ("x87 long double (64-bit mantissa), every operation of the oracle's algorithm: "
                                 "oracle/topopt_oracle.c rebuilt with double -> long double")
-        kf_hi = KEf.astype(np.float64)
+        kf_hi, kk_hi = KEf.astype(np.float64), KEk.astype(np.float64)
         np.savez(extras_npz, df_tight=np.asarray(df_t, dtype=np.float64), df_tight_arb=df_at, df_tight_arb_eff=df_eff,
-                 ke_eff_hi=kf_hi, ke_eff_lo=(KEf - kf_hi.astype(np.longdouble)).astype(np.float64))
+                 ke_eff_hi=kf_hi, ke_eff_lo=(KEf - kf_hi.astype(np.longdouble)).astype(np.float64),
+                 ke_kry_hi=kk_hi, ke_kry_lo=(KEk - kk_hi.astype(np.longdouble)).astype(np.float64))
         res["extras"] = {"tight_rtol": TIGHT_RTOL, "its_tight": int(its_t), "fx_tight": float(fx_t),
                          "rel_residual_tight": float(hist_t[-1] / hist_t[0]),
                          "arbiter": arb_ke, "arbiter_effective": arb_eff,
                          "element_matrix": {"max_abs_KE": mx,
                                             "KE_eff_vs_KE": float(np.abs(KEf - KE.astype(np.longdouble)).max()) / mx,
+                                            "KE_krylov_vs_KE": float(np.abs(KEk - KE.astype(np.longdouble)).max()) / mx,
+                                            # KE's answer to a unit rigid translation (24 x 3 columns) and the translation mode's answer to
+                                            # everything (3 x 24 rows): how far the two operators are from KE there, relative to max|KE|
+                                            "translation_column_defect_KE_eff":
+                                                float(max(np.abs((KEf.reshape(24, 24) - KE.reshape(24, 24).astype(np.longdouble))[:, c::3].sum(1)).max() for c in range(3))) / mx,
+                                            "translation_column_defect_KE_krylov":
+                                                float(max(np.abs((KEk.reshape(24, 24) - KE.reshape(24, 24).astype(np.longdouble))[:, c::3].sum(1)).max() for c in range(3))) / mx,
                                             "KE_vs_80bit_formula": float(np.abs(KE.astype(np.longdouble) - KEx).max()) / mx,
                                             "KE_eff_vs_80bit_formula": float(np.abs(KEf - KEx).max()) / mx,
                                             "row_sum_defect_KE": float(np.abs(KE.reshape(24, 24).sum(1)).max()) / mx,
@@ -458,6 +483,7 @@ def fine_kernel_times(tp, torch, ex, ey, ez, reps):
     spmv = timed(lambda: le.MatMult(u, y), reps)
     cheb = (timed(lambda: le.smooth(0, u, y, k, False), max(reps // 4, 2)) -
             timed(lambda: le.smooth(0, u, y, 0, False), max(reps // 4, 2))) / k
+    fine_kernel_times.krylov_ms = timed(lambda: le.MatMultKrylov(u, y), max(reps // 2, 2))   # CG's own product (+ the translation residues)
     torch.cuda.synchronize()
     grid.close()
     return spmv, cheb, (ex + 1) * (ey + 1) * (ez + 1), ex * ey * ez
@@ -514,7 +540,8 @@ def main():
         if not a.no_parity:
             extras_npz = cpu_json + ".extras.npz"
             cmd[-1] = extras_npz
-        cmd.append(json.dumps({"ftype": W.get("ftype", 1), "bc": W.get("bc", "cantilever"), "rmin": W.get("rmin"), "pde": W.get("pde"), "nlanczos": a.nlanczos or None}))
+        cmd.append(json.dumps({"ftype": W.get("ftype", 1), "bc": W.get("bc", "cantilever"), "rmin": W.get("rmin"), "pde": W.get("pde"), "nlanczos": a.nlanczos or None,
+                               "pde_rtol": a.pde_rtol or None}))
         # How many threads, and where?  All hardware threads unbound is NOT the fastest way to run these memory-bound loops
         # (measured on the 2 x 64-core host of the GPU box, tools/r04_cpu_threads.sh: 256 threads 13.9 s, 128 bound to cores
         # 7.4 s, 64 spread over the cores 5.1 s per design iteration).  The baseline is the BEST of a short list, chosen on
@@ -632,7 +659,13 @@ def main():
             self.grid = tp.Grid(nx, ny, nz_nodes, h, rank=rank, nranks=world)
             self.le = self.solver(nlv_, ncoarse_, nsmooth_, direct, cycles)
             pde = W.get("pde")
-            self.flt = tp.Filter(self.grid, ftype, rmin, tp.SolverOptions(**dict(dict(rtol=1e-8, dtol=1e3, max_it=60), **pde)) if (pde and ftype == 2) else None)
+            po = None
+            if ftype == 2 and (pde or a.pde_rtol):
+                # (the library's defaults without options: the reference's 3 levels / 10 coarse steps, PDEFilter.cc:32, :357, as CG + Chebyshev-Jacobi)
+                po = dict(dict(rtol=1e-8, dtol=1e3, max_it=60), **dict(dict(nlvls=3, nsmooth=2, ncoarse=10), **(pde or {})))
+                if a.pde_rtol:
+                    po.update(rtol=a.pde_rtol, max_it=300)
+            self.flt = tp.Filter(self.grid, ftype, rmin, tp.SolverOptions(**po) if po else None)
             g = self.grid
             self.x = g.synth_density(12345)
             self.xt, self.xp, self.df, self.dg = g.elem_vec(), g.elem_vec(), g.elem_vec(), g.elem_vec()
@@ -775,7 +808,10 @@ def main():
                   "hist_compared": k, "bounds": dict(PARITY_BOUNDS)}
         breaches = []
         B = PARITY_BOUNDS
-        pde = ftype == 2
+        pde = ftype == 2 and not (a.pde_rtol and a.pde_rtol <= 1e-12)   # (filter solved to rounding on both sides: the cone-filter bounds apply)
+        if ftype == 2 and not pde:
+            parity["note_pde"] = ("Helmholtz filter solved to rtol %g on both sides (--pde-rtol): the filtered densities agree to rounding, fx and "
+                                  "||r_k|| are held to 'vs_oracle'" % a.pde_rtol)
         if pde:
             # behind a Helmholtz filter the solver's input is itself the result of a solve to rtol 1e-8 (PDEFilter.cc:280): the
             # two filtered densities agree to ~1e-9, and everything after them to what that leaves (tests/test_gpu_configs.py)
@@ -803,7 +839,9 @@ def main():
             kf_lib = le.KE_effective()
             kf_cpu = z["ke_eff_hi"].astype(np.longdouble) + z["ke_eff_lo"].astype(np.longdouble)
             em = dict(ext["element_matrix"])
-            em["library_export_equals_restatement"] = bool(np.array_equal(kf_lib, kf_cpu))
+            kk_lib = le.KE_krylov()
+            kk_cpu = z["ke_kry_hi"].astype(np.longdouble) + z["ke_kry_lo"].astype(np.longdouble)
+            em["library_export_equals_restatement"] = bool(np.array_equal(kf_lib, kf_cpu) and np.array_equal(kk_lib, kk_cpu))
             parity["element_matrix"] = em
             if not em["library_export_equals_restatement"]:
                 breaches.append("element_matrix.library_export_equals_restatement")
@@ -874,9 +912,11 @@ def main():
                 parity["dense_KE"] = dense
                 if not dense["its_equal"]:
                     breaches.append("dense_KE.its_equal")
+                # (held against the ARBITER on KE: two double-precision runs of a 35-iteration solve differ by 1e-10 in their late
+                # ||r_k|| through summation order alone -- C2: oracle vs arbiter 4.4e-11, this run vs arbiter 5.9e-11, vs oracle 1.03e-10)
                 for key in ("fx_rel_err", "hist_max_rel_err"):
-                    if dense["vs_oracle_on_KE"][key] > B["vs_oracle"]:
-                        breaches.append("dense_KE.vs_oracle_on_KE." + key)
+                    if dense["vs_arbiter_on_KE"][key] > B["vs_oracle"]:
+                        breaches.append("dense_KE.vs_arbiter_on_KE." + key)
                 le_d.close()
                 le_d = df_d = dg_d = None
             try:
@@ -966,6 +1006,60 @@ def main():
             barrier()
         else:
             other = {"scaling": o_scal, "skipped": "%d element layers do not split into %d slabs of whole coarse layers of a %d-level hierarchy" % (ezg, world, nlv)}
+    # ---- N > 1: where the communication time goes, and whether the slab run is the one-GPU run (VERDICT r5 "next" 6).  Two more
+    # steps with the communication timer on (tp_grid_comm_timer: hook calls, host wall time inside the hooks, device time between
+    # HIP event pairs around them, per kind); then rank 0 alone solves the SAME global mesh on its own GPU, without slabs, and the
+    # residual history of the slab run is held against it: 1e-10 is the claim (the rank-ordered sums of the host-staged hooks give
+    # the same bits on every rank; ncclAllReduce's order is its own -- equal to rounding, not bitwise).
+    comm_time = one_gpu = None
+    if world > 1:
+        wd.phase("communication timing", 300)
+        keep = dict(info)
+        grid.comm_timer(True)
+        barrier()
+        tc0 = time.perf_counter()
+        for _ in range(2):
+            step(hist_cap=64)
+        barrier()
+        tc = (time.perf_counter() - tc0) / 2
+        ct = grid.comm_timer_read()
+        grid.comm_timer(False)
+        comm_time = {"ms_per_step_with_timer": 1e3 * tc, "per_step": {k: {kk: (vv / 2) for kk, vv in v.items()} for k, v in ct.items()},
+                     "note": "rank 0; host_ms = wall time inside the hooks (a host-staged hook blocks there), device_ms = between event pairs on the "
+                             "stream the operation is issued on (RCCL: the collective itself + what it waits for); overlapped halos run beside the interior kernels"}
+        hist_slab, fx_slab, its_slab = [float(v) for v in le.last_hist], info.get("fx"), le.last_its
+        info.clear()
+        info.update(keep)
+        # the same global mesh on ONE GPU (rank 0), no slabs
+        n_glob_dof = 3 * nx * ny * nz
+        fits = n_glob_dof * 8.0 * 40 < 0.6 * torch.cuda.get_device_properties(dev).total_memory
+        if a.same_device:
+            fits = fits and world * n_glob_dof * 8.0 * 40 / max(world, 1) < 0.5 * torch.cuda.get_device_properties(dev).total_memory
+        if fits:
+            wd.phase("one-GPU reference of the slab run", 600)
+            if rank == 0:
+                g1 = tp.Grid(nx, ny, nz, h)
+                le1 = tp.LinearElasticity(g1, tp.SolverOptions(nlvls=nlv, rtol=a.rtol, fine_eig=a.fine_eig, ncoarse=a.ncoarse, nlanczos=a.nlanczos or 10,
+                                                               nsmooth=a.nsmooth, coarse_direct=int(a.coarse == "direct"), cheb_lo=a.cheb_lo, cheb_hi=a.cheb_hi))
+                if a.cycles:
+                    le1.set_cycles([int(v) for v in a.cycles.split(",")])
+                le1.SetUpLoadAndBC_MBB() if bc == "mbb" else le1.SetUpLoadAndBC()
+                f1 = tp.Filter(g1, ftype, rmin)
+                x1 = g1.synth_density(12345)
+                xt1, xp1, df1, dg1 = g1.elem_vec(), g1.elem_vec(), g1.elem_vec(), g1.elem_vec()
+                f1.FilterProject(x1, xt1, xp1)
+                fx1, _ = le1.ComputeObjectiveConstraintsSensitivities(df1, dg1, xp1, Emin, Emax, penal, volfrac, hist_cap=64)
+                h1 = [float(v) for v in le1.last_hist]
+                m_ = min(len(h1), len(hist_slab))
+                one_gpu = {"mesh": "%dx%dx%d elements on one GPU (rank 0)" % (ex, ey, ez), "its_one_gpu": le1.last_its, "its_slabs": its_slab,
+                           "its_equal": le1.last_its == its_slab, "coarse_direct_one_gpu": bool(le1.coarse_direct_active()),
+                           "hist_max_rel_err": max(abs(hist_slab[i] / h1[i] - 1.0) for i in range(m_)) if m_ else None,
+                           "fx_rel_err": abs(fx_slab / fx1 - 1.0) if fx_slab else None, "claim": 1e-10}
+                g1.close()
+                g1 = le1 = f1 = x1 = xt1 = xp1 = df1 = dg1 = None
+            barrier()
+        else:
+            one_gpu = {"skipped": "the global mesh (%d DOF) does not fit beside the slab on one GPU" % n_glob_dof}
     wd.phase("roofline measurements", 300)
 
     # ---- the roofline kernel where it runs: two more steps (outside the timed region, so that the 126 event pairs per
@@ -996,6 +1090,7 @@ def main():
     t_copy = timed(lambda: (le.smooth(0, u, y, 0, False)), max(a.spmv_reps // 4, 2))
     cheb_ms = (t_smooth - t_copy) / ksm
     spmv_ms = timed(lambda: le.MatMult(u, y), a.spmv_reps)
+    krylov_ms = timed(lambda: le.MatMultKrylov(u, y), max(a.spmv_reps // 2, 2))
     b2b = {"avg_launch_ms": cheb_ms, "achieved": cheb_bytes / (cheb_ms * 1e-3) / 1e9, "frac": cheb_bytes / (cheb_ms * 1e-3) / 1e9 / 8000.0,
            "how": "HIP events around >= %d back-to-back launches (>= %.1f s) on the same vectors (Infinity Cache warm)" % (ksm * max(a.spmv_reps // 4, 2), MEASURE_S)}
     how = "back-to-back launches"
@@ -1047,7 +1142,10 @@ def main():
                          "avg_launch_ms": spmv_ms, "achieved": spmv_bytes / (spmv_ms * 1e-3) / 1e9,
                          "frac": spmv_bytes / (spmv_ms * 1e-3) / 1e9 / 8000.0,
                          "traffic": (traffic or {}).get("hbm_bytes_per_launch", None) and traffic["hbm_bytes_per_launch"] / 1e9,
-                         "fp64_tflops_dense_equiv": 1152.0 * n_el_own / (spmv_ms * 1e-3) / 1e12}}
+                         "fp64_tflops_dense_equiv": 1152.0 * n_el_own / (spmv_ms * 1e-3) / 1e12},
+                "krylov_product": {"kernel": "%s<EPI_APPLY_DOT> (CG's A p with its p . A p: the packed form + KE's translation column and row, 132 fma per "
+                                             "element more -- what keeps the residual history on the reference's KE to 1e-12, DESIGN 2.1; one launch per Krylov iteration)" % kname,
+                                   "alg_bytes_per_launch": spmv_bytes, "avg_launch_ms": krylov_ms, "frac": spmv_bytes / (krylov_ms * 1e-3) / 1e9 / 8000.0}}
     # the runner-up by total time: the level-2 operator (27 x 3 x 3 block stencil stored by diagonals, 33^3 nodes at 128^3), launched
     # 15 times per Krylov iteration.  Algorithmic bytes per SURVEY 8(d): (243 + 6) * 8 B per node of the level -- the kernel reads
     # the symmetric half of the coefficients twice over (mirrored addresses), and at 72 MB the level never leaves the Infinity
@@ -1077,12 +1175,39 @@ def main():
                 un, yn = grid.node_vec(1).normal_(), grid.node_vec(1)
                 t_pa = timed(lambda: flt.PDEApply(un, yn), a.spmv_reps)
                 pb = 16.0 * n_nd_own
-                roofline["pde_filter"] = {"kernel": "k_node<1, MatfreeOp<1>, EPI_APPLY> (scalar 27-point Helmholtz operator K_f, matrix-free from KF; PDEFilter.cc:251-264)",
+                stencil_form = not os.environ.get("TP_NO_PDE_STENCIL")
+                roofline["pde_filter"] = {"kernel": ("k_node<1, ScalarStencilOp, EPI_APPLY> (scalar Helmholtz operator K_f as the tabulated 27-point stencil it is: weights per "
+                                                     "boundary class of a node from KF; PDEFilter.cc:251-264 assembles the same matrix)") if stencil_form else
+                                                    "k_node<1, MatfreeOp<1>, EPI_APPLY> (scalar Helmholtz operator K_f by the 8-element gather from KF; TP_NO_PDE_STENCIL=1)",
                                           "alg_bytes_per_launch": pb, "avg_launch_ms": t_pa, "achieved": pb / (t_pa * 1e-3) / 1e9,
                                           "frac": pb / (t_pa * 1e-3) / 1e9 / 8000.0, "n_nodes": n_nd_own,
                                           "pde_solve_its": flt.last_pde_solve()[0],
                                           "note": "back-to-back launches; %.1f MB per launch: the vectors stay in the Infinity Cache, the launch is latency bound" % (pb / 1e6)}
                 un = yn = None
+                # the filter's own solver, reference-shaped, beside the workload's: one FilterProject each with
+                # (a) the workload's solver, (b) the reference's hierarchy and counts as PETSc options would give them on this path
+                # (3 levels, coarse 10 steps, CG + Chebyshev-Jacobi: the library's default), (c) PDEFilt::SetUpSolver AS HARD-CODED
+                # (FGMRES(20) + 3-level PCMG, GMRES(1)/Jacobi smoothers, GMRES(10)/Jacobi coarse solve; PDEFilter.cc:276-378)
+                def time_filter(f_, reps=5):
+                    xt_, xp_ = grid.elem_vec(), grid.elem_vec()
+                    f_.FilterProject(case.x, xt_, xp_)
+                    torch.cuda.synchronize()
+                    t_ = time.perf_counter()
+                    for _ in range(reps):
+                        f_.FilterProject(case.x, xt_, xp_)
+                    torch.cuda.synchronize()
+                    return {"ms_per_filter_application": 1e3 * (time.perf_counter() - t_) / reps, "its": f_.last_pde_solve()[0],
+                            "rnorm": f_.last_pde_solve()[1]}, xt_
+                cmp_ = {}
+                cmp_["workload"], xt_w = time_filter(flt)
+                cmp_["workload"]["solver"] = W.get("pde") or "library default"
+                for tag_, opts_ in (("reference_counts_cg_chebyshev", tp.SolverOptions(nlvls=3, nsmooth=2, ncoarse=10, rtol=1e-8, dtol=1e3, max_it=60)),
+                                    ("reference_hard_coded_fgmres", tp.SolverOptions.reference_pdefilter())):
+                    f2 = tp.Filter(grid, 2, rmin, opts_)
+                    cmp_[tag_], xt_2 = time_filter(f2, 3)
+                    cmp_[tag_]["xTilde_vs_workload_max_abs"] = float((xt_2 - xt_w).abs().max())
+                    f2.close()
+                roofline["pde_filter"]["solver_comparison"] = cmp_
             else:
                 xe, ye = grid.elem_vec().uniform_(), grid.elem_vec()
                 t_h = timed(lambda: flt.MultH(xe, ye), a.spmv_reps)
@@ -1109,7 +1234,50 @@ def main():
                      "traffic": rec and rec.get("hbm_bytes_per_launch") and rec["hbm_bytes_per_launch"] / 1e9},
             "cheb": {"alg_bytes_per_launch": 96.0 * nn + 8.0 * ne, "avg_launch_ms": c256,
                      "achieved": (96.0 * nn + 8.0 * ne) / (c256 * 1e-3) / 1e9, "frac": (96.0 * nn + 8.0 * ne) / (c256 * 1e-3) / 1e9 / 8000.0,
-                     "traffic": rec and rec.get("cheb_hbm_bytes_per_launch") and rec["cheb_hbm_bytes_per_launch"] / 1e9}}
+                     "traffic": rec and rec.get("cheb_hbm_bytes_per_launch") and rec["cheb_hbm_bytes_per_launch"] / 1e9},
+            # CG's own product A p (EPI_APPLY_DOT): the same bytes, + 132 fma per element for KE's translation column and row (parity of
+            # the residual history with the reference's KE) and its p . A p; one of the five fine-level operator applications
+            # of a Krylov iteration
+            "krylov_product": {"alg_bytes_per_launch": 48.0 * nn + 8.0 * ne, "avg_launch_ms": fine_kernel_times.krylov_ms,
+                               "frac": (48.0 * nn + 8.0 * ne) / (fine_kernel_times.krylov_ms * 1e-3) / 1e9 / 8000.0}}
+
+    # ---- real iterates (SURVEY 8(d) input iii; VERDICT r5 missing 5): the reference's loop main.cc:54-123 on the workload's mesh
+    # and cycle -- uniform start x = volfrac (TopOpt.cc:367-369), warm-started solves (LinearElasticity.cc:647), fscale from the
+    # first iteration, device MMA -- for N iterations.  The synthetic field of `value` never has the 1e-9 contrast of a converged
+    # design; this shows what the solver does as the contrast develops.  Not part of `value`.
+    design_loop = None
+    n_loop = a.design_loop if a.design_loop >= 0 else (60 if (world == 1 and a.workload == "cantilever128") else 0)
+    if world == 1 and n_loop > 0 and ftype == 1:
+        wd.phase("design loop", 120 + 2 * n_loop)
+        from topopt_in_petsc_amd.driver import TopOpt
+        so = tp.SolverOptions(nlvls=nlv, rtol=a.rtol, fine_eig=a.fine_eig, ncoarse=a.ncoarse, nlanczos=a.nlanczos or 10, nsmooth=a.nsmooth,
+                              coarse_direct=int(a.coarse == "direct"), cheb_lo=a.cheb_lo, cheb_hi=a.cheb_hi)
+        opt = TopOpt(nxyz=(nx, ny, nz), xc=(0.0, ex * h, 0.0, ey * h, 0.0, ez * h), nlvls=nlv, rmin=rmin, solver=so)
+        if a.cycles:
+            opt.physics.set_cycles([int(v) for v in a.cycles.split(",")])
+        recs = []
+        for _ in range(n_loop):
+            r_ = opt.step()
+            recs.append({"itr": r_["itr"], "ms": 1e3 * r_["time"], "cg_its": r_["ksp_its"], "fx": r_["fx"], "gx": r_["gx"], "ch": r_["ch"],
+                         "mnd": r_["mnd"], "mma_inner": r_["mma_inner"], "rel_residual": r_["ksp_rerr"]})
+        def window(lo, hi):
+            w = [r_ for r_ in recs if lo <= r_["itr"] <= hi]
+            return None if not w else {"iterations": "%d-%d" % (w[0]["itr"], w[-1]["itr"]), "ms_mean": sum(r_["ms"] for r_ in w) / len(w),
+                                       "ms_min": min(r_["ms"] for r_ in w), "ms_max": max(r_["ms"] for r_ in w),
+                                       "cg_its_mean": sum(r_["cg_its"] for r_ in w) / len(w), "cg_its_max": max(r_["cg_its"] for r_ in w)}
+        xp_ = opt.xPhys
+        design_loop = {"what": "main.cc:54-123 from the uniform start (x = volfrac), warm-started solves, device MMA included in the time; "
+                               "the workload's mesh, filter radius and multigrid cycle",
+                       "iterations": n_loop, "first": window(1, 10), "last": window(max(n_loop - 10, 11), n_loop) if n_loop > 10 else None,
+                       "cg_its_by_iteration": [r_["cg_its"] for r_ in recs], "ms_by_iteration": [round(r_["ms"], 3) for r_ in recs],
+                       "fx_first_last": [recs[0]["fx"], recs[-1]["fx"]], "mnd_last": recs[-1]["mnd"],
+                       "modulus_contrast_last": float((Emin + xp_.max() ** penal * (Emax - Emin)) / (Emin + xp_.min() ** penal * (Emax - Emin))),
+                       "xPhys_min_max_last": [float(xp_.min()), float(xp_.max())],
+                       "giveups_xcdoff_deferoff": list(opt.physics.xcd_status())}
+        if a.design_loop_records:
+            design_loop["records"] = recs
+        opt.grid.close()
+        opt = xp_ = None
 
     out = {
         "metric": "DOF-updates/s per design iter (assembly+PCG+filter)",
@@ -1135,7 +1303,7 @@ def main():
                    "comm_calls": dict(zip(("halo_exchanges", "all_reduces"), grid.comm_stats())) if grid.comm_kind.startswith("rccl") else None,
                    "backend": (a.backend if world > 1 else None), "halo_overlap": grid.halo_overlap,
                    "scaling_note": "weak: %dx%dx%d elements per GPU" % (ex, ey, ezg) if a.scaling == "weak" else "strong: fixed %dx%dx%d mesh" % (ex, ey, ezg), "kernel_launches_per_step": launches / max(a.steps, 1),
-                   "stated_cycle": stated,
+                   "stated_cycle": stated, "design_loop": design_loop, "comm_time": comm_time, "slabs_vs_one_gpu": one_gpu,
                    "alg_GB_per_step": alg_bytes / max(a.steps, 1) / 1e9,
                    "hot_path_alg_GBps": alg_bytes / dt / 1e9},
         "roofline": roofline,

@@ -40,6 +40,9 @@ int main(int argc, char **argv) {
                dm == nodes ? "nodes" : "elems", md, nd, pd, xs, ys, zs, xm, ym, zm, gxs, gys, gzs, gxm, gym, gzm, info.zs, info.zm,
                info.gzs, info.gzm, info.sw);
     }
+    delete[] Lx;
+    delete[] Ly;
+    delete[] Lz;
     DMDestroy(&elems);
     DMDestroy(&nodes);
     PetscFinalize();

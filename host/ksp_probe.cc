@@ -55,6 +55,8 @@ int main(int argc, char **argv) {
     const PetscErrorCode ierr = KSPCompatResolve(ksp, &o);
     if (ierr) {
         printf("KSP_PROBE error %d\n", (int)ierr);
+        KSPDestroy(&ksp);
+        PetscFinalize();
         return 1;
     }
     printf("KSP_PROBE mode %d nlvls %d rtol %g atol %g dtol %g max_it %d nsmooth %d ncoarse %d restart %d smooth_pc %d coarse_pc %d "

@@ -107,6 +107,17 @@ class LinearElasticity {
         CHKERRQ(ierr);
         return tp_elasticity_objective(e, U->d, xPhys->d, Emin, Emax, penal, volfrac, fx, gx, dfdx->d, dgdx->d);
     }
+    // LinearElasticity.cc:225-297 and :299-361: the split pair
+    PetscErrorCode ComputeObjectiveConstraints(PetscScalar *fx, PetscScalar *gx, Vec xPhys, PetscScalar Emin, PetscScalar Emax,
+                                               PetscScalar penal, PetscScalar volfrac) {
+        PetscErrorCode ierr = SolveState(xPhys, Emin, Emax, penal);
+        CHKERRQ(ierr);
+        return tp_elasticity_objective_only(e, U->d, xPhys->d, Emin, Emax, penal, volfrac, fx, gx);
+    }
+    PetscErrorCode ComputeSensitivities(Vec dfdx, Vec dgdx, Vec xPhys, PetscScalar Emin, PetscScalar Emax, PetscScalar penal,
+                                        PetscScalar /*volfrac*/) {
+        return tp_elasticity_sensitivities(e, U->d, xPhys->d, Emin, Emax, penal, dfdx->d, dgdx->d);
+    }
     Vec GetStateField() { return U; }
     PetscInt niter = 0;
     PetscScalar rerr = 0.0;

@@ -131,6 +131,12 @@ int tp_grid_comm_info(const tp_grid *g, int *rccl_ranks, int *two_communicators)
 /* The roofline kernel timed where it runs (bench.py): with on = 1 every launch of the fine level's fused operator +
  * Chebyshev step is bracketed by a pair of HIP events on the grid's stream; the read waits for the stream, returns
  * the summed elapsed time and the number of launches, and clears the list. */
+/* Timing of the slab communication where it runs (N > 1): per kind -- 0 blocking halo exchange, 1 halo exchange overlapped on
+ * the second stream, 2 all-reduce, 3 all-gather of the replicated coarse levels -- hook calls, host wall time inside the hooks and
+ * device time between HIP event pairs around them.  What the reference spends in DMGlobalToLocalBegin/End
+ * (/root/reference/LinearElasticity.cc:249-250) and MPI_Allreduce (:283, :429). */
+int tp_grid_comm_timer(tp_grid *g, int on);
+int tp_grid_comm_timer_read(tp_grid *g, long calls[4], double host_ms[4], double device_ms[4]);
 int tp_grid_kernel_timer(tp_grid *g, int on);
 int tp_grid_kernel_timer_read(tp_grid *g, double *total_ms, long *launches);
 /* the same plus the algorithmic bytes of exactly the timed launches */
@@ -208,10 +214,17 @@ int tp_elasticity_create(tp_elasticity **e, tp_grid *g, const tp_solver_opts *o)
 int tp_elasticity_create_ke(tp_elasticity **e, tp_grid *g, const tp_solver_opts *o, const double *ke_host_576);
 int tp_elasticity_destroy(tp_elasticity *e);
 int tp_elasticity_get_ke(const tp_elasticity *e, double *ke_host_576);
-/* The element matrix the fine-level kernels apply (KE with the rounding residue of its box symmetry removed: it differs
- * from KE by less than one unit in the last place of KE's largest entry), as a double-double pair hi + lo (host arrays of
- * 576).  Test/diagnostic entry point: the parity checks hand it to the extended-precision arbiter (oracle/arbiter.py). */
+/* The element matrix the fine-level kernels apply INSIDE THE PRECONDITIONER (smoother, V-cycle residual): KE in its packed
+ * Walsh-Hadamard block form, 36 values -- the 33 structural ones and KE's three translation residues; it differs from KE by
+ * less than one unit in the last place of KE's largest entry -- as a double-double pair hi + lo (host arrays of 576).
+ * Test/diagnostic entry point: the parity checks hand it to the extended-precision arbiter (the 80-bit rebuild of the CPU checker). */
 int tp_elasticity_get_ke_effective(const tp_elasticity *e, double *hi_host_576, double *lo_host_576);
+/* The element matrix of the KRYLOV operator -- A p and the initial residual of CG (KSPSolve,
+ * /root/reference/LinearElasticity.cc:204; tp_elasticity_apply_krylov): the packed form plus the translation mode's
+ * column and row of T KE T / 64 exactly as KE has them (132 more values).  On a displacement field whose translation
+ * dominates its strain (any iterate of the state solve) its action is KE's to rounding; the residual history follows the
+ * reference's KE to 1e-12.  Same double-double convention. */
+int tp_elasticity_get_ke_krylov(const tp_elasticity *e, double *hi_host_576, double *lo_host_576);
 int tp_elasticity_cantilever(tp_elasticity *e, double *N, double *RHS);      /* :143-171 */
 int tp_elasticity_set_bc(tp_elasticity *e, const double *N);                /* N [dev] */
 /* AssembleStiffnessMatrix + KSPSetOperators/KSPSetUp (:487-549, :198-200):
@@ -222,6 +235,10 @@ int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, double Emin, d
 /* MatMult with the operator  N K(x) N + (I - N).  u, y [dev, local nodes*3];
  * ghost planes of u are refreshed internally, y is valid on owned planes. */
 int tp_elasticity_apply(tp_elasticity *e, const double *u, double *y);
+/* The same product with the operator the Krylov method multiplies with inside tp_elasticity_solve (KE_krylov, see
+ * tp_elasticity_get_ke_krylov): KE's action to rounding on fields whose translation dominates their strain.
+ * tp_elasticity_apply itself applies the packed form (tp_elasticity_get_ke_effective: within 5e-16 max|KE| of KE entrywise). */
+int tp_elasticity_apply_krylov(tp_elasticity *e, const double *u, double *y);
 /* KSPSolve(ksp, RHS, U) with a warm start from U (:204, :647).  U, RHS [dev,
  * local nodes*3].  its / rnorm as KSPGetIterationNumber / KSPGetResidualNorm
  * (:212-213).  hist (host, may be NULL) receives ||b - A x_k|| for k = 0..its,
@@ -233,6 +250,14 @@ int tp_elasticity_solve(tp_elasticity *e, const double *RHS, double *U, int *its
  * U [dev, local nodes*3], xPhys, dfdx, dgdx [dev, own elements] (dgdx may be NULL). */
 int tp_elasticity_objective(tp_elasticity *e, const double *U, const double *xPhys, double Emin, double Emax,
                             double penal, double volfrac, double *fx, double *gx, double *dfdx, double *dgdx);
+/* The reference's split forms.  ComputeObjectiveConstraints minus the solve (/root/reference/LinearElasticity.cc:237-294):
+ * fx and gx of the state U, no sensitivities written. */
+int tp_elasticity_objective_only(tp_elasticity *e, const double *U, const double *xPhys, double Emin, double Emax,
+                                 double penal, double volfrac, double *fx, double *gx);
+/* ComputeSensitivities (/root/reference/LinearElasticity.cc:299-361): dfdx = -p x^(p-1) (Emax - Emin) u^T KE u and
+ * dgdx = 1/n (may be NULL) of the state U as it is -- no solve, no reduction, no host synchronisation. */
+int tp_elasticity_sensitivities(tp_elasticity *e, const double *U, const double *xPhys, double Emin, double Emax,
+                                double penal, double *dfdx, double *dgdx);
 /* introspection for parity tests */
 /* KSPSetTolerances (LinearElasticity.cc:646); a negative value keeps the current one (PETSC_DEFAULT) */
 int tp_elasticity_set_tolerances(tp_elasticity *le, double rtol, double atol, double dtol, int max_it);

@@ -30,8 +30,8 @@ def symke_nz(q, r, s, translation_residue=True):
     return (r != m and s != m) or (r == m and s == m)
 
 
-def ke_effective(KE, translation_residue=True):
-    """translation_residue=False: the packed form of rounds 1-5 (33 values; rows sum to exactly 0)"""
+def _packed_d(KE, translation_residue=True):
+    """the packed D (24 x 24, transform order p * 3 + r) as the library's make_sym_ke holds it: doubles"""
     KE = np.asarray(KE, dtype=np.float64).reshape(24, 24)
     pc = lambda v: bin(v).count("1")
     # D = T KE T / 64 in double, term by term as the library's make_sym_ke accumulates it
@@ -63,6 +63,12 @@ def ke_effective(KE, translation_residue=True):
                     continue
                 i, j = (q ^ (1 << r)) * 3 + r, (q ^ (1 << s)) * 3 + s
                 Dp[i, j] = Dp[j, i] = np.longdouble(0.5 * (D[i, j] + D[j, i]))
+    return Dp
+
+
+def _back_transform(Dp):
+    """T^T D T in 80-bit arithmetic, term by term as the library's export sums it (reference dof order)"""
+    pc = lambda v: bin(v).count("1")
     out = np.zeros((24, 24), dtype=np.longdouble)
     for m in range(8):
         for r in range(3):
@@ -75,3 +81,32 @@ def ke_effective(KE, translation_residue=True):
                             acc += -v if (pc(p & m) + pc(p2 & m2)) & 1 else v
                     out[3 * M2A[m] + r, 3 * M2A[m2] + s] = acc
     return out.reshape(-1)
+
+
+def ke_effective(KE, translation_residue=True):
+    """translation_residue=False: the packed form of rounds 1-5 (33 values; rows sum to exactly 0)"""
+    return _back_transform(_packed_d(KE, translation_residue))
+
+
+def ke_krylov(KE):
+    """The element matrix of the library's KRYLOV operator (csrc/matfree_tile.h: SYMKE_KRYLOV; library export
+    tp_elasticity_get_ke_krylov): ke_effective plus the translation mode's column D[(p,r),(0,s)] and row D[(0,r),(p,s)] of
+    D = T KE T / 64, each entry the exact (80-bit) sum of its 64 terms rounded once to double, one-sided (not averaged with its
+    mirror image: KE's asymmetry, 1.4e-17, is a tenth of these residues)."""
+    KE = np.asarray(KE, dtype=np.float64).reshape(24, 24)
+    LD = np.longdouble
+    pc = lambda v: bin(v).count("1")
+    T = np.zeros((24, 24), dtype=LD)
+    for p in range(8):
+        for m in range(8):
+            for r in range(3):
+                T[p * 3 + r, 3 * M2A[m] + r] = -1 if pc(p & m) & 1 else 1
+    Dp = _packed_d(KE, True)
+    Dx = T @ KE.astype(LD) @ T.T / 64                          # 64-term sums of doubles of one magnitude: exact in 80 bits
+    for i in range(24):
+        for j in range(24):
+            col = j < 3 and not (i < 3 and i == j)
+            row = i < 3 and j >= 3
+            if col or row:
+                Dp[i, j] = LD(float(Dx[i, j]))
+    return _back_transform(Dp)

@@ -56,6 +56,7 @@ def lib():
         L.orc_mg_set_cycles.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_mg_assemble.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_mg_reassemble_fine.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_mg_set_krylov_operator.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_mg_precond.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_mg_solve.restype = C.c_int
         L.orc_mg_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, c_real, c_real, c_real, C.c_int,
@@ -244,6 +245,15 @@ class MG:
         last assemble() stays"""
         self._keep2 = (f64(KE), self._keep[1], self._keep[2])
         self.L.orc_mg_reassemble_fine(self.h, *[_p(a) for a in self._keep2])
+
+    def set_krylov_operator(self, KE):
+        """diagnostic: the Krylov method's own products (initial residual, A p) from another element matrix than the
+        preconditioner's fine level (None: back to one operator); E and N of the last assemble()"""
+        if KE is None:
+            self.L.orc_mg_set_krylov_operator(self.h, None, None, None)
+        else:
+            self._keep3 = (f64(KE), self._keep[1], self._keep[2])
+            self.L.orc_mg_set_krylov_operator(self.h, *[_p(a) for a in self._keep3])
 
     def fine_matfree(self, on=True):
         """CPU baseline variant: apply the fine-level operator of the solve matrix-free (OpenMP gather over the 8

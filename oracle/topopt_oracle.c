@@ -679,6 +679,9 @@ typedef struct {
     int coarse_direct;
     long chol_hb;
     double *chol;
+    /* diagnostic (round 6): a separate operator for the Krylov method's own products A x0, A p (NULL: A[0]); the
+     * preconditioner's fine level stays A[0] */
+    csr_t *Akry;
 } orc_mg_t;
 
 /* largest eigenvalue of the symmetric tridiagonal (a[0..m-1], b[0..m-2]) by
@@ -949,7 +952,15 @@ ORC_API void orc_mg_destroy(orc_mg_t *s) {
         free(s->d[l]);
     }
     free(s->chol);
+    csr_free(s->Akry);
     free(s);
+}
+/* Diagnostic: the operator of the KRYLOV METHOD (initial residual, A p) from another element matrix than
+ * the one the preconditioner's fine level was assembled from; KE = NULL removes it.  Which of the two uses of the fine-level
+ * operator carries the sensitivity of the late residual history to the element matrix's rounding residue? */
+ORC_API void orc_mg_set_krylov_operator(orc_mg_t *s, const double *KE, const double *E, const double *N) {
+    csr_free(s->Akry);
+    s->Akry = KE ? assemble_csr(s->nx[0], s->ny[0], s->nz[0], s->dof, KE, E, N) : NULL;
 }
 
 /* Diagnostic: replace ONLY the fine-level operator and its Jacobi diagonal by the one assembled from another
@@ -1091,7 +1102,7 @@ ORC_API void orc_mg_precond(orc_mg_t *s, const double *r, double *z) {
  * (used as an independent cross-check in the tests). */
 ORC_API int orc_mg_solve(orc_mg_t *s, const double *b, double *x, double rtol, double atol, double dtol, int maxit,
                          int use_pc, double *hist, double *rnorm_out) {
-    const csr_t *A = s->A[0];
+    const csr_t *A = s->Akry ? s->Akry : s->A[0];
     long n         = A->nrow;
     double *r = (double *)xmalloc(sizeof(double) * (size_t)n), *z = (double *)xmalloc(sizeof(double) * (size_t)n),
            *p = (double *)xmalloc(sizeof(double) * (size_t)n), *w = (double *)xmalloc(sizeof(double) * (size_t)n);

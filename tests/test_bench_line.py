@@ -51,6 +51,8 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert em["library_export_equals_restatement"] is True and 0 < em["KE_eff_vs_KE"] <= 1e-15, em
     # round 6: the packed form keeps KE's translation residues (three values) -- its translation energy is KE's, to one rounding
     assert em["translation_residue_kept"] is True and 0 < em["translation_energy_KE"] and em["translation_energy_KE_eff_vs_KE"] <= 1e-3, em
+    # ... and the Krylov operator (A p, initial residual, MatMult) also KE's whole answer to a rigid translation
+    assert 0 < em["KE_krylov_vs_KE"] <= 1e-15 and em["translation_column_defect_KE_krylov"] <= 1e-18 < em["translation_column_defect_KE_eff"], em
     # (1) the GPU against the 80-bit arbiter on that operator: iteration counts, ||r_k||, compliance -- 1e-10, as north_star has it
     ar = p["arbiter"]
     ge = ar["gpu_vs_arbiter_on_KE_eff"]
@@ -77,6 +79,56 @@ def test_bench_exits_nonzero_when_a_parity_bound_breaks():
     assert len(lines) == 1
     p = json.loads(lines[0])["parity"]
     assert p["ok"] is False and "converged.gpu_vs_arbiter_on_KE_eff.fx_rel_err" in p["breaches"] and "parity bounds broken" in r.stderr
+
+
+@pytest.mark.gpu
+def test_design_loop_mode_against_the_oracle_loop():
+    """`bench.py --design-loop N` (real iterates: main.cc:54-123 from the uniform start, warm-started solves LinearElasticity.cc:647,
+    device MMA) at 64 x 32 x 32 with the metric mesh's recipe (4 levels, Chebyshev(2), level 2 cycled three times, exact coarse solve):
+    the first 5 iterations' CG iteration counts, fx, gx and design change against the same loop driven by the oracle (assembled CSR,
+    oracle MMA)."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as orc
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cant64", "--steps", "1", "--warmup", "1", "--no-cube256",
+                        "--no-stated-cycle", "--no-cpu-baseline", "--design-loop", "5", "--design-loop-records"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.split("\n") if ln.strip()][0])
+    dl = d["config"]["design_loop"]
+    assert dl["iterations"] == 5 and len(dl["records"]) == 5 and dl["first"]["iterations"] == "1-5" and dl["giveups_xcdoff_deferoff"] == [0, False, False]
+    ex, ey, ez, nlv = 64, 32, 32, 4
+    nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
+    rmin = 2.56 * h
+    KE = orc.hex8_ke_box(h, h, h, 0.3)
+    N, R = orc.cantilever_bc(nx, ny, nz, h)
+    flt = orc.Filter(nx, ny, nz, h, rmin)
+    mg = orc.MG(nx, ny, nz, 3, nlv, 2, 20)
+    mg.set_coarse_direct(True)
+    mg.set_cycles([1, 3, 1])
+    x = np.full(ex * ey * ez, 0.12)
+    xt, xp = flt.project(1, x)
+    mma = orc.MMA(x, 1)
+    xold = x.copy()
+    U = np.zeros(3 * nx * ny * nz)
+    fscale = None
+    for it in range(5):
+        rec = dl["records"][it]
+        mg.assemble(KE, orc.simp(xp), N)
+        U, its, hist = mg.solve(R * N, x0=U, rtol=1e-5)
+        fx, gx, df, dg = orc.compliance_sens(nx, ny, nz, KE, U, xp)
+        if fscale is None:
+            fscale = 10.0 / fx
+        df = flt.gradient(1, x, xt, df * fscale)
+        dg = flt.gradient(1, x, xt, dg)
+        xmin, xmax = mma.SetOuterMovelimit(0.0, 1.0, 0.2, x)
+        x = mma.Update(x, df, [gx], [dg], xmin, xmax)
+        ch = mma.DesignChange(x, xold)
+        xt, xp = flt.project(1, x)
+        assert rec["itr"] == it + 1 and rec["cg_its"] == its, (it, rec, its)
+        assert rec["fx"] == pytest.approx(fx, rel=1e-8), (it, rec["fx"], fx)
+        assert rec["gx"] == pytest.approx(gx, abs=1e-10) and rec["ch"] == pytest.approx(ch, abs=1e-7)
+        assert rec["mnd"] == pytest.approx(orc.mnd(xp), rel=1e-7)
 
 
 def _check_two_rank_line(r, scaling):

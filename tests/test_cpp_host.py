@@ -262,3 +262,35 @@ def test_solver_configuration_the_compat_layer_resolves():
     assert "more than one rank" in out.stderr and "KSP_PROBE error 56" in out.stdout
     out, o = _ksp_probe("le", 4, *FAST, nranks=2)
     assert out.returncode == 0 and out.stdout.count("KSP_PROBE mode 0") == 2
+
+
+def test_host_boundary_under_address_and_ub_sanitizers(tmp_path):
+    """SURVEY 5 / VERDICT r5: the host side of the boundary -- the PETSc-named shim (hand-rolled reference counting, borrowed
+    references), the shared-memory job of host/slab_comm.h and the MPI subset on top of it -- built with
+    -fsanitize=address,undefined (host/Makefile: `make asan`) and driven, without a GPU, by every CPU probe this file runs on the
+    normal build plus host/refcount_probe (the ownership pattern of LinearElasticity.cc:689-707: interpolations handed to PCMG and
+    destroyed by the caller, the operator handed to the KSP, coarse meshes destroyed before the solver): no sanitizer report, no
+    leak, every probe exits 0."""
+    _build()
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "asan"], stdout=subprocess.DEVNULL)
+    A = os.path.join(ROOT, "host", "_asan")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:halt_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    fast = ("-ksp_type cg -mg_levels_ksp_type chebyshev -mg_levels_pc_type jacobi -mg_coarse_ksp_type chebyshev -mg_coarse_pc_type jacobi").split()
+    runs = [
+        ([os.path.join(A, "slabrun"), "-n", "1", os.path.join(A, "slab_selftest")], 0),
+        ([os.path.join(A, "slabrun"), "-n", "3", os.path.join(A, "slab_selftest")], 0),
+        ([os.path.join(A, "slabrun"), "-n", "4", os.path.join(A, "dmda_probe"), "9", "5", "17", "2"], 0),
+        ([os.path.join(A, "slabrun"), "-n", "3", os.path.join(A, "mpi_probe"), str(tmp_path / "p.bin")], 0),
+        ([os.path.join(A, "ksp_probe"), "le", "4"], 0),
+        ([os.path.join(A, "ksp_probe"), "pde", "3"] + fast, 0),
+        ([os.path.join(A, "ksp_probe"), "le", "5"] + fast + ["-mg_levels_ksp_max_it", "2", "-ksp_rtol", "1e-7"], 0),
+        ([os.path.join(A, "ksp_probe"), "le", "4", "-pc_type", "gamg"], 1),                       # the refused path frees its objects too
+        ([os.path.join(A, "slabrun"), "-n", "2", os.path.join(A, "ksp_probe"), "le", "4"] + fast, 0),
+        ([os.path.join(A, "refcount_probe"), "17", "9", "9", "3"], 0),
+        ([os.path.join(A, "refcount_probe"), "9", "9", "9", "1"], 0),
+        ([os.path.join(A, "slabrun"), "-n", "2", os.path.join(A, "refcount_probe"), "17", "9", "17", "4"], 0),
+    ]
+    for cmd, want in runs:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=120, env=env)
+        assert out.returncode == want, (cmd, out.returncode, out.stdout[-1500:], out.stderr[-3000:])
+        assert "Sanitizer" not in out.stderr and "runtime error" not in out.stderr, (cmd, out.stderr[-3000:])

@@ -678,6 +678,41 @@ def test_one_xcd_kernels_give_up_path(tmp_path, where):
     assert np.abs(f["U"] - n["U"]).max() <= 1e-12 * np.abs(n["U"]).max()
 
 
+def test_split_objective_and_sensitivities_equal_the_fused_form(tp, orc):
+    """LinearElasticity.cc:225-297 + :299-361 (ComputeObjectiveConstraints, then ComputeSensitivities on the state it left) against
+    :363-445 (the fused method): the same fx, gx, dfdx, dgdx bit for bit, the same iteration count; and against the oracle."""
+    ex, ey, ez, nlv = 32, 16, 16, 3
+    nx, ny, nz, h = ex + 1, ey + 1, ez + 1, 1.0 / ey
+    grid = tp.Grid(nx, ny, nz, h)
+    xp = grid.synth_density()
+    res = []
+    for split in (False, True):
+        le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=nlv, rtol=1e-9))
+        le.SetUpLoadAndBC()
+        df, dg = grid.elem_vec(), grid.elem_vec()
+        if split:
+            fx, gx = le.ComputeObjectiveConstraints(xp, 1e-9, 1.0, 3.0, 0.12)
+            assert float(df.abs().max()) == 0.0                      # nothing written yet
+            le.ComputeSensitivities(df, dg, xp, 1e-9, 1.0, 3.0, 0.12)
+        else:
+            fx, gx = le.ComputeObjectiveConstraintsSensitivities(df, dg, xp, 1e-9, 1.0, 3.0, 0.12)
+        res.append((fx, gx, le.last_its, df.cpu().numpy(), dg.cpu().numpy()))
+        le.close()
+    a, b = res
+    assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2]
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+    KE = orc.hex8_ke_box(h, h, h, 0.3)
+    N, R = orc.cantilever_bc(nx, ny, nz, h)
+    mg = orc.MG(nx, ny, nz, 3, nlv)
+    xpn = xp.cpu().numpy()
+    mg.assemble(KE, orc.simp(xpn), N)
+    U, its, _ = mg.solve(R * N, rtol=1e-9)
+    fo, go, dfo, dgo = orc.compliance_sens(nx, ny, nz, KE, U, xpn)
+    assert b[2] == its and abs(b[0] / fo - 1) <= 1e-9 and abs(b[1] - go) <= 1e-13
+    assert np.abs(b[3] - dfo).max() <= 1e-8 * np.abs(dfo).max() and np.abs(b[4] - dgo).max() <= 1e-16
+    grid.close()
+
+
 @pytest.mark.gpu
 def test_deferred_factorisation_give_up_costs_the_deferral_only(tmp_path):
     """the coarse factorisation runs on a side stream beside the head of the solve; if THAT chain alone gives up, the
@@ -832,10 +867,11 @@ def test_effective_element_matrix(tp, orc):
     grid = tp.Grid(nx, ny, nz, h)
     le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=1))
     KE = le.KE
-    kf = le.KE_effective()
-    assert kf.dtype == np.longdouble and np.array_equal(kf, ke_effective(KE))
+    from oracle.ke_effective import ke_krylov
+    kf, kk = le.KE_effective(), le.KE_krylov()
+    assert kf.dtype == np.longdouble and np.array_equal(kf, ke_effective(KE)) and np.array_equal(kk, ke_krylov(KE))
     mx = np.abs(KE).max()
-    assert 0 < float(np.abs(kf - KE).max()) <= 1e-15 * mx
+    assert 0 < float(np.abs(kf - KE).max()) <= 1e-15 * mx and 0 < float(np.abs(kk - KE).max()) <= 1e-15 * mx
     assert np.abs(KE.reshape(24, 24).sum(1)).max() > 1e-16 * mx
     # the operator: no Dirichlet dofs, E = 1 everywhere
     le.SetBC(torch.ones(3 * nx * ny * nz, dtype=torch.float64, device="cuda"), torch.zeros(3 * nx * ny * nz, dtype=torch.float64, device="cuda"))
@@ -843,21 +879,29 @@ def test_effective_element_matrix(tp, orc):
     rng = np.random.default_rng(5)
     u = rng.standard_normal(3 * nx * ny * nz)
     y = le.MatMult(torch.from_numpy(u).cuda()).cpu().numpy()
-    yo = orc.matfree_apply(nx, ny, nz, 3, np.asarray(kf, dtype=np.float64), None, None, u)
+    yo = orc.matfree_apply(nx, ny, nz, 3, np.asarray(kf, dtype=np.float64), None, None, u)     # MatMult: the packed form
     assert np.abs(y - yo).max() <= 1e-13 * np.abs(yo).max()
-    # ... and a rigid translation: every strain term cancels exactly in the transformed basis, what is left is the kept residue --
-    # per element and component c the same force (sum of KE's (c, c) block / 64) . (8 t_c) / 8 at each of its 8 nodes; an
-    # interior node collects it from 8 elements.  The reference's KE leaves a residue of the same size, node by node different.
+    y = le.MatMultKrylov(torch.from_numpy(u).cuda()).cpu().numpy()
+    yo = orc.matfree_apply(nx, ny, nz, 3, np.asarray(kk, dtype=np.float64), None, None, u)     # the Krylov method's product
+    assert np.abs(y - yo).max() <= 1e-13 * np.abs(yo).max()
+    # ... and a rigid translation through the Krylov operator (MatMultKrylov): every strain term cancels exactly in the transformed
+    # basis, what is left is KE's own answer to the translation, node by node -- the matrix-free gather with the reference's KE,
+    # summed in 80-bit arithmetic (in double its 8 x 24 terms of size |KE| |t| cancel to 1e-16 of themselves), gives the same
+    # vector; the packed form alone answers with a different vector of the same size (exact zeros before round 6)
+    from oracle import arbiter as arb
     tv = np.array([1000.0, -2000.0, 500.0])
     t = np.tile(tv, nx * ny * nz)
-    yt = le.MatMult(torch.from_numpy(t).cuda()).cpu().numpy().reshape(nz, ny, nx, 3)
+    yt = le.MatMultKrylov(torch.from_numpy(t).cuda()).cpu().numpy()
+    yk = np.asarray(arb.matfree_apply(nx, ny, nz, 3, KE.astype(np.longdouble), None, None, t.astype(np.longdouble)), dtype=np.float64)
+    assert np.abs(yk).max() > 0.0 and np.abs(yt - yk).max() <= 5e-3 * np.abs(yk).max()
+    # the packed form: the mean answer only -- per element fhat[c][0] = d_c (8 t_c), the same at its 8 nodes; 8 elements per interior node
+    y36 = le.MatMult(torch.from_numpy(t).cuda()).cpu().numpy()
+    assert np.abs(y36 - yk).max() >= 0.1 * np.abs(yk).max()
     K2 = KE.reshape(24, 24)
     for c in range(3):
         d_c = float(K2[c::3, c::3].astype(np.longdouble).sum() / np.longdouble(64))
-        assert d_c != 0.0 and abs(d_c) <= 1e-15 * mx
-        inner = yt[1:-1, 1:-1, 1:-1, c]
-        assert np.abs(inner - 8.0 * d_c * tv[c]).max() <= 1e-14 * abs(8.0 * d_c * tv[c])
-    assert np.abs(orc.matfree_apply(nx, ny, nz, 3, KE, None, None, t)).max() > 0.0
+        inner = y36.reshape(nz, ny, nx, 3)[1:-1, 1:-1, 1:-1, c]
+        assert d_c != 0.0 and np.abs(inner - 64.0 * d_c * tv[c]).max() <= 1e-14 * abs(64.0 * d_c * tv[c])
     grid.close()
 
 
@@ -886,18 +930,19 @@ def test_bench_cycle_against_the_arbiter_on_the_operator_the_kernels_apply(tp, o
         df, dg = grid.elem_vec(), grid.elem_vec()
         fx, _ = le.ComputeObjectiveConstraintsSensitivities(df, dg, xp, 1e-9, 1.0, 3.0, 0.12, hist_cap=200)
         out[rtol] = (le.last_its, np.array(le.last_hist), fx, df.cpu().numpy())
-        kf, KE = le.KE_effective(), le.KE
+        kf, kk, KE = le.KE_effective(), le.KE_krylov(), le.KE
         le.close()
     N, R = orc.cantilever_bc(nx, ny, nz, h)
     E = orc.simp(xpn)
 
-    def arbiter(K, K_fine=None):
+    def arbiter(K, K_fine=None, K_krylov=None):
         mg = arb.MG(nx, ny, nz, 3, nlv, 2, 20)
         mg.set_coarse_direct(True)
         mg.set_cycles(cyc)
         mg.assemble(K, E, N)
-        if K_fine is not None:     # the operators the library applies: fine level from KE_eff, Galerkin hierarchy from KE
-            mg.reassemble_fine(K_fine)
+        if K_fine is not None:     # the operators the library applies: the preconditioner's fine level from KE_eff, Galerkin hierarchy
+            mg.reassemble_fine(K_fine)       # from KE, the Krylov method's own products from KE_krylov
+            mg.set_krylov_operator(K_krylov)
         res = {}
         for rtol in (1e-5, 1e-12):
             U, its, hist = mg.solve(arb.f64(R * N), rtol=rtol)
@@ -905,7 +950,7 @@ def test_bench_cycle_against_the_arbiter_on_the_operator_the_kernels_apply(tp, o
             res[rtol] = (its, np.asarray(hist, dtype=np.float64), float(fx), np.asarray(df, dtype=np.float64))
         return res
 
-    a_eff, a_ke = arbiter(KE, kf), arbiter(KE)
+    a_eff, a_ke = arbiter(KE, kf, kk), arbiter(KE)
     for rtol in (1e-5, 1e-12):
         its, hist, fx, df = out[rtol]
         assert its == a_eff[rtol][0] == a_ke[rtol][0]
@@ -917,9 +962,10 @@ def test_bench_cycle_against_the_arbiter_on_the_operator_the_kernels_apply(tp, o
     # on this mesh, 1.6e-10 at 128^3; with the translation residues kept (round 6) the packed form follows KE itself to 1e-12
     gap_gpu = abs(out[1e-12][2] / a_ke[1e-12][2] - 1)
     gap_arb = abs(a_eff[1e-12][2] / a_ke[1e-12][2] - 1)
-    assert abs(gap_gpu - gap_arb) <= 1e-11 and gap_arb <= 2e-12 and gap_gpu <= 1e-11
-    for rtol in (1e-5, 1e-12):       # ... and so does the whole residual history
-        k = min(len(out[rtol][1]), len(a_ke[rtol][1]))
+    assert abs(gap_gpu - gap_arb) <= 1e-11 and gap_arb <= 1e-13 and gap_gpu <= 1e-11
+    for rtol in (1e-5, 1e-12):       # ... and so does the whole residual history: the arbiter itself does not move (1e-13) when KE is
+        k = min(len(out[rtol][1]), len(a_ke[rtol][1]))      # replaced by the library's pair of operators
+        assert np.abs(a_eff[rtol][1][:k] / a_ke[rtol][1][:k] - 1).max() <= 1e-12
         assert np.abs(out[rtol][1][:k] / a_ke[rtol][1][:k] - 1).max() <= 1e-11
     grid.close()
 

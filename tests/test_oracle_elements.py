@@ -125,3 +125,34 @@ def test_effective_element_matrix_restatement():
         rng = np.random.default_rng(3)
         u = rng.standard_normal(24)
         assert abs(float(u @ (F2 @ u)) / (u @ K2 @ u) - 1) <= 1e-14
+
+
+def test_krylov_element_matrix_restatement():
+    """oracle/ke_effective.py: ke_krylov -- the element matrix of the library's Krylov operator (the plain products; DESIGN 2.1,
+    round 6): the packed form plus the translation mode's column and row of T KE T / 64 as the reference's KE
+    (LinearElasticity.cc:841-998) has them.  Its answer to a rigid translation (24 x 3) and the translation mode's answer to any
+    field (3 x 24) are KE's to the rounding of one double per entry of the transformed matrix (1e-19 max|KE|), where the packed form
+    alone is 3e-16 away; entrywise it stays within 1e-15 max|KE| of KE, and it equals the packed form on every pair of non-translation
+    modes."""
+    import numpy as np
+    from oracle import oracle as orc
+    from oracle.ke_effective import ke_effective, ke_krylov
+    LD = np.longdouble
+    for dims in ((1.0 / 128,) * 3, (0.5, 0.25, 0.125)):
+        KE = orc.hex8_ke_box(*dims, 0.3)
+        K = KE.reshape(24, 24).astype(LD)
+        Fe, Fk = ke_effective(KE).reshape(24, 24), ke_krylov(KE).reshape(24, 24)
+        mx = float(np.abs(KE).max())
+        assert 0 < float(np.abs(Fk - K).max()) <= 1e-15 * mx
+        for c in range(3):
+            t = np.zeros(24, dtype=LD)
+            t[c::3] = 1.0
+            assert float(np.abs(Fk @ t - K @ t).max()) <= 1e-18 * mx and float(np.abs(Fe @ t - K @ t).max()) >= 5e-17 * mx     # column
+            assert float(np.abs(t @ Fk - t @ K).max()) <= 1e-18 * mx and float(np.abs(t @ Fe - t @ K).max()) >= 5e-17 * mx     # row
+        # strain modes (zero mean per component) to strain modes: the packed form
+        rng = np.random.default_rng(5)
+        u, v = rng.standard_normal(24), rng.standard_normal(24)
+        for c in range(3):
+            u[c::3] -= u[c::3].mean()
+            v[c::3] -= v[c::3].mean()
+        assert abs(float(v.astype(LD) @ ((Fk - Fe) @ u.astype(LD)))) <= 1e-17 * mx * np.abs(u).max() * np.abs(v).max() * 24

@@ -135,6 +135,17 @@ class Grid:
         _chk(self.L.tp_grid_reduction_selftest(self.handle, int(n), int(reps), C.byref(bad)), "tp_grid_reduction_selftest")
         return bad.value
 
+    def comm_timer(self, on):
+        """N > 1: start / stop collecting the communication timing (tp_grid_comm_timer)"""
+        _chk(self.L.tp_grid_comm_timer(self.handle, int(on)), "tp_grid_comm_timer")
+
+    def comm_timer_read(self):
+        """-> {kind: {"calls", "host_ms", "device_ms"}} for the kinds halo_blocking, halo_overlapped, all_reduce, all_gather"""
+        n, h, d = (C.c_long * 4)(), (C.c_double * 4)(), (C.c_double * 4)()
+        _chk(self.L.tp_grid_comm_timer_read(self.handle, n, h, d), "tp_grid_comm_timer_read")
+        kinds = ("halo_blocking", "halo_overlapped", "all_reduce", "all_gather")
+        return {k: {"calls": int(n[i]), "host_ms": float(h[i]), "device_ms": float(d[i])} for i, k in enumerate(kinds)}
+
     def kernel_timer(self, on):
         """bracket every launch of the fine level's fused Chebyshev step with a HIP event pair (bench.py's roofline)"""
         _chk(self.L.tp_grid_kernel_timer(self.handle, int(on)), "tp_grid_kernel_timer")
@@ -283,11 +294,20 @@ class LinearElasticity:
         return ke
 
     def KE_effective(self):
-        """the element matrix the fine-level kernels apply, as a numpy.longdouble array of 576 (hi + lo of the library's
-        double-double pair): KE with the rounding residue of its box symmetry removed, < 1 ulp of max|KE| away from KE"""
+        """the element matrix the fine-level kernels apply inside the preconditioner (smoother, V-cycle residual), as a
+        numpy.longdouble array of 576 (hi + lo of the library's double-double pair): KE in its packed block form (36 values),
+        < 1 ulp of max|KE| away from KE"""
         import numpy as np
         hi, lo = np.zeros(576), np.zeros(576)
         _chk(self.L.tp_elasticity_get_ke_effective(self.handle, hi.ctypes.data, lo.ctypes.data), "tp_elasticity_get_ke_effective")
+        return hi.astype(np.longdouble) + lo.astype(np.longdouble)
+
+    def KE_krylov(self):
+        """the element matrix of the Krylov operator (the plain products: A p and the initial residual of CG, MatMult): the packed
+        form plus the translation mode's column and row of T KE T / 64 as KE has them; numpy.longdouble array of 576"""
+        import numpy as np
+        hi, lo = np.zeros(576), np.zeros(576)
+        _chk(self.L.tp_elasticity_get_ke_krylov(self.handle, hi.ctypes.data, lo.ctypes.data), "tp_elasticity_get_ke_krylov")
         return hi.astype(np.longdouble) + lo.astype(np.longdouble)
 
     def SetUpLoadAndBC(self):
@@ -327,6 +347,13 @@ class LinearElasticity:
         _chk(self.L.tp_elasticity_apply(self.handle, _ptr(u), _ptr(y)), "tp_elasticity_apply")
         return y
 
+    def MatMultKrylov(self, u, y=None):
+        """the product CG multiplies with inside KSPSolve (the operator from KE_krylov(): KE's action to rounding on
+        translation-dominated fields); MatMult applies the packed form (KE_effective())"""
+        y = torch.zeros_like(u) if y is None else y
+        _chk(self.L.tp_elasticity_apply_krylov(self.handle, _ptr(u), _ptr(y)), "tp_elasticity_apply_krylov")
+        return y
+
     def KSPSolve(self, hist_cap=0):
         import numpy as np
         its, rn, bn = C.c_int(), C.c_double(), C.c_double()
@@ -357,6 +384,19 @@ class LinearElasticity:
         """LinearElasticity.cc:363-445 -> (fx, gx)"""
         self.SolveState(xPhys, Emin, Emax, penal, hist_cap)
         return self.Objective(xPhys, Emin, Emax, penal, volfrac, dfdx, dgdx)
+
+    def ComputeObjectiveConstraints(self, xPhys, Emin, Emax, penal, volfrac, hist_cap=0):
+        """LinearElasticity.cc:225-297: solve, then fx and gx -- no sensitivities -> (fx, gx)"""
+        self.SolveState(xPhys, Emin, Emax, penal, hist_cap)
+        fx, gx = C.c_double(), C.c_double()
+        _chk(self.L.tp_elasticity_objective_only(self.handle, _ptr(self.U), _ptr(xPhys), Emin, Emax, penal, volfrac,
+                                                 C.byref(fx), C.byref(gx)), "tp_elasticity_objective_only")
+        return fx.value, gx.value
+
+    def ComputeSensitivities(self, dfdx, dgdx, xPhys, Emin, Emax, penal, volfrac=0.0):
+        """LinearElasticity.cc:299-361: dfdx, dgdx of the current state U (no solve)"""
+        _chk(self.L.tp_elasticity_sensitivities(self.handle, _ptr(self.U), _ptr(xPhys), Emin, Emax, penal, _ptr(dfdx),
+                                                _ptr(dgdx) if dgdx is not None else None), "tp_elasticity_sensitivities")
 
     # ---- introspection used by the parity tests ----------------------------
     def petsc_options(self):

@@ -416,6 +416,7 @@ __device__ __forceinline__ void fine_dma_run(const TileArgs &t, const NodeArgs &
         int boff;
         asm volatile("s_mov_b32 %0, %1" : "=s"(boff) : "s"(t.slot_off));
         sym_ke_blocks(c_symB + boff, u, f);
+        sym_ke_translation<KrylovEpi<EPI>::value>(c_symX + 4 * boff, u, f);
         const double Ee = elem_ok ? Eraw : 0.0;  // (k_fine_tile multiplies by 1.0 / 0.0: the same bits)
         double P[3][4];
 #pragma unroll

@@ -259,6 +259,7 @@ __device__ __forceinline__ void fine_tile_run(const TileArgs &t, const NodeArgs 
                 for (int m = 0; m < 8; m++) f[c][m] = u[c][m];
         } else {
             sym_ke_blocks(c_symB + boff, u, f);
+            sym_ke_translation<KrylovEpi<EPI>::value>(c_symX + 4 * boff, u, f);
         }
         const double Ee = Eraw * emul;
         double P[3][4];
@@ -354,8 +355,15 @@ __device__ __forceinline__ void fine_tile_run(const TileArgs &t, const NodeArgs 
     }
 }
 
+// The Krylov product carries 135 more scalar-loaded constants through its loop: at three workgroups per CU (168 VGPRs) the
+// compiler spills 52 vector and 165 scalar registers into it (79.9 us at 128^3), at two none (59.5 us; the packed form: 36.6).
+#ifdef SYMKE_X_OCC3
+#define FT_WAVES(EPI) 3
+#else
+#define FT_WAVES(EPI) (KrylovEpi<EPI>::value ? 2 : 3)
+#endif
 template <int EPI>
-__global__ __launch_bounds__(TILE * TILE, 3) void k_fine_tile(TileArgs t, NodeArgs a) {
+__global__ __launch_bounds__(TILE * TILE, FT_WAVES(EPI)) void k_fine_tile(TileArgs t, NodeArgs a) {
     __shared__ double s_u[RING][SLOT];           // node-plane ring
     __shared__ double s_y[2][TILE * TILE * 3];   // y-combination, double buffered -> one barrier per step
     __shared__ double s_e[2][TILE * TILE];       // modulus sums for the on-the-fly Jacobi diagonal (CHEB)

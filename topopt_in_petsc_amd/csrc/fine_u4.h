@@ -310,6 +310,7 @@ __device__ __forceinline__ void fine_u4_run(const TileArgs &t, const NodeArgs &a
                     if (CARRY) Ub[c][m] = Ut[c][m];
                 }
             sym_ke_blocks(c_symB + boff, u, f);
+            sym_ke_translation<KrylovEpi<EPI>::value>(c_symX + 4 * boff, u, f);
             const double Ee = elem_ok ? Eraw : 0.0;
             double P[3][4];
 #pragma unroll

@@ -1,6 +1,7 @@
 // grid.h -- z-slab partition, halo exchange through the host framework's
 // collectives, deterministic reductions with device-resident results.
 #pragma once
+#include <chrono>
 #include <vector>
 #include "common.h"
 
@@ -33,6 +34,39 @@ struct tp_grid {
     bool kt_on = false;
     double kt_bytes = 0.0;          // algorithmic bytes of the timed launches (per variant: with / without previous iterate)
     std::vector<hipEvent_t> kt_ev;  // pairs (start, stop)
+    // opt-in timer of the communication (tp_grid_comm_timer; N > 1): per kind -- 0 blocking halo exchange on `stream`, 1 halo
+    // exchange overlapped on `comm_stream`, 2 all-reduce, 3 all-gather of the replicated coarse levels -- the host wall time spent
+    // inside the hook and a HIP event pair around it on the stream it is issued on (device time: what a host-staged hook hides
+    // behind its own synchronisation shows in the first, what RCCL enqueues in the second)
+    bool ct_on = false;
+    std::vector<hipEvent_t> ct_ev[4];
+    double ct_host_s[4] = {0, 0, 0, 0};
+    long ct_calls[4] = {0, 0, 0, 0};
+};
+struct CommMark {
+    tp_grid *g;
+    int kind;
+    hipStream_t s;
+    std::chrono::steady_clock::time_point t0;
+    CommMark(tp_grid *g_, int kind_, hipStream_t s_) : g(g_), kind(kind_), s(s_) {
+        if (!g->ct_on) return;
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) == hipSuccess) {
+            (void)hipEventRecord(e, s);
+            g->ct_ev[kind].push_back(e);
+        }
+        t0 = std::chrono::steady_clock::now();
+    }
+    ~CommMark() {
+        if (!g->ct_on) return;
+        g->ct_host_s[kind] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        g->ct_calls[kind]++;
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) == hipSuccess) {
+            (void)hipEventRecord(e, s);
+            g->ct_ev[kind].push_back(e);
+        }
+    }
 };
 inline void kernel_timer_mark(tp_grid *g) {
     if (!g->kt_on) return;
@@ -71,6 +105,7 @@ inline void count_launch(tp_grid *g, double bytes = 0.0, double flops = 0.0) {
 template <int NV>
 inline int finish_reduction(tp_grid *g, int slot) {
     if (g->has_comm) {
+        CommMark cm(g, 2, g->stream);
         if (g->comm.allreduce_inplace) {  // the CG scalars are reduced where they live
             if (g->comm.allreduce_inplace(g->comm.user, g->scal + slot, NV)) return TP_ERR_COMM;
         } else {
@@ -163,7 +198,10 @@ inline int exchange_segments(tp_grid *g, const double *to_lo, double *from_lo, c
         if (to_hi && g->rank < g->nranks - 1)
             TP_HIP(hipMemcpy2DAsync(c.send_hi, seg * 8, to_hi + r0 * pitch, pitch * 8, seg * 8, nr,
                                     hipMemcpyDeviceToDevice, g->stream));
-        if (c.exchange(c.user, seg * nr)) return TP_ERR_COMM;
+        {
+            CommMark cm(g, 0, g->stream);
+            if (c.exchange(c.user, seg * nr)) return TP_ERR_COMM;
+        }
         if (from_lo && g->rank > 0)
             TP_HIP(hipMemcpy2DAsync(from_lo + r0 * pitch, pitch * 8, c.recv_lo, seg * 8, seg * 8, nr,
                                     hipMemcpyDeviceToDevice, g->stream));
@@ -187,8 +225,12 @@ inline int halo_nodes_begin(tp_grid *g, const Geom &q, double *v, int dof, hipEv
     TP_HIP(hipEventRecord(g->ev_ready, g->stream));
     TP_HIP(hipStreamWaitEvent(g->comm_stream, g->ev_ready, 0));
     g->comm.set_stream(g->comm.user, g->comm_stream);
-    const int rc = g->comm.exchange_direct(g->comm.user, lo ? v + pl * q.own_lo : nullptr, lo ? v : nullptr,
-                                           hi ? v + pl * q.own_hi : nullptr, hi ? v + pl * (q.nzl - 1) : nullptr, pl);
+    int rc;
+    {
+        CommMark cm(g, 1, g->comm_stream);
+        rc = g->comm.exchange_direct(g->comm.user, lo ? v + pl * q.own_lo : nullptr, lo ? v : nullptr,
+                                     hi ? v + pl * q.own_hi : nullptr, hi ? v + pl * (q.nzl - 1) : nullptr, pl);
+    }
     g->comm.set_stream(g->comm.user, nullptr);
     if (rc == 2) {
         g->overlap = false;
@@ -209,8 +251,12 @@ inline int halo_nodes(tp_grid *g, const Geom &q, double *v, int dof) {
     long pl = q.plane() * dof;
     if (g->comm.exchange_direct) {  // zero-copy: the framework sends/receives the planes in place
         const bool lo = g->rank > 0, hi = g->rank < g->nranks - 1;
-        const int rc = g->comm.exchange_direct(g->comm.user, lo ? v + pl * q.own_lo : nullptr, lo ? v : nullptr,
-                                               hi ? v + pl * q.own_hi : nullptr, hi ? v + pl * (q.nzl - 1) : nullptr, pl);
+        int rc;
+        {
+            CommMark cm(g, 0, g->stream);
+            rc = g->comm.exchange_direct(g->comm.user, lo ? v + pl * q.own_lo : nullptr, lo ? v : nullptr,
+                                         hi ? v + pl * q.own_hi : nullptr, hi ? v + pl * (q.nzl - 1) : nullptr, pl);
+        }
         if (rc == 0) return TP_OK;
         if (rc != 2) return TP_ERR_COMM;
         g->comm.exchange_direct = nullptr;  // 2: the host cannot address our memory in place -> staging from now on

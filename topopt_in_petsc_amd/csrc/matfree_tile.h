@@ -69,9 +69,29 @@ constexpr int SYMKE_N = SYMKE_TRANSL ? 36 : 33;
 static_assert(symke_idx(7, 2, 2) == SYMKE_N - 1, "packed size");
 
 constexpr int SYMKE_NTOT = SYMKE_N + 3;  // + 1 / KE[c][c]: the nodal diagonal is KE[c][c] * (sum of the 8 adjacent moduli)
+// Round 6, the KRYLOV operator's extra entries.  The operator of the Krylov method itself (EPI_APPLY_DOT: A p of CG, and the
+// initial residual A x0; tp_elasticity_apply_krylov) also applies what is left of T KE T / 64 in the translation mode's
+// COLUMN (how every mode of the element answers a rigid translation: D[(p,r),(0,s)], 69 entries beside the three of the packed
+// form) and ROW (how the translation mode answers every other mode: D[(0,r),(p,s)], p >= 1, 63 entries) -- one-sided, as KE has
+// them, not averaged: KE's asymmetry (1.4e-17) is 10 % of these residues.  Why: a late CG residual is ~1e-5 ||b|| while the
+// iterate's translation is ~1e5 x its strain, so KE's O(1e-16) answer to that translation is worth 1e-9 of ||r_k|| (C2, 35
+// iterations; 1.6e-10 at C3) -- and the 80-bit arbiter shows that ONLY the Krylov operator carries this: with the Krylov products
+// from KE and the whole preconditioner from the packed form, the reference's residual history is reproduced to 7e-15; with
+// these 132 entries to 8e-13 (tools/r06_arbiter_sets.py).  The smoother and the residual inside the V-cycle keep the 36-value form
+// (4 of the 5 fine-level operator applications of a Krylov iteration), and so does the plain product EPI_APPLY (MatMult, the
+// spectrum estimates): +132 fma on ~170 FP64 instructions cost the product 36.6 -> 59.5 us at 128^3 (measured; 12.21 -> 12.40 ms per
+// design iteration, 1.6 %).  -DSYMKE_NO_KRYLOV_RESIDUE: off.
+#ifdef SYMKE_NO_KRYLOV_RESIDUE
+constexpr bool SYMKE_KRYLOV = false;
+#else
+constexpr bool SYMKE_KRYLOV = SYMKE_TRANSL;
+#endif
+constexpr int SYMKE_XCOL = 72, SYMKE_XROW = 63, SYMKE_XN = SYMKE_XCOL + SYMKE_XROW;
 struct SymKE {
     double a[SYMKE_NTOT];
+    double x[SYMKE_XN];  // column [(p * 3 + r) * 3 + s] (0 where the packed form holds the entry), row [72 + (r * 7 + p - 1) * 3 + s]
 };
+__host__ __device__ constexpr bool symx_col(int p, int r, int s) { return !(p == 0 && r == s); }
 
 // natural index m = lx + 2 ly + 4 lz  ->  reference corner number
 static const int h_M2A[8] = {0, 1, 3, 2, 4, 5, 7, 6};
@@ -120,6 +140,24 @@ inline double make_sym_ke(const double *KE, SymKE *out) {
                 for (int m2 = 0; m2 < 8; m2++) acc += (long double)KE[(3 * h_M2A[m] + r) * 24 + 3 * h_M2A[m2] + r];
             out->a[symke_idx(1 << r, r, r)] = (double)(acc / 64.0L);
         }
+    {   // the translation column and row, each entry the exact (80-bit) sum of its 64 terms rounded once
+        auto Dx = [&](int p, int r, int p2, int s2) -> double {
+            long double acc = 0.0L;
+            for (int m = 0; m < 8; m++)
+                for (int m2 = 0; m2 < 8; m2++) {
+                    const int sg = (__builtin_popcount(p & m) + __builtin_popcount(p2 & m2)) & 1;
+                    const long double v = (long double)KE[(3 * h_M2A[m] + r) * 24 + 3 * h_M2A[m2] + s2];
+                    acc += sg ? -v : v;
+                }
+            return (double)(acc / 64.0L);
+        };
+        for (int p = 0; p < 8; p++)
+            for (int r = 0; r < 3; r++)
+                for (int s2 = 0; s2 < 3; s2++) out->x[(p * 3 + r) * 3 + s2] = symx_col(p, r, s2) ? Dx(p, r, 0, s2) : 0.0;
+        for (int r = 0; r < 3; r++)
+            for (int p = 1; p < 8; p++)
+                for (int s2 = 0; s2 < 3; s2++) out->x[SYMKE_XCOL + (r * 7 + p - 1) * 3 + s2] = Dx(0, r, p, s2);
+    }
     for (int c = 0; c < 3; c++) {
         out->a[SYMKE_N + c] = 1.0 / KE[c * 24 + c];
         for (int m = 1; m < 8; m++)  // equal at all 8 corners for a box element
@@ -150,6 +188,9 @@ __device__ inline void wht4(double v[4]) {
 constexpr int SYMKE_SLOTS = 16, SYMKE_STRIDE = 40;
 static_assert(SYMKE_N + 3 <= SYMKE_STRIDE, "stride");
 __constant__ double c_symB[SYMKE_SLOTS * SYMKE_STRIDE];
+constexpr int SYMKE_XSTRIDE = 4 * SYMKE_STRIDE;  // the Krylov operator's extra entries of slot i start at 4 * (offset of slot i in c_symB)
+static_assert(SYMKE_XN <= SYMKE_XSTRIDE, "stride");
+__constant__ double c_symX[SYMKE_SLOTS * SYMKE_XSTRIDE];
 
 // level-1 operator constants (MACG_N packed values of G_sigma, macro_pattern.h), same slot numbering
 constexpr int MACG_STRIDE = 80;
@@ -204,7 +245,7 @@ inline int macro_slot_upload(int slot, const double *vals) {
 }
 
 struct SymSlots {
-    double key[SYMKE_SLOTS][SYMKE_NTOT];
+    SymKE key[SYMKE_SLOTS];
     int refs[SYMKE_SLOTS];
 };
 inline SymSlots &sym_slots() {
@@ -215,7 +256,7 @@ inline SymSlots &sym_slots() {
 inline int sym_slot_acquire(const SymKE &sk) {
     SymSlots &S = sym_slots();
     for (int i = 0; i < SYMKE_SLOTS; i++)
-        if (S.refs[i] > 0 && std::memcmp(S.key[i], sk.a, sizeof(sk.a)) == 0) {
+        if (S.refs[i] > 0 && std::memcmp(&S.key[i], &sk, sizeof(SymKE)) == 0) {
             S.refs[i]++;
             return i;
         }
@@ -223,7 +264,9 @@ inline int sym_slot_acquire(const SymKE &sk) {
         if (S.refs[i] == 0) {
             if (hipMemcpyToSymbol(HIP_SYMBOL(c_symB), sk.a, sizeof(sk.a), sizeof(double) * i * SYMKE_STRIDE) != hipSuccess)
                 return -1;
-            std::memcpy(S.key[i], sk.a, sizeof(sk.a));
+            if (hipMemcpyToSymbol(HIP_SYMBOL(c_symX), sk.x, sizeof(sk.x), sizeof(double) * i * SYMKE_XSTRIDE) != hipSuccess)
+                return -1;
+            std::memcpy(&S.key[i], &sk, sizeof(SymKE));
             S.refs[i] = 1;
             return i;
         }
@@ -255,6 +298,51 @@ __device__ inline void sym_ke_blocks(const double *B, const double u[3][8], doub
         }
     }
 }
+
+// The Krylov operator's share (see SYMKE_KRYLOV): fhat += column . (translation part of uhat) and row . (the other modes).
+// X: the slot's entries in c_symX (scalar loads).  The three row sums are chains of 21 fma each, split in two.
+template <bool ON>
+__device__ inline void sym_ke_translation(const double *X, const double u[3][8], double f[3][8]) {
+#pragma clang fp contract(off)
+    if (!ON) return;
+#ifdef SYMKE_X_GROUPS
+    // experiment: the scalar loads of the 135 constants in groups of 9 behind scheduling barriers (the compiler otherwise
+    // hoists them all and spills SGPRs into vector lanes)
+#define SYMX_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SYMX_FENCE() ((void)0)
+#endif
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+        SYMX_FENCE();
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int s = 0; s < 3; s++)
+                if (symx_col(p, r, s)) f[r][p] = fma(X[(p * 3 + r) * 3 + s], u[s][0], f[r][p]);
+    }
+    double a0[3] = {0.0, 0.0, 0.0}, a1[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int p = 1; p < 8; p++) {
+        SYMX_FENCE();
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int s = 0; s < 3; s++) {
+                const double c = X[SYMKE_XCOL + (r * 7 + p - 1) * 3 + s];
+                if (p & 1) a0[r] = fma(c, u[s][p], a0[r]);
+                else a1[r] = fma(c, u[s][p], a1[r]);
+            }
+    }
+    SYMX_FENCE();
+#pragma unroll
+    for (int r = 0; r < 3; r++) f[r][0] = f[r][0] + (a0[r] + a1[r]);
+#undef SYMX_FENCE
+}
+template <int EPI>
+struct KrylovEpi {   // the product of the Krylov method (A p with its p . A p; the initial residual goes through it too)
+    static constexpr bool value = SYMKE_KRYLOV && EPI == EPI_APPLY_DOT;
+};
 
 constexpr int TILE = 16;             // threads per tile edge
 constexpr int TOUT = TILE - 1;       // node columns produced per tile edge
@@ -504,6 +592,7 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
         double Ee = 0.0;
         if (!MACRO) {
             sym_ke_blocks(c_symB + boff, u, f);
+            sym_ke_translation<KrylovEpi<EPI>::value>(c_symX + 4 * boff, u, f);
             Ee = Eraw * emul;
         } else {
             const bool eok = elem_ok && el >= 0 && el < t.ezl;

@@ -924,6 +924,18 @@ struct MGSolver {
         a.out = y;
         return op<EPI_APPLY>(l, a);
     }
+    // y = A_0 u with the operator of the Krylov method (the kernel of CG's A p; its dot product u . A u is discarded)
+    int apply_krylov(double *u, double *y) {
+        TP_TRY(halo(0, u));
+        NodeArgs a{};
+        a.x = u;
+        a.out = y;
+        a.partials = grid->partials;
+        a.ticket = tail_ticket(grid);
+        a.red_out = grid->scal + S_PW;
+        TP_TRY(op<EPI_APPLY_DOT>(0, a));
+        return finish_tail<1>(grid, last_nblocks, S_PW);
+    }
 
     // ---- the long smoothing run of the coarsest level (30 steps of 4-5 us kernels) as a hipGraph: captured when its
     // arguments change -- the Chebyshev window once per design iteration, the x/x2 roles alternate between consecutive
@@ -1415,7 +1427,10 @@ struct MGSolver {
             for (int q = 0; q < ns; q++)
                 TP_HIP(hipMemcpyAsync(c.send_lo + (long)q * pad, src + (long)(s0 + q) * src_stride + L.own_off(),
                                       sizeof(double) * (size_t)L.own_n(), hipMemcpyDeviceToDevice, s));
-            if (c.allgather(c.user, (long)ns * pad)) return TP_ERR_COMM;
+            {
+                CommMark cm(grid, 3, s);
+                if (c.allgather(c.user, (long)ns * pad)) return TP_ERR_COMM;
+            }
             for (int rk = 0; rk < grid->nranks; rk++) {
                 const long p0 = (long)rk * L.g.ez_own + (rk > 0 ? 1 : 0), np = L.g.ez_own + (rk == 0 ? 1 : 0);
                 for (int q = 0; q < ns; q++)
@@ -1543,7 +1558,10 @@ struct MGSolver {
         for (int o = 0; o < n; o += 16) {
             const int c = n - o < 16 ? n - o : 16;
             TP_HIP(hipMemcpyAsync(grid->comm.red, p + o, sizeof(double) * c, hipMemcpyDeviceToDevice, grid->stream));
-            if (grid->comm.allreduce_sum(grid->comm.user, c)) return TP_ERR_COMM;
+            {
+                CommMark cm(grid, 2, grid->stream);
+                if (grid->comm.allreduce_sum(grid->comm.user, c)) return TP_ERR_COMM;
+            }
             TP_HIP(hipMemcpyAsync(p + o, grid->comm.red, sizeof(double) * c, hipMemcpyDeviceToDevice, grid->stream));
         }
         return TP_OK;
@@ -1757,7 +1775,20 @@ struct MGSolver {
             a.out = r;
             a.b = b;
             TP_TRY(halo(0, x));
-            TP_TRY(op<EPI_RESID>(0, a));
+            if (SYMKE_KRYLOV && DOF == 3 && L.use_tile) {
+                // the initial residual belongs to the Krylov method: its operator is the Krylov product (matfree_tile.h:
+                // SYMKE_KRYLOV -- KE's action on the iterate's translation part included), not the V-cycle's residual kernel
+                a.b = nullptr;
+                a.partials = grid->partials;
+                a.ticket = tail_ticket(grid);
+                a.red_out = grid->scal + S_PW;   // (x0 . A x0: not used)
+                TP_TRY(op<EPI_APPLY_DOT>(0, a));
+                TP_TRY(finish_tail<1>(grid, last_nblocks, S_PW));
+                TP_LAUNCH(k_axpby, dim3(grid_for(n)), dim3(BLK), 0, s, r + off, 1.0, b + off, -1.0, n);   // r = b - A x
+                count_launch(grid, 24.0 * n, 1.0 * n);
+            } else {
+                TP_TRY(op<EPI_RESID>(0, a));
+            }
         }
         TP_LAUNCH(k_dot2, dim3(nb), dim3(BLK), 0, s, b, b, r, r, off, n, grid->partials);
         count_launch(grid, 16.0 * n, 4.0 * n);

@@ -234,6 +234,34 @@ extern "C" int tp_grid_kernel_timer_read(tp_grid *g, double *total_ms, long *lau
     *launches = n;
     return TP_OK;
 }
+// Timing of the communication where it runs (N > 1; grid.h: CommMark).  on = 1 starts collecting; the read synchronises both
+// streams and returns, per kind (0 blocking halo, 1 overlapped halo, 2 all-reduce, 3 all-gather), the number of hook calls, the
+// host wall time spent inside them and the device time between the event pairs around them, then clears the collection.
+extern "C" int tp_grid_comm_timer(tp_grid *g, int on) {
+    if (!g) return TP_ERR_ARG;
+    g->ct_on = on != 0;
+    return TP_OK;
+}
+extern "C" int tp_grid_comm_timer_read(tp_grid *g, long calls[4], double host_ms[4], double device_ms[4]) {
+    if (!g || !calls || !host_ms || !device_ms) return TP_ERR_ARG;
+    TP_HIP(hipStreamSynchronize(g->stream));
+    if (g->comm_stream) TP_HIP(hipStreamSynchronize(g->comm_stream));
+    for (int k = 0; k < 4; k++) {
+        double t = 0.0;
+        for (size_t i = 0; i + 1 < g->ct_ev[k].size(); i += 2) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, g->ct_ev[k][i], g->ct_ev[k][i + 1]) == hipSuccess) t += ms;
+        }
+        for (hipEvent_t e : g->ct_ev[k]) (void)hipEventDestroy(e);
+        g->ct_ev[k].clear();
+        calls[k] = g->ct_calls[k];
+        host_ms[k] = 1e3 * g->ct_host_s[k];
+        device_ms[k] = t;
+        g->ct_calls[k] = 0;
+        g->ct_host_s[k] = 0.0;
+    }
+    return TP_OK;
+}
 extern "C" int tp_grid_comm_stats(const tp_grid *g, long *ex, long *red) {
     if (!g) return TP_ERR_ARG;
     if (ex) *ex = g->rccl ? g->rccl->n_exchanges : 0;
@@ -680,7 +708,7 @@ extern "C" int tp_elasticity_get_ke(const tp_elasticity *e, double *ke) {
 // largest entry.  Returned as a double-double pair (hi + lo, summed in long double on the host): the parity checks feed it to
 // the 80-bit arbiter, which must see the operator the kernels see, not its rounding to double.  Without the tile kernels
 // (TP_NO_TILE, a KE that is not box symmetric) the kernels apply KE itself: hi = KE, lo = 0.
-extern "C" int tp_elasticity_get_ke_effective(const tp_elasticity *e, double *hi, double *lo) {
+static int ke_applied(const tp_elasticity *e, bool krylov, double *hi, double *lo) {
     if (!e || !hi || !lo) return TP_ERR_ARG;
     if (!e->mg.lv[0].use_tile) {
         for (int i = 0; i < 576; i++) hi[i] = e->KE[i], lo[i] = 0.0;
@@ -699,6 +727,15 @@ extern "C" int tp_elasticity_get_ke_effective(const tp_elasticity *e, double *hi
                 const int i = (q ^ (1 << r)) * 3 + r, j = (q ^ (1 << s2)) * 3 + s2;
                 D[i][j] = D[j][i] = (long double)sk.a[id];
             }
+    if (krylov && SYMKE_KRYLOV) {   // the plain products also apply the translation mode's column and row (one-sided)
+        for (int p2 = 0; p2 < 8; p2++)
+            for (int r = 0; r < 3; r++)
+                for (int s2 = 0; s2 < 3; s2++)
+                    if (symx_col(p2, r, s2)) D[p2 * 3 + r][s2] = (long double)sk.x[(p2 * 3 + r) * 3 + s2];
+        for (int r = 0; r < 3; r++)
+            for (int p2 = 1; p2 < 8; p2++)
+                for (int s2 = 0; s2 < 3; s2++) D[r][p2 * 3 + s2] = (long double)sk.x[SYMKE_XCOL + (r * 7 + p2 - 1) * 3 + s2];
+    }
     for (int m = 0; m < 8; m++)
         for (int r = 0; r < 3; r++)
             for (int m2 = 0; m2 < 8; m2++)
@@ -715,6 +752,10 @@ extern "C" int tp_elasticity_get_ke_effective(const tp_elasticity *e, double *hi
                 }
     return TP_OK;
 }
+extern "C" int tp_elasticity_get_ke_effective(const tp_elasticity *e, double *hi, double *lo) { return ke_applied(e, false, hi, lo); }
+// The element matrix of the KRYLOV operator (the plain products A p, A x0, MatMult): KE_eff plus the translation mode's column
+// and row of T KE T / 64 as KE has them (matfree_tile.h: SYMKE_KRYLOV).  Same double-double convention.
+extern "C" int tp_elasticity_get_ke_krylov(const tp_elasticity *e, double *hi, double *lo) { return ke_applied(e, true, hi, lo); }
 extern "C" int tp_elasticity_set_bc(tp_elasticity *e, const double *N) {
     if (e) e->mg.topology_epoch++;  // captured launch chains reference the lists rebuilt below
     tp_grid *g = e->grid;
@@ -1129,6 +1170,11 @@ extern "C" int tp_elasticity_apply(tp_elasticity *e, const double *u, double *y)
     if (!e->assembled) return TP_ERR_STATE;
     return e->mg.apply(0, const_cast<double *>(u), y);
 }
+// the same product with the operator of the Krylov method (tp_elasticity_get_ke_krylov): what KSPSolve's CG multiplies with
+extern "C" int tp_elasticity_apply_krylov(tp_elasticity *e, const double *u, double *y) {
+    if (!e || !e->assembled) return TP_ERR_STATE;
+    return e->mg.apply_krylov(const_cast<double *>(u), y);
+}
 
 __global__ __launch_bounds__(BLK) void k_mul(double *__restrict__ y, const double *__restrict__ a,
                                              const double *__restrict__ b, long n) {
@@ -1173,6 +1219,8 @@ extern "C" int tp_elasticity_solve(tp_elasticity *e, const double *RHS, double *
 
 // fx = sum_e E_e u_e^T KE u_e, dfdx_e = -p x^(p-1) (Emax-Emin) u_e^T KE u_e, partial sum x
 // (LinearElasticity.cc:405-437); one thread per own element, KE rows wave-uniform.
+// REDUCE = false: the sensitivities alone (LinearElasticity.cc:299-361) -- no sums, nothing for the host to wait for.
+template <bool REDUCE>
 __global__ __launch_bounds__(BLK) void k_objective(Geom g, const double *__restrict__ KE, const double *__restrict__ U,
                                                    const double *__restrict__ x, double Emin, double Emax, double penal,
                                                    double *__restrict__ dfdx, double *__restrict__ partials) {
@@ -1201,6 +1249,7 @@ __global__ __launch_bounds__(BLK) void k_objective(Geom g, const double *__restr
         vol = xe;
         if (dfdx) dfdx[t] = -1.0 * penal * pow(xe, penal - 1) * (Emax - Emin) * uKu;
     }
+    if (!REDUCE) return;
     f = block_sum(f);
     vol = block_sum(vol);
     if (threadIdx.x == 0) {
@@ -1218,16 +1267,35 @@ extern "C" int tp_elasticity_objective(tp_elasticity *e, const double *U, const 
     const long nel_glob = (long)g->ex * g->ey * g->ez_glob;
     TP_TRY(halo_nodes(g, q, const_cast<double *>(U), 3));  // DMGlobalToLocal, :388-390
     const int nb = (int)((nel + BLK - 1) / BLK);
-    TP_LAUNCH(k_objective, dim3(nb), dim3(BLK), 0, g->stream, q, e->d_KE, U, xPhys, Emin, Emax, penal, dfdx,
-                       g->partials);
-    count_launch(g, 24.0 * q.owned_nodes() + 16.0 * nel, 2.0 * 600 * nel);
-    TP_TRY(reduce_partials<2>(g, nb, S_TMP));
-    double v[2];
-    TP_TRY(read_scal(g, S_TMP, 2, v));
-    if (fx) *fx = v[0];
-    if (gx) *gx = v[1] / (double)nel_glob - volfrac;
+    if (!fx && !gx) {  // sensitivities only: no reduction, no host synchronisation
+        if (dfdx) {
+            TP_LAUNCH(k_objective<false>, dim3(nb), dim3(BLK), 0, g->stream, q, e->d_KE, U, xPhys, Emin, Emax, penal, dfdx, g->partials);
+            count_launch(g, 24.0 * q.owned_nodes() + 16.0 * nel, 2.0 * 600 * nel);
+        }
+    } else {
+        TP_LAUNCH(k_objective<true>, dim3(nb), dim3(BLK), 0, g->stream, q, e->d_KE, U, xPhys, Emin, Emax, penal, dfdx, g->partials);
+        count_launch(g, 24.0 * q.owned_nodes() + 16.0 * nel, 2.0 * 600 * nel);
+        TP_TRY(reduce_partials<2>(g, nb, S_TMP));
+        double v[2];
+        TP_TRY(read_scal(g, S_TMP, 2, v));
+        if (fx) *fx = v[0];
+        if (gx) *gx = v[1] / (double)nel_glob - volfrac;
+    }
     if (dgdx) TP_TRY(tp_vec_set(g, dgdx, 1.0 / (double)nel_glob, nel));
     return TP_OK;
+}
+// The reference's split forms (main.cc can call either pair instead of the fused method):
+// ComputeObjectiveConstraints minus the solve (LinearElasticity.cc:237-294): fx and gx of the state U, no sensitivities
+extern "C" int tp_elasticity_objective_only(tp_elasticity *e, const double *U, const double *xPhys, double Emin, double Emax,
+                                            double penal, double volfrac, double *fx, double *gx) {
+    if (!e || !U || !xPhys || !fx || !gx) return TP_ERR_ARG;
+    return tp_elasticity_objective(e, U, xPhys, Emin, Emax, penal, volfrac, fx, gx, nullptr, nullptr);
+}
+// ComputeSensitivities (LinearElasticity.cc:299-361): dfdx, dgdx of the state U as it is -- no solve, no sums
+extern "C" int tp_elasticity_sensitivities(tp_elasticity *e, const double *U, const double *xPhys, double Emin, double Emax,
+                                           double penal, double *dfdx, double *dgdx) {
+    if (!e || !U || !xPhys || !dfdx) return TP_ERR_ARG;
+    return tp_elasticity_objective(e, U, xPhys, Emin, Emax, penal, 0.0, nullptr, nullptr, dfdx, dgdx);
 }
 
 extern "C" int tp_elasticity_set_tolerances(tp_elasticity *e, double rtol, double atol, double dtol, int max_it) {

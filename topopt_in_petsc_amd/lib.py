@@ -62,6 +62,8 @@ SYMBOLS = {
     "tp_grid_use_rccl2": (_i, [_vp, _vp, _vp]),
     "tp_grid_comm_stats": (_i, [_vp, C.POINTER(_l), C.POINTER(_l)]),
     "tp_grid_comm_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "tp_grid_comm_timer": (_i, [_vp, _i]),
+    "tp_grid_comm_timer_read": (_i, [_vp, C.POINTER(_l), C.POINTER(_d), C.POINTER(_d)]),
     "tp_grid_kernel_timer": (_i, [_vp, _i]),
     "tp_grid_kernel_timer_read": (_i, [_vp, C.POINTER(_d), C.POINTER(_l)]),
     "tp_grid_kernel_timer_read2": (_i, [_vp, C.POINTER(_d), C.POINTER(_l), C.POINTER(_d)]),
@@ -91,12 +93,16 @@ SYMBOLS = {
     "tp_elasticity_destroy": (_i, [_vp]),
     "tp_elasticity_get_ke": (_i, [_vp, _vp]),
     "tp_elasticity_get_ke_effective": (_i, [_vp, _vp, _vp]),
+    "tp_elasticity_get_ke_krylov": (_i, [_vp, _vp, _vp]),
     "tp_elasticity_cantilever": (_i, [_vp, _vp, _vp]),
     "tp_elasticity_set_bc": (_i, [_vp, _vp]),
     "tp_elasticity_assemble": (_i, [_vp, _vp, _d, _d, _d]),
     "tp_elasticity_apply": (_i, [_vp, _vp, _vp]),
+    "tp_elasticity_apply_krylov": (_i, [_vp, _vp, _vp]),
     "tp_elasticity_solve": (_i, [_vp, _vp, _vp, C.POINTER(_i), C.POINTER(_d), C.POINTER(_d), _vp, _i]),
     "tp_elasticity_objective": (_i, [_vp, _vp, _vp, _d, _d, _d, _d, C.POINTER(_d), C.POINTER(_d), _vp, _vp]),
+    "tp_elasticity_objective_only": (_i, [_vp, _vp, _vp, _d, _d, _d, _d, C.POINTER(_d), C.POINTER(_d)]),
+    "tp_elasticity_sensitivities": (_i, [_vp, _vp, _vp, _d, _d, _d, _vp, _vp]),
     "tp_elasticity_petsc_options": (_i, [_vp, C.c_char_p, C.c_size_t]),
     "tp_elasticity_level_count": (_i, [_vp]),
     "tp_elasticity_level_nodes": (_l, [_vp, _i]),
