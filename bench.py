@@ -809,9 +809,15 @@ def main():
         breaches = []
         B = PARITY_BOUNDS
         pde = ftype == 2 and not (a.pde_rtol and a.pde_rtol <= 1e-12)   # (filter solved to rounding on both sides: the cone-filter bounds apply)
+        hist_all_bound = B["vs_oracle"]
         if ftype == 2 and not pde:
-            parity["note_pde"] = ("Helmholtz filter solved to rtol %g on both sides (--pde-rtol): the filtered densities agree to rounding, fx and "
-                                  "||r_k|| are held to 'vs_oracle'" % a.pde_rtol)
+            # a relative difference d of the two filtered densities is a relative difference d of the operator: it moves a residual of
+            # size rtol ||b|| by ~d / rtol (C4, filter at 1e-13: 4.9e-9 in the last ||r_k||, 2.7e-11 over the first ten, fx 7e-13)
+            hist_all_bound = max(B["vs_oracle"], a.pde_rtol / a.rtol)
+            parity["note_pde"] = ("Helmholtz filter solved to rtol %g on both sides (--pde-rtol): fx, the first ten ||r_k|| and the converged quantities are "
+                                  "held to 'vs_oracle'; the late ||r_k|| to pde_rtol / rtol = %g (the two filtered densities differ by ~pde_rtol, and a "
+                                  "residual of size rtol ||b|| answers an operator difference d with d / rtol)" % (a.pde_rtol, hist_all_bound))
+            parity["bounds"]["hist_all_behind_tight_pde_filter"] = hist_all_bound
         if pde:
             # behind a Helmholtz filter the solver's input is itself the result of a solve to rtol 1e-8 (PDEFilter.cc:280): the
             # two filtered densities agree to ~1e-9, and everything after them to what that leaves (tests/test_gpu_configs.py)
@@ -825,8 +831,10 @@ def main():
             breaches.append("fx_rel_err")
         if pde and (parity["hist_max_rel_err_first10"] or 0.0) > B["behind_pde_filter"]:
             breaches.append("hist_max_rel_err_first10")
-        if not pde and (parity["hist_max_rel_err_all"] or 0.0) > B["vs_oracle"]:
+        if not pde and (parity["hist_max_rel_err_all"] or 0.0) > hist_all_bound:
             breaches.append("hist_max_rel_err_all")
+        if ftype == 2 and not pde and (parity["hist_max_rel_err_first10"] or 0.0) > B["vs_oracle"]:
+            breaches.append("hist_max_rel_err_first10")
         ext = cpu_res.get("extras")
         if ext:
             z = np.load(ext["npz"])

@@ -4,7 +4,7 @@ kernels that precede the idle gaps."""
 import sqlite3, sys, collections
 con = sqlite3.connect(sys.argv[1])
 rows = con.execute("select name, start, end from kernels order by start").fetchall()
-obj = [i for i, r in enumerate(rows) if r[0].startswith("k_objective")]
+obj = [i for i, r in enumerate(rows) if ("k_objective" in r[0][:24])]
 rows = rows[obj[-2]:obj[-1]]
 t0, t1 = rows[0][1], rows[-1][2]
 busy = 0; cur_e = rows[0][1]; prev = ""; gaps = collections.defaultdict(lambda: [0, 0]); hist = collections.Counter()

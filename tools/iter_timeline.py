@@ -3,7 +3,7 @@ kernel: start offset, duration, idle gap before, grid.   usage: iter_timeline.py
 import sqlite3, sys
 con = sqlite3.connect(sys.argv[1])
 rows = con.execute("select name, start, end, grid_x, workgroup_x from kernels order by start").fetchall()
-obj = [i for i, r in enumerate(rows) if r[0].startswith("k_objective")]
+obj = [i for i, r in enumerate(rows) if ("k_objective" in r[0][:24])]
 if len(obj) >= 2:
     rows = rows[obj[-2]:obj[-1]]
 xr = [i for i, r in enumerate(rows) if "k_cg_update_xr" in r[0][:40]]
