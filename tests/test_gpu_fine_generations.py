@@ -85,3 +85,58 @@ def test_generations_bitwise(tmp_path, mesh, scattered):
             # summation order that follows the tile shape and the z-chunks -> last-bit differences in alpha, beta
             for k in ("U", "hist"):
                 assert np.abs(got[k] - ref[k]).max() <= 1e-9 * np.abs(ref[k]).max(), (tag, k)
+
+
+STENCIL_WORKER = r"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, %(root)r)
+import topopt_in_petsc_amd as tp
+tp.load_library()
+ex, ey, ez, nlv, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+grid = tp.Grid(ex + 1, ey + 1, ez + 1, 1.0 / ey)
+le = tp.LinearElasticity(grid, tp.SolverOptions(nlvls=nlv, nsmooth=2, ncoarse=20, rtol=1e-8, coarse_direct=1))
+le.set_cycles([1, 3, 1, 1][: nlv - 1])
+le.SetUpLoadAndBC()
+le.AssembleStiffnessMatrix(grid.synth_density(12345), 1e-9, 1.0, 3.0)
+rng = np.random.default_rng(11)
+res = {}
+for l in range(2, nlv):
+    n = 3 * le.level_nodes(l)
+    u, b = torch.from_numpy(rng.standard_normal(n)).cuda(), torch.from_numpy(rng.standard_normal(n)).cuda()
+    res["apply%%d" %% l] = le.level_apply(l, u).cpu().numpy()
+    x = torch.zeros_like(u)
+    le.smooth(l, b, x, 3, True)
+    res["cheb0_%%d" %% l] = x.cpu().numpy()
+    x = u.clone()
+    le.smooth(l, b, x, 4, False)
+    res["cheb1_%%d" %% l] = x.cpu().numpy()
+    res["lam%%d" %% l] = np.asarray([le.level_lambda(l)])
+r = torch.from_numpy(rng.standard_normal(3 * (ex + 1) * (ey + 1) * (ez + 1))).cuda()
+res["pc"] = le.precond(r).cpu().numpy()
+its = le.KSPSolve(hist_cap=300)
+res["U"], res["hist"], res["its"] = le.U.cpu().numpy(), np.asarray(le.last_hist), np.asarray([its])
+np.savez(out, **res)
+"""
+
+
+@pytest.mark.parametrize("mesh,nlv", [((128, 128, 64), 4), ((96, 96, 96), 5), ((128, 96, 64), 4)])   # level 2: 18 513 / 15 625 / 14 025 nodes -- the three-way split
+def test_stencil_kernel_per_node_equals_per_row_bitwise(tmp_path, mesh, nlv):
+    """Round 6: on the stored-stencil levels whose rows are split three ways, a thread per NODE and z-offset (k_dia_node3: a third
+    of the waves, the index arithmetic of a node shared by its three rows) against a thread per ROW and z-offset
+    (k_dia_row_split<3, EPI, 3>; TP_DIA_NODE=0): operator, Chebyshev steps from a zero and a non-zero guess, the eigenvalue
+    estimates, one V-cycle and a whole solve -- the same bits (every row is summed in the same order)."""
+    res = {}
+    for tag, env in (("node", {}), ("row", {"TP_DIA_NODE": "0"})):
+        out = str(tmp_path / (tag + ".npz"))
+        e = dict(os.environ)
+        e.pop("TP_DIA_NODE", None)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", STENCIL_WORKER % {"root": ROOT}] + [str(v) for v in mesh] + [str(nlv), out],
+                           env=e, capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = np.load(out)
+    a, b = res["node"], res["row"]
+    assert sorted(a.files) == sorted(b.files) and any(k.startswith("apply") for k in a.files)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k

@@ -811,16 +811,31 @@ struct MGSolver {
             auto launch_rows = [&](long t0, long tn, long t1, long tn1) -> int {
                 o.t0 = t0, o.tn = tn, o.t1 = t1, o.tn1 = tn1;
                 const long rows = tn < 0 ? rows_all : tn + tn1;
-                int nbr;
+                int nbr = 0;
                 if (rsplit == 9) {
                     nbr = (int)((rows + BLK / 9 - 1) / (BLK / 9));
                     TP_LAUNCH((k_dia_row_split<DOF, EPI, 9>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
                 } else if (rsplit == 3) {
-                    nbr = (int)((rows + BLK / 3 - 1) / (BLK / 3));
-                    if (sym)
-                        TP_LAUNCH((k_dia_row_split<DOF, EPI, 3, true>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
-                    else
-                        TP_LAUNCH((k_dia_row_split<DOF, EPI, 3>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
+                    // round 6: a thread per node and z-offset (k_dia_node3: the same bits, a third of the waves); TP_DIA_NODE=0: per row
+                    static const bool by_node = !(getenv("TP_DIA_NODE") && atoi(getenv("TP_DIA_NODE")) == 0);
+                    bool done = false;
+                    if constexpr (DOF == 3) {
+                        if (by_node && EPI != EPI_APPLY_DOT) {
+                            nbr = (int)((rows / 3 + 63) / 64);
+                            if (sym)
+                                TP_LAUNCH((k_dia_node3<EPI, true>), dim3(nbr), dim3(192), 0, grid->stream, o, a);
+                            else
+                                TP_LAUNCH((k_dia_node3<EPI, false>), dim3(nbr), dim3(192), 0, grid->stream, o, a);
+                            done = true;
+                        }
+                    }
+                    if (!done) {
+                        nbr = (int)((rows + BLK / 3 - 1) / (BLK / 3));
+                        if (sym)
+                            TP_LAUNCH((k_dia_row_split<DOF, EPI, 3, true>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
+                        else
+                            TP_LAUNCH((k_dia_row_split<DOF, EPI, 3>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
+                    }
                 } else {
                     nbr = (int)((rows + BLK - 1) / BLK);
                     TP_LAUNCH((k_dia_row<DOF, EPI>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);

@@ -295,6 +295,11 @@ __global__ __launch_bounds__(BLK) void k_matfree_diag(MatfreeOp<DOF> op, double 
 // coarse b_c[I] = sum over the 27 fine neighbours of 2I of w * r_f ; owned coarse nodes
 // first != NULL: also the first Chebyshev step of the coarse level from a zero guess (k_cheb_first fused in):
 // x_c = dinv_c * b_c * inv_theta (and d_c = x_c where the level keeps a direction vector)
+#ifdef TP_RESTRICT_NARROW
+constexpr bool RESTRICT_NARROW = true;   // A/B: round 1-5's nine 8-byte loads per row
+#else
+constexpr bool RESTRICT_NARROW = false;
+#endif
 template <int DOF>
 __global__ __launch_bounds__(BLK) void k_restrict(Geom gc, Geom gf, const double *__restrict__ rf,
                                                   double *__restrict__ bc, const double *__restrict__ dinv_c = nullptr,
@@ -315,8 +320,44 @@ __global__ __launch_bounds__(BLK) void k_restrict(Geom gc, Geom gf, const double
     double s[DOF];
 #pragma unroll
     for (int r = 0; r < DOF; r++) s[r] = 0.0;
-    // branch-free: a neighbour outside the array is read at the centre node with weight 0 (fma(0, v, s) = s: the same
-    // bits as skipping it), so that all 27 x DOF loads are in flight at once instead of one round trip per branch
+    if (DOF == 3 && !RESTRICT_NARROW) {
+        // Round 6: the three x-neighbours of a row are 9 CONTIGUOUS doubles per thread: four 16-byte loads and one 8-byte load
+        // (8-byte aligned: legal on this target) instead of nine 8-byte loads at a lane stride of 48 bytes -- the kernel was
+        // bound by vector-memory issue (63 % of the wave time issue-stalled, every load instruction touching 24-48 lines:
+        // profiles/r06_pmc_counters_other_kernels.json).  Branch-free at the x-boundaries too: the window starts at
+        // clamp(2I - 1, 0, nx - 3) and each of its three nodes takes the weight of its distance from 2I (0 beyond the stencil),
+        // so the non-zero terms enter the sums in the order of the narrow form: the same bits.
+        typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+        const int s0 = min(max(2 * I - 1, 0), gf.nx - 3);
+        double wx[3];
+#pragma unroll
+        for (int t3 = 0; t3 < 3; t3++) {
+            const int di = s0 + t3 - 2 * I;
+            wx[t3] = di == 0 ? 1.0 : ((di == 1 || di == -1) ? 0.5 : 0.0);
+        }
+#pragma unroll
+        for (int dk = -1; dk <= 1; dk++) {
+            const int k = 2 * K + dk;
+            const bool okk = k >= 0 && k < gf.nzl;
+#pragma unroll
+            for (int dj = -1; dj <= 1; dj++) {
+                const int j = 2 * J + dj;
+                const bool ok = okk && j >= 0 && j < gf.ny;
+                const double wyz = ok ? (dj ? 0.5 : 1.0) * (dk ? 0.5 : 1.0) : 0.0;
+                const long row = ok ? (long)gf.nx * (j + (long)gf.ny * k) : (long)gf.nx * (2 * J + (long)gf.ny * (2 * K));
+                const double *__restrict__ q = rf + (row + s0) * 3;
+                const d2u a = *(const d2u *)(q), b2 = *(const d2u *)(q + 2), c2 = *(const d2u *)(q + 4), d2 = *(const d2u *)(q + 6);
+                const double v[9] = {a.x, a.y, b2.x, b2.y, c2.x, c2.y, d2.x, d2.y, q[8]};
+#pragma unroll
+                for (int t3 = 0; t3 < 3; t3++) {
+                    // (the narrow form's weight is (x * y) * z: powers of two, exact in any order)
+                    const double w = wx[t3] * wyz;
+#pragma unroll
+                    for (int r = 0; r < 3; r++) s[r] = fma(w, v[3 * t3 + r], s[r]);
+                }
+            }
+        }
+    } else
 #pragma unroll
     for (int dk = -1; dk <= 1; dk++) {
         const int k = 2 * K + dk;
@@ -369,6 +410,9 @@ __global__ __launch_bounds__(BLK) void k_prolong_add(Geom gc, Geom gf, const dou
     double s[DOF];
 #pragma unroll
     for (int r = 0; r < DOF; r++) s[r] = 0.0;
+    // (Round 6, measured and dropped: the same gather branch-free -- always 8 coarse triples, the absent ones with weight 0, the
+    // fine triple requested with them: bit-equal, 34.1 us against 30.6 in the step for the 1 -> 0 launch: the launch is bound by
+    // its read-modify-write of the fine vector out of a cold cache, not by the latency of its gathers.)
     for (int kk = 0; kk <= mk; kk++)
         for (int jj = 0; jj <= mj; jj++)
             for (int ii = 0; ii <= mi; ii++) {
@@ -438,6 +482,112 @@ __global__ __launch_bounds__(BLK) void k_dia_row(DiaOp<DOF> op, NodeArgs a) {
         } else {
             a.out[q] = y;
             pdot = u[q] * y;
+        }
+    }
+    if (EPI == EPI_APPLY_DOT) {
+        const double v[1] = {block_sum(pdot)};
+        reduce_tail<1>(v, a.partials, gridDim.x, blockIdx.x, a.ticket, a.red_out);
+    }
+}
+
+// Round 6: the 3-way split with a thread per NODE and z-offset instead of per row and z-offset (DOF = 3): the three rows of a
+// node share their neighbour indices, boundary flags and the 27 input values, and the 3 x 3 block towards a neighbour is three
+// contiguous triples either way it is stored -- own row: S[(blk 3 + c) nrows + 3 n + (0..2)] over the rows, mirrored:
+// S[((26 - blk) 3 + rr) nrows + 3 nb + (0..2)] over the columns.  Counters of the row form at 128^3's level 2 (35 937 nodes):
+// 25 FP64 instructions in 446 vector + 210 scalar instructions per wave on 3 888 waves -- index arithmetic; this form runs a third
+// of the waves.  One wave = one z-offset (the offset and everything derived from it are scalar), 64 nodes per workgroup of 192
+// threads.  Every row is summed in the order of k_dia_row_split<3, EPI, 3, SYM> (neighbours (dj, di), then c; the three partial
+// sums in LDS in the order of the z-offsets): the same bits.
+template <int EPI, bool SYM>
+__global__ __launch_bounds__(192) void k_dia_node3(DiaOp<3> op, NodeArgs a) {
+    constexpr int NPB = 64;
+    typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+    __shared__ double s_part[3][3][NPB];
+    const Geom &g = op.g;
+    const long plane = g.plane();
+    const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = threadIdx.x & 63;
+    const int nbk = gridDim.x, x8 = blockIdx.x & 7;
+    const int bid = SYM ? x8 * (nbk >> 3) + min(x8, nbk & 7) + (blockIdx.x >> 3) : blockIdx.x;
+    const long tl = ((long)bid * NPB + r) * 3;          // first row of the node, counted inside the launch
+    const bool valid = tl < op.rows_here();
+    const long q0 = (valid ? op.row_of(tl) : 0) + plane * g.own_lo * 3;
+    const long n = q0 / 3;
+    const double *__restrict__ u = a.x;
+    const double *__restrict__ S = op.S;
+    double e_b[3] = {0, 0, 0}, e_d[3] = {0, 0, 0}, e_di[3] = {0, 0, 0}, e_u[3] = {0, 0, 0};
+    if (valid && part == 0) {
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++) {
+            if (EPI == EPI_RESID || EPI == EPI_CHEB) e_b[rr] = a.b[q0 + rr];
+            if (EPI == EPI_CHEB) e_d[rr] = a.d[q0 + rr], e_di[rr] = a.dinv[q0 + rr];
+            if (EPI == EPI_APPLY && a.dinv) e_di[rr] = a.dinv[q0 + rr];
+            if (EPI == EPI_CHEB || EPI == EPI_APPLY_DOT) e_u[rr] = u[q0 + rr];
+        }
+    }
+    double y[3] = {0.0, 0.0, 0.0};
+    if (valid) {
+        const int k = (int)(n / plane);
+        const int rem = (int)(n % plane);
+        const int j = rem / g.nx, i = rem % g.nx;
+        const int dk = part - 1;
+        const bool okk = k + dk >= 0 && k + dk < g.nzl;
+        const bool own_k = k + dk >= g.own_lo && k + dk <= g.own_hi;
+#pragma unroll
+        for (int dj = -1; dj <= 1; dj++) {
+            const bool okj = okk && j + dj >= 0 && j + dj < g.ny;
+#pragma unroll
+            for (int di = -1; di <= 1; di++) {
+                const bool ok = okj && i + di >= 0 && i + di < g.nx;
+                const int blk = (dk + 1) * 9 + (dj + 1) * 3 + (di + 1);      // scalar
+                const long nb = ok ? n + di + (long)g.nx * (dj + (long)g.ny * dk) : n;
+                const bool mir = SYM && blk > 13 && ok && own_k;
+                const double *__restrict__ un = u + nb * 3;
+                const d2u u01 = *(const d2u *)un;
+                const double uv[3] = {u01.x, u01.y, un[2]};
+                // three contiguous triples: T[kq][0..2]
+                double T[3][3];
+#pragma unroll
+                for (int kq = 0; kq < 3; kq++) {
+                    const long ad = mir ? (long)((26 - blk) * 3 + kq) * op.nrows + nb * 3 : (long)(blk * 3 + kq) * op.nrows + q0;
+                    const d2u t01 = *(const d2u *)(S + ad);
+                    T[kq][0] = t01.x;
+                    T[kq][1] = t01.y;
+                    T[kq][2] = S[ad + 2];
+                }
+                // coefficient of row rr towards column c: own row T[c][rr], mirrored T[rr][c]
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+#pragma unroll
+                    for (int rr = 0; rr < 3; rr++) {
+                        const double cf = (rr == c) ? T[c][c] : (mir ? T[rr][c] : T[c][rr]);
+                        y[rr] = fma(cf, uv[c], y[rr]);
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 3; rr++) s_part[part][rr][r] = y[rr];
+    __syncthreads();
+    double pdot = 0.0;
+    if (valid && part == 0) {
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++) {
+            double yy = s_part[0][rr][r];
+            yy += s_part[1][rr][r];
+            yy += s_part[2][rr][r];
+            const long q = q0 + rr;
+            if (EPI == EPI_APPLY) {
+                a.out[q] = a.dinv ? e_di[rr] * yy : yy;
+            } else if (EPI == EPI_RESID) {
+                a.out[q] = e_b[rr] - yy;
+            } else if (EPI == EPI_CHEB) {
+                const double dn = cheb_dn(a.c1, e_d[rr], a.c2, e_di[rr], e_b[rr], yy);
+                a.d[q] = dn;
+                a.out[q] = e_u[rr] + dn;
+            } else {
+                a.out[q] = yy;
+                pdot = fma(e_u[rr], yy, pdot);
+            }
         }
     }
     if (EPI == EPI_APPLY_DOT) {
