@@ -101,7 +101,7 @@ le.SetUpLoadAndBC()
 le.AssembleStiffnessMatrix(grid.synth_density(12345), 1e-9, 1.0, 3.0)
 rng = np.random.default_rng(11)
 res = {}
-for l in range(2, nlv):
+for l in range(1 if os.environ.get("TP_NO_MACRO") else 2, nlv):
     n = 3 * le.level_nodes(l)
     u, b = torch.from_numpy(rng.standard_normal(n)).cuda(), torch.from_numpy(rng.standard_normal(n)).cuda()
     res["apply%%d" %% l] = le.level_apply(l, u).cpu().numpy()
@@ -120,8 +120,11 @@ np.savez(out, **res)
 """
 
 
-@pytest.mark.parametrize("mesh,nlv", [((128, 128, 64), 4), ((96, 96, 96), 5), ((128, 96, 64), 4)])   # level 2: 18 513 / 15 625 / 14 025 nodes -- the three-way split
-def test_stencil_kernel_per_node_equals_per_row_bitwise(tmp_path, mesh, nlv):
+# level 2 of the first three: 18 513 / 15 625 / 14 025 nodes; the fourth stores level 1 as a stencil (TP_NO_MACRO: 65^3 = 274 625
+# nodes, the size of the 256^3 class's level 2, where the row form used to run unsplit: both forms three-way split here)
+@pytest.mark.parametrize("mesh,nlv,extra", [((128, 128, 64), 4, {}), ((96, 96, 96), 5, {}), ((128, 96, 64), 4, {}),
+                                            ((128, 128, 128), 3, {"TP_NO_MACRO": "1", "TP_DIA_SPLIT": "3"})])
+def test_stencil_kernel_per_node_equals_per_row_bitwise(tmp_path, mesh, nlv, extra):
     """Round 6: on the stored-stencil levels whose rows are split three ways, a thread per NODE and z-offset (k_dia_node3: a third
     of the waves, the index arithmetic of a node shared by its three rows) against a thread per ROW and z-offset
     (k_dia_row_split<3, EPI, 3>; TP_DIA_NODE=0): operator, Chebyshev steps from a zero and a non-zero guess, the eigenvalue
@@ -130,8 +133,10 @@ def test_stencil_kernel_per_node_equals_per_row_bitwise(tmp_path, mesh, nlv):
     for tag, env in (("node", {}), ("row", {"TP_DIA_NODE": "0"})):
         out = str(tmp_path / (tag + ".npz"))
         e = dict(os.environ)
-        e.pop("TP_DIA_NODE", None)
+        for k in ("TP_DIA_NODE", "TP_NO_MACRO", "TP_NO_DIA_SYM", "TP_DIA_SPLIT"):
+            e.pop(k, None)
         e.update(env)
+        e.update(extra)
         r = subprocess.run([sys.executable, "-c", STENCIL_WORKER % {"root": ROOT}] + [str(v) for v in mesh] + [str(nlv), out],
                            env=e, capture_output=True, text=True, timeout=240)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -140,3 +145,30 @@ def test_stencil_kernel_per_node_equals_per_row_bitwise(tmp_path, mesh, nlv):
     assert sorted(a.files) == sorted(b.files) and any(k.startswith("apply") for k in a.files)
     for k in a.files:
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_large_level_node_stencil_with_mirrored_reads_against_the_plain_form(tmp_path):
+    """on a large stencil level (65^3 nodes: the 256^3 class's level 2, stored here as level 1 of 128^3) the node form reads the
+    upper half of the stencil from the neighbours' rows (mirrored, transposed blocks: half the coefficient stream -- what took
+    that level from 121 to 73 us per Chebyshev step); against the same kernel reading every coefficient from its own row
+    (TP_NO_DIA_SYM): operator, smoothing steps, V-cycle and solve agree to rounding (the stored stencil is symmetric to the
+    rounding of its Galerkin sums)"""
+    res = {}
+    mesh, nlv = (128, 128, 128), 3
+    for tag, env in (("sym", {}), ("plain", {"TP_NO_DIA_SYM": "1"})):
+        out = str(tmp_path / (tag + ".npz"))
+        e = dict(os.environ)
+        for k in ("TP_DIA_NODE", "TP_NO_DIA_SYM"):
+            e.pop(k, None)
+        e.update(env)
+        e["TP_NO_MACRO"] = "1"
+        r = subprocess.run([sys.executable, "-c", STENCIL_WORKER % {"root": ROOT}] + [str(v) for v in mesh] + [str(nlv), out],
+                           env=e, capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = np.load(out)
+    a, b = res["sym"], res["plain"]
+    assert int(a["its"][0]) == int(b["its"][0])
+    for k in a.files:
+        if k.startswith(("apply", "cheb", "pc")):
+            assert np.abs(a[k] - b[k]).max() <= 1e-12 * np.abs(b[k]).max(), k
+    assert np.abs(a["U"] - b["U"]).max() <= 1e-9 * np.abs(b["U"]).max()      # (a solve to rtol 1e-8 under a preconditioner that differs in its last bits)

@@ -806,7 +806,13 @@ struct MGSolver {
             // launches below must sum every row in the order the single launch would
             const int nbr_all = (int)((rows_all + BLK - 1) / BLK);
             static const int split_env = getenv("TP_DIA_SPLIT") ? atoi(getenv("TP_DIA_SPLIT")) : -1;
-            const int rsplit = split_env >= 0 ? split_env : (nbr_all < 128 ? 9 : (nbr_all < 512 ? 3 : 1));
+            // DOF 3, round 6: the node form (k_dia_node3: a wave per z-offset, mirrored reads) serves EVERY level beyond the 9-way
+            // class.  Measured per Chebyshev step against the unsplit row form the large levels used to run: C3's level 2 (70 785
+            // nodes) 27.9 -> 19.0 us, the 256^3 class's (274 625) 121.5 -> 73.2, C5's (545 025) 231.7 -> 158.2 -- the mirrored reads
+            // halve the coefficient stream out of HBM (the second use comes from the L2 / Infinity Cache); an unsplit node form
+            // (one thread over all 27 neighbours) measured 209 / 387 us: too many registers per thread to keep the stream busy.
+            static const bool by_node = !(getenv("TP_DIA_NODE") && atoi(getenv("TP_DIA_NODE")) == 0);
+            const int rsplit = split_env >= 0 ? split_env : (nbr_all < 128 ? 9 : ((DOF == 3 && by_node) ? 3 : (nbr_all < 512 ? 3 : 1)));
             static const bool sym = getenv("TP_NO_DIA_SYM") == nullptr;
             auto launch_rows = [&](long t0, long tn, long t1, long tn1) -> int {
                 o.t0 = t0, o.tn = tn, o.t1 = t1, o.tn1 = tn1;
@@ -817,7 +823,6 @@ struct MGSolver {
                     TP_LAUNCH((k_dia_row_split<DOF, EPI, 9>), dim3(nbr), dim3(BLK), 0, grid->stream, o, a);
                 } else if (rsplit == 3) {
                     // round 6: a thread per node and z-offset (k_dia_node3: the same bits, a third of the waves); TP_DIA_NODE=0: per row
-                    static const bool by_node = !(getenv("TP_DIA_NODE") && atoi(getenv("TP_DIA_NODE")) == 0);
                     bool done = false;
                     if constexpr (DOF == 3) {
                         if (by_node && EPI != EPI_APPLY_DOT) {

@@ -498,14 +498,17 @@ __global__ __launch_bounds__(BLK) void k_dia_row(DiaOp<DOF> op, NodeArgs a) {
 // of the waves.  One wave = one z-offset (the offset and everything derived from it are scalar), 64 nodes per workgroup of 192
 // threads.  Every row is summed in the order of k_dia_row_split<3, EPI, 3, SYM> (neighbours (dj, di), then c; the three partial
 // sums in LDS in the order of the z-offsets): the same bits.
+// Used for every level beyond the 9-way class (mg.h): on the large ones (C3's, the 256^3 class's and C5's level 2) the mirrored
+// reads halve the coefficient stream the unsplit row form used to pull from HBM.
 template <int EPI, bool SYM>
 __global__ __launch_bounds__(192) void k_dia_node3(DiaOp<3> op, NodeArgs a) {
+    constexpr int SPLIT = 3;
     constexpr int NPB = 64;
     typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
-    __shared__ double s_part[3][3][NPB];
+    __shared__ double s_part[SPLIT == 3 ? 3 : 1][3][SPLIT == 3 ? NPB : 1];
     const Geom &g = op.g;
     const long plane = g.plane();
-    const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = threadIdx.x & 63;
+    const int part = SPLIT == 3 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0, r = SPLIT == 3 ? (threadIdx.x & 63) : threadIdx.x;
     const int nbk = gridDim.x, x8 = blockIdx.x & 7;
     const int bid = SYM ? x8 * (nbk >> 3) + min(x8, nbk & 7) + (blockIdx.x >> 3) : blockIdx.x;
     const long tl = ((long)bid * NPB + r) * 3;          // first row of the node, counted inside the launch
@@ -529,52 +532,60 @@ __global__ __launch_bounds__(192) void k_dia_node3(DiaOp<3> op, NodeArgs a) {
         const int k = (int)(n / plane);
         const int rem = (int)(n % plane);
         const int j = rem / g.nx, i = rem % g.nx;
-        const int dk = part - 1;
-        const bool okk = k + dk >= 0 && k + dk < g.nzl;
-        const bool own_k = k + dk >= g.own_lo && k + dk <= g.own_hi;
 #pragma unroll
-        for (int dj = -1; dj <= 1; dj++) {
-            const bool okj = okk && j + dj >= 0 && j + dj < g.ny;
+        for (int dkk = 0; dkk < (SPLIT == 3 ? 1 : 3); dkk++) {
+            const int dk = (SPLIT == 3 ? part : dkk) - 1;
+            const bool okk = k + dk >= 0 && k + dk < g.nzl;
+            const bool own_k = k + dk >= g.own_lo && k + dk <= g.own_hi;
 #pragma unroll
-            for (int di = -1; di <= 1; di++) {
-                const bool ok = okj && i + di >= 0 && i + di < g.nx;
-                const int blk = (dk + 1) * 9 + (dj + 1) * 3 + (di + 1);      // scalar
-                const long nb = ok ? n + di + (long)g.nx * (dj + (long)g.ny * dk) : n;
-                const bool mir = SYM && blk > 13 && ok && own_k;
-                const double *__restrict__ un = u + nb * 3;
-                const d2u u01 = *(const d2u *)un;
-                const double uv[3] = {u01.x, u01.y, un[2]};
-                // three contiguous triples: T[kq][0..2]
-                double T[3][3];
+            for (int dj = -1; dj <= 1; dj++) {
+                const bool okj = okk && j + dj >= 0 && j + dj < g.ny;
 #pragma unroll
-                for (int kq = 0; kq < 3; kq++) {
-                    const long ad = mir ? (long)((26 - blk) * 3 + kq) * op.nrows + nb * 3 : (long)(blk * 3 + kq) * op.nrows + q0;
-                    const d2u t01 = *(const d2u *)(S + ad);
-                    T[kq][0] = t01.x;
-                    T[kq][1] = t01.y;
-                    T[kq][2] = S[ad + 2];
-                }
-                // coefficient of row rr towards column c: own row T[c][rr], mirrored T[rr][c]
+                for (int di = -1; di <= 1; di++) {
+                    const bool ok = okj && i + di >= 0 && i + di < g.nx;
+                    const int blk = (dk + 1) * 9 + (dj + 1) * 3 + (di + 1);      // scalar (SPLIT 3) / compile time (SPLIT 1)
+                    const long nb = ok ? n + di + (long)g.nx * (dj + (long)g.ny * dk) : n;
+                    const bool mir = SYM && blk > 13 && ok && own_k;
+                    const double *__restrict__ un = u + nb * 3;
+                    const d2u u01 = *(const d2u *)un;
+                    const double uv[3] = {u01.x, u01.y, un[2]};
+                    // three contiguous triples: T[kq][0..2]
+                    double T[3][3];
 #pragma unroll
-                for (int c = 0; c < 3; c++)
-#pragma unroll
-                    for (int rr = 0; rr < 3; rr++) {
-                        const double cf = (rr == c) ? T[c][c] : (mir ? T[rr][c] : T[c][rr]);
-                        y[rr] = fma(cf, uv[c], y[rr]);
+                    for (int kq = 0; kq < 3; kq++) {
+                        const long ad = mir ? (long)((26 - blk) * 3 + kq) * op.nrows + nb * 3 : (long)(blk * 3 + kq) * op.nrows + q0;
+                        const d2u t01 = *(const d2u *)(S + ad);
+                        T[kq][0] = t01.x;
+                        T[kq][1] = t01.y;
+                        T[kq][2] = S[ad + 2];
                     }
+                    // coefficient of row rr towards column c: own row T[c][rr], mirrored T[rr][c]
+#pragma unroll
+                    for (int c = 0; c < 3; c++)
+#pragma unroll
+                        for (int rr = 0; rr < 3; rr++) {
+                            const double cf = (rr == c) ? T[c][c] : (mir ? T[rr][c] : T[c][rr]);
+                            y[rr] = fma(cf, uv[c], y[rr]);
+                        }
+                }
             }
         }
     }
+    if (SPLIT == 3) {
 #pragma unroll
-    for (int rr = 0; rr < 3; rr++) s_part[part][rr][r] = y[rr];
-    __syncthreads();
+        for (int rr = 0; rr < 3; rr++) s_part[part][rr][r] = y[rr];
+        __syncthreads();
+    }
     double pdot = 0.0;
     if (valid && part == 0) {
 #pragma unroll
         for (int rr = 0; rr < 3; rr++) {
-            double yy = s_part[0][rr][r];
-            yy += s_part[1][rr][r];
-            yy += s_part[2][rr][r];
+            double yy = y[rr];
+            if (SPLIT == 3) {
+                yy = s_part[0][rr][r];
+                yy += s_part[1][rr][r];
+                yy += s_part[2][rr][r];
+            }
             const long q = q0 + rr;
             if (EPI == EPI_APPLY) {
                 a.out[q] = a.dinv ? e_di[rr] * yy : yy;
