@@ -54,6 +54,10 @@ WORKLOADS = {
     # until the coarsest level fits the exact solve, level 2 cycled three times (tools/r05_c5_deep.sh: 18.3 -> 7.7 ms, 481 -> 176 ms)
     "c2_deep": dict(el=(128, 64, 64), nlvls=5, nsmooth=2, ncoarse=45, cycles="1,3,1,1"),
     "c5_deep": dict(el=(512, 256, 256), nlvls=7, nsmooth=2, ncoarse=60, cycles="1,3,1,1,1,1"),
+    # configs[0] and configs[3] AT the depths SURVEY 8(d) states for them ("MG levels: C1 4, C4 3"), beside the re-scanned cycles of
+    # `c1` (3 levels) and `c4` (5 levels) -- VERDICT r5 weak 10: the stated-depth figures belong beside the tuned ones, as for C2 / C5
+    "c1_stated": dict(el=(48, 24, 24), nlvls=4, nsmooth=2, ncoarse=22),
+    "c4_stated": dict(el=(192, 64, 64), nlvls=3, nsmooth=2, ncoarse=45, ftype=2, bc="mbb"),
     "tiny": dict(el=(32, 16, 16), nlvls=3, nsmooth=2, ncoarse=30),
     # the mesh of the design-loop parity test (tests/test_bench_line.py: --design-loop against the oracle's loop), the metric mesh's recipe
     "cant64": dict(el=(64, 32, 32), nlvls=4, nsmooth=2, ncoarse=20, cycles="1,3,1"),
