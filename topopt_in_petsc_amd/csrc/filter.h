@@ -297,15 +297,19 @@ static int filter_conv(tp_filter *f, double *out, const double *d1, const double
 #define TP_CONV_TILED(CC)                                                                                            \
     TP_LAUNCH(k_conv_filter_tiled<CC>, tg, dim3(256), 0, g->stream, g->ex, g->ey, g->ez_own, g->rank * g->ez_own, \
                        g->ez_glob, f->xg, f->wtab, out, d1, d2)
+#define TP_CONV_WIDE(CC, TYE, TZE)                                                                                                   \
+    TP_LAUNCH((k_conv_filter_wide<CC, TYE, TZE>), dim3((g->ex + 31) / 32, (g->ey + TYE - 1) / TYE, (g->ez_own + TZE - 1) / TZE), \
+              dim3(8 * TYE * TZE), 0, g->stream, g->ex, g->ey, g->ez_own, g->rank * g->ez_own, g->ez_glob, f->xg, f->wtab, out, d1, d2)
+    // Round 6 (counters: the one-output form is LDS-issue bound, one ds_read per fma): the four-outputs-per-thread form was
+    // measured for the small radii too, bit-equal -- ElemConn 3 (343 taps): 105.5 -> 69.8 us at 128^3, taken; ElemConn 2 (125
+    // taps, the bench's 2.56 h): 96 us against 50 (its 32-byte lane stride of the staged rows conflicts in the LDS banks, and a
+    // quarter of the threads), fully unrolled no better: the one-output form stays for ElemConn 1 and 2
     if (!no_tile && c == 1)
         TP_CONV_TILED(1);
     else if (!no_tile && c == 2)
         TP_CONV_TILED(2);
     else if (!no_tile && c == 3)
-        TP_CONV_TILED(3);
-#define TP_CONV_WIDE(CC, TYE, TZE)                                                                                                   \
-    TP_LAUNCH((k_conv_filter_wide<CC, TYE, TZE>), dim3((g->ex + 31) / 32, (g->ey + TYE - 1) / TYE, (g->ez_own + TZE - 1) / TZE), \
-              dim3(8 * TYE * TZE), 0, g->stream, g->ex, g->ey, g->ez_own, g->rank * g->ez_own, g->ez_glob, f->xg, f->wtab, out, d1, d2)
+        TP_CONV_WIDE(3, 8, 4);
     else if (!no_tile && c == 4)
         TP_CONV_WIDE(4, 8, 4);
     else if (!no_tile && c == 5)
