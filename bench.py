@@ -238,6 +238,10 @@ PARITY_BOUNDS = {
     "vs_oracle": 1e-10,                    # GPU vs the double-precision oracle on the reference's KE: everything above.  Rounds 4-5 measured
                                            # 1.6e-10 / 3.0e-10 at 128^3 (and ran with 1e-9 here): the packed form dropped KE's translation
                                            # residues; round 6 keeps them (csrc/matfree_tile.h: SYMKE_TRANSL) -- north_star's figure, as is
+    "dense_check": 1e-9,                   # the diagnostic step on the dense-KE kernels against the arbiter on KE.  A dense 24x24 product of an
+                                           # iterate whose translation is 1e5 x its strain carries a rounding error of eps |KE| |t| per term -- the
+                                           # size of KE's own residue -- where the packed form differences the translation away first: over C2's 35
+                                           # iterations 1.2e-10 (the product path: 2e-12; the CSR oracle, dense too: 4.4e-11); 6e-13 at 128^3
     "gx_abs": 1e-13,                       # volume constraint
     "behind_pde_filter": 1e-6,             # workloads with the Helmholtz filter (its own solve stops at rtol 1e-8): fx, first ten ||r_k||, gx
 }
@@ -927,7 +931,7 @@ def main():
                 # (held against the ARBITER on KE: two double-precision runs of a 35-iteration solve differ by 1e-10 in their late
                 # ||r_k|| through summation order alone -- C2: oracle vs arbiter 4.4e-11, this run vs arbiter 5.9e-11, vs oracle 1.03e-10)
                 for key in ("fx_rel_err", "hist_max_rel_err"):
-                    if dense["vs_arbiter_on_KE"][key] > B["vs_oracle"]:
+                    if dense["vs_arbiter_on_KE"][key] > B["dense_check"]:
                         breaches.append("dense_KE.vs_arbiter_on_KE." + key)
                 le_d.close()
                 le_d = df_d = dg_d = None

@@ -45,7 +45,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert p["its_equal"] and p["its_gpu"] == cb["cg_its"], p
     assert p["gx_abs_err"] <= 1e-13, p
     # the bounds bench.py itself enforces (exit code 4 on a breach)
-    assert p["bounds"] == {"vs_arbiter_on_own_operator": 1e-10, "element_matrix": 1e-15, "vs_oracle": 1e-10, "gx_abs": 1e-13, "behind_pde_filter": 1e-6}
+    assert p["bounds"] == {"vs_arbiter_on_own_operator": 1e-10, "element_matrix": 1e-15, "vs_oracle": 1e-10, "dense_check": 1e-9, "gx_abs": 1e-13, "behind_pde_filter": 1e-6}
     # (2) the operator the kernels apply: the library's export is the restatement the arbiter ran on, and it is KE to 1e-15
     em = p["element_matrix"]
     assert em["library_export_equals_restatement"] is True and 0 < em["KE_eff_vs_KE"] <= 1e-15, em

@@ -546,8 +546,8 @@ struct MGSolver {
                     TP_HIP(hipMalloc((void **)p, rb));
                     TP_HIP(hipMemsetAsync(*p, 0, rb, grid->stream));
                 }
-                TP_HIP(hipMalloc((void **)&R.S, rb * 27 * DOF));
-                TP_HIP(hipMemsetAsync(R.S, 0, rb * 27 * DOF, grid->stream));
+                TP_HIP(hipMalloc((void **)&R.S, rb * 28 * DOF));   // (+ DOF slices: row-sum correction of the mirrored reads)
+                TP_HIP(hipMemsetAsync(R.S, 0, rb * 28 * DOF, grid->stream));
             }
         }
         size_t nb = sizeof(double) * (size_t)lv[0].ndof();
@@ -1470,6 +1470,10 @@ struct MGSolver {
             if (L.kind != LV_DIA) return TP_ERR_STATE;   // (only stored-stencil levels have rows to gather)
             TP_TRY(gather_owned(L, L.S, R, R.S, 27 * DOF, L.ndof(), R.ndof()));
             TP_TRY(gather_owned(L, L.dinv, R, R.dinv, 1));
+            if constexpr (DOF == 3) {   // the replicated copy owns every row: its own correction of the mirrored reads
+                TP_LAUNCH(k_dia_sym_fix, dim3((int)((R.g.owned_nodes() + BLK - 1) / BLK)), dim3(BLK), 0, grid->stream, R.g, R.S, (long)R.ndof());
+                count_launch(grid);
+            }
         }
         return TP_OK;
     }

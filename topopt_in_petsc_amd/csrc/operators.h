@@ -490,6 +490,41 @@ __global__ __launch_bounds__(BLK) void k_dia_row(DiaOp<DOF> op, NodeArgs a) {
     }
 }
 
+// Round 6: what the mirrored reads change, and the correction that goes with them.  Reading the block towards an "upper"
+// neighbour from that neighbour's row (transposed) replaces A_ij by A_ji^T.  The stored stencil is symmetric only to the
+// rounding of its Galerkin sums, and entry by entry that is harmless -- but it changes every ROW SUM by sum_j (A_ji^T - A_ij): the
+// row's answer to a rigid translation, itself only the rounding residue of an exact zero and, as on the fine level,
+// what a multigrid iterate with its large smooth component feels.  Measured on C3 (256 x 128 x 128, 14 iterations): the last
+// ||r_k|| moves by 6.5e-11 against the CPU checker when level 2 takes the mirrored reads, 1.6e-13 for a mere change of summation
+// order.  So the difference is kept: dS = sum over the mirrored neighbours of (A_ij - A_ji^T), a 3 x 3 block per node in the
+// three extra slices 81 .. 83 of the stencil array, added to the row's result as dS u_i -- each row answers a translation as
+// the stored row does, and only fields that vary from node to node see the mirrored values.
+__global__ __launch_bounds__(BLK) void k_dia_sym_fix(Geom g, double *__restrict__ S, long nrows) {
+    const long plane = g.plane();
+    const long t = blockIdx.x * (long)BLK + threadIdx.x;
+    if (t >= g.owned_nodes()) return;
+    const int k = g.own_lo + (int)(t / plane);
+    const int rem = (int)(t % plane);
+    const int j = rem / g.nx, i = rem % g.nx;
+    const long n = t + plane * g.own_lo;
+    double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int blk = 14; blk < 27; blk++) {
+        const int di = blk % 3 - 1, dj = (blk / 3) % 3 - 1, dk = blk / 9 - 1;
+        const bool ok = k + dk >= 0 && k + dk < g.nzl && j + dj >= 0 && j + dj < g.ny && i + di >= 0 && i + di < g.nx;
+        if (!(ok && k + dk >= g.own_lo && k + dk <= g.own_hi)) continue;   // (the kernel's own condition for a mirrored read)
+        const long nb = n + di + (long)g.nx * (dj + (long)g.ny * dk);
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                acc[r][c] += S[(long)(blk * 3 + c) * nrows + n * 3 + r] - S[(long)((26 - blk) * 3 + r) * nrows + nb * 3 + c];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) S[(long)(81 + c) * nrows + n * 3 + r] = acc[r][c];
+}
+
 // Round 6: the 3-way split with a thread per NODE and z-offset instead of per row and z-offset (DOF = 3): the three rows of a
 // node share their neighbour indices, boundary flags and the 27 input values, and the 3 x 3 block towards a neighbour is three
 // contiguous triples either way it is stored -- own row: S[(blk 3 + c) nrows + 3 n + (0..2)] over the rows, mirrored:
@@ -524,8 +559,16 @@ __global__ __launch_bounds__(192) void k_dia_node3(DiaOp<3> op, NodeArgs a) {
             if (EPI == EPI_RESID || EPI == EPI_CHEB) e_b[rr] = a.b[q0 + rr];
             if (EPI == EPI_CHEB) e_d[rr] = a.d[q0 + rr], e_di[rr] = a.dinv[q0 + rr];
             if (EPI == EPI_APPLY && a.dinv) e_di[rr] = a.dinv[q0 + rr];
-            if (EPI == EPI_CHEB || EPI == EPI_APPLY_DOT) e_u[rr] = u[q0 + rr];
+            if (EPI == EPI_CHEB || EPI == EPI_APPLY_DOT || SYM) e_u[rr] = u[q0 + rr];
         }
+    }
+    // SYM: the row-sum correction of the mirrored reads (k_dia_sym_fix), requested with the epilogue operands
+    double e_ds[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    if (SYM && valid && part == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int rr = 0; rr < 3; rr++) e_ds[rr][c] = S[(long)(81 + c) * op.nrows + q0 + rr];
     }
     double y[3] = {0.0, 0.0, 0.0};
     if (valid) {
@@ -586,6 +629,10 @@ __global__ __launch_bounds__(192) void k_dia_node3(DiaOp<3> op, NodeArgs a) {
                 yy += s_part[1][rr][r];
                 yy += s_part[2][rr][r];
             }
+            if (SYM) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) yy = fma(e_ds[rr][c], e_u[c], yy);
+            }
             const long q = q0 + rr;
             if (EPI == EPI_APPLY) {
                 a.out[q] = a.dinv ? e_di[rr] * yy : yy;
@@ -638,6 +685,18 @@ __global__ __launch_bounds__(BLK) void k_dia_row_split(DiaOp<DOF> op, NodeArgs a
         if (EPI == EPI_APPLY && a.dinv) e_di = a.dinv[q];
         if (EPI == EPI_CHEB || EPI == EPI_APPLY_DOT) e_u = u[q];
     }
+    // SYM: the row-sum correction of the mirrored reads (k_dia_sym_fix; the same three fma as k_dia_node3, the same bits)
+    double e_ds[DOF], e_un[DOF];
+#pragma unroll
+    for (int c = 0; c < DOF; c++) e_ds[c] = 0.0, e_un[c] = 0.0;
+    if (SYM && DOF == 3 && valid && part == 0) {
+        const long nn = q / DOF;
+#pragma unroll
+        for (int c = 0; c < DOF; c++) {
+            e_ds[c] = op.S[(long)(27 * DOF + c) * op.nrows + q];
+            e_un[c] = u[nn * DOF + c];
+        }
+    }
     if (valid) {
         const long n = q / DOF;
         const int k = (int)(n / plane);
@@ -673,6 +732,10 @@ __global__ __launch_bounds__(BLK) void k_dia_row_split(DiaOp<DOF> op, NodeArgs a
         double y = s_part[0][r];
 #pragma unroll
         for (int p = 1; p < SPLIT; p++) y += s_part[p][r];
+        if (SYM && DOF == 3) {
+#pragma unroll
+            for (int c = 0; c < DOF; c++) y = fma(e_ds[c], e_un[c], y);
+        }
         if (EPI == EPI_APPLY) {
             a.out[q] = a.dinv ? e_di * y : y;
         } else if (EPI == EPI_RESID) {

@@ -671,8 +671,9 @@ extern "C" int tp_elasticity_create_ke(tp_elasticity **out, tp_grid *g, const tp
         }
         if (l > 0) {
             if (L.kind == LV_DIA) {
-                TP_HIP(hipMalloc((void **)&L.S, sizeof(double) * 81 * (size_t)L.ndof()));
-                TP_HIP(hipMemset(L.S, 0, sizeof(double) * 81 * (size_t)L.ndof()));
+                // 81 diagonals + 3 slices for the row-sum correction of the mirrored reads (operators.h: k_dia_sym_fix)
+                TP_HIP(hipMalloc((void **)&L.S, sizeof(double) * 84 * (size_t)L.ndof()));
+                TP_HIP(hipMemset(L.S, 0, sizeof(double) * 84 * (size_t)L.ndof()));
             }
             // the matrix-free level 1 materialises no element matrices (1.2 GB at 128^3)
             if (L.kind != LV_MACRO) TP_HIP(hipMalloc((void **)&L.Kel, sizeof(double) * 576 * (size_t)L.g.elems_stored()));
@@ -1139,6 +1140,8 @@ static int elasticity_setup_from_E(tp_elasticity *e) {
         } else {
             TP_LAUNCH(k_elem_to_dia, dim3(gn, 27), dim3(BLK), 0, s, C.g, C.Kel, C.S, C.dinv);
             count_launch(g, 8.0 * (576.0 * C.g.elems_stored() + 243.0 * C.g.owned_nodes()), 9.0 * 64 * C.g.owned_nodes());
+            TP_LAUNCH(k_dia_sym_fix, dim3(gn), dim3(BLK), 0, s, C.g, C.S, (long)C.ndof());
+            count_launch(g, 8.0 * 243.0 * C.g.owned_nodes(), 2.0 * 117 * C.g.owned_nodes());
         }
         return TP_OK;
     };
