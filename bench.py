@@ -105,6 +105,9 @@ def parse():
                         "sensitivities, filter, device MMA, filter) from the uniform start and report their times and CG iteration counts in "
                         "config.design_loop; -1: 60 for the default workload on one GPU, else 0")
     p.add_argument("--design-loop-records", action="store_true", help="keep every iteration's record (fx, gx, ch, its, ms) in config.design_loop")
+    p.add_argument("--no-parity-extras", action="store_true",
+                   help="parity object from the oracle's step alone (fx, gx, iteration count, every ||r_k||): no converged step, no 80-bit arbiter, "
+                        "no dense-KE step -- for meshes where the arbiter's memory (20 B per non-zero of the assembled matrix) is too much")
     p.add_argument("--no-dense-check", action="store_true", help="parity object without the step on the dense-KE kernels (TP_NO_TILE / TP_NO_MACRO)")
     return p.parse_args()
 
@@ -220,6 +223,10 @@ class Watchdog:
 def cpu_baseline_worker(argv):
     """`bench.py --cpu-baseline-worker out.json sample rtol fine_eig ex ey ez ndof budget nlv nsmooth ncoarse cycles direct`:
     the oracle's design iteration in a process of its own (all host cores, nothing of torch or the GPU library loaded)."""
+    if os.environ.get("TP_CPU_WORKER_MEM_GB"):   # a ceiling of this process' address space: a mesh too large for the host ends in a failed
+        import resource                           # allocation here, not in the kernel's out-of-memory killer (the CSR of 1e8 DOF is 100 GB)
+        lim = int(float(os.environ["TP_CPU_WORKER_MEM_GB"]) * (1 << 30))
+        resource.setrlimit(resource.RLIMIT_AS, (lim, lim))
     out, sample, rtol, fine_eig, ex, ey, ez, ndof, budget, nlv, nsmooth, ncoarse, cycles, direct = argv[:14]
     extras_npz = argv[14] if len(argv) > 14 and argv[14] != "-" else None   # where the parity extras' vectors go (same-mesh run only)
     problem = json.loads(argv[15]) if len(argv) > 15 else None              # {"ftype", "bc", "rmin"} of the workload
@@ -545,7 +552,7 @@ def main():
                str(ex0), str(ey0), str(ez0), str(3 * (ex0 + 1) * (ey0 + 1) * (ez0 + 1)), repr(a.cpu_budget), str(nlv), str(a.nsmooth),
                str(a.ncoarse), a.cycles or "-", str(direct_guess), "-"]
         extras_npz = None
-        if not a.no_parity:
+        if not a.no_parity and not a.no_parity_extras:
             extras_npz = cpu_json + ".extras.npz"
             cmd[-1] = extras_npz
         cmd.append(json.dumps({"ftype": W.get("ftype", 1), "bc": W.get("bc", "cantilever"), "rmin": W.get("rmin"), "pde": W.get("pde"), "nlanczos": a.nlanczos or None,
