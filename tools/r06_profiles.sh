@@ -26,6 +26,7 @@ if want bench; then
     python tools/step_shares.py $DB > gpurun_out/r06_bench_step_shares.txt
     python tools/iter_timeline.py $DB > gpurun_out/r06_iteration_timeline.txt
     python tools/setup_trace.py $DB > gpurun_out/r06_setup_streams.txt
+    python tools/setup_trace.py $DB -v > gpurun_out/r06_setup_timeline.txt
   fi
   rm -rf /tmp/prof_bench
   head -n 14 gpurun_out/r06_bench_kernel_stats.csv | cut -c1-130; head -8 gpurun_out/r06_bench_idle_gaps.txt; head -n 26 gpurun_out/r06_bench_step_shares.txt

@@ -21,3 +21,7 @@ for k, v in by.items():
     names = collections.Counter(x[0].split("(")[0][:40] for x in v)
     print("stream %s: %4d kernels, from %.3f to %.3f ms, busy %.3f ms | %s" % (k, len(v), (v[0][1] - t0) / 1e6, (max(x[2] for x in v) - t0) / 1e6,
           sum(x[2] - x[1] for x in v) / 1e6, ", ".join("%s x%d" % kv for kv in names.most_common(4))))
+if "-v" in sys.argv:  # every kernel of the set-up, in start order
+    print("\nstart_ms  dur_us  stream  kernel")
+    for r in seg:
+        print("%8.3f %7.1f  %6s  %s" % ((r[1] - t0) / 1e6, (r[2] - r[1]) / 1e3, r[3] if key else 0, r[0].split("(")[0][:60]))

@@ -542,7 +542,7 @@ __global__ __launch_bounds__(BLK) void k_macro_corr_gather(const int *__restrict
 
 // Gather of the element-row products around every affected node (as k_macro_corr_gather) applied directly to the
 // result of the level-1 operator launch that computed them (matfree_tile.h: workgroups beyond the tiles):
-//   APPLY  y += c      RESID  r -= c      CHEB  (d, x_out) -= c2 dinv c
+//   APPLY  y += c (y += dinv c for the scaled product)      RESID  r -= c      CHEB  (d, x_out) -= c2 dinv c
 template <int EPI>
 __global__ __launch_bounds__(BLK) void k_macro_corr_apply(const int *__restrict__ nodes, const int *__restrict__ adj,
                                                           int nnodes, const double *__restrict__ tmp, int nlist,
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(BLK) void k_macro_corr_apply(const int *__restrict_
     for (int r = 0; r < 3; r++) {
         const long q = 3 * n + r;
         if (EPI == EPI_APPLY) {
-            a.out[q] += acc[r];
+            a.out[q] += a.dinv ? acc[r] * a.dinv[q] : acc[r];  // a.dinv: the scaled product of the spectrum estimate
         } else if (EPI == EPI_RESID) {
             a.out[q] -= acc[r];
         } else if (EPI == EPI_CHEB) {

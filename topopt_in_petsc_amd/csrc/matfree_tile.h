@@ -562,6 +562,7 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
                     }
                 }
                 if (MACRO && t.corr) co[c] = t.corr[nq + c];
+                if (EPI == EPI_APPLY && a.dinv) di[c] = a.dinv[nq + c];  // scaled product (the spectrum estimate's D^-1/2 A D^-1/2)
             }
         }
         if (more) load_plane(el + 3, pre);      // lands in slot b0 once this step is done with it
@@ -662,7 +663,7 @@ __global__ __launch_bounds__(TILE * TILE, MACRO ? 2 : 3) void k_matfree_tile(Til
                 if ((m >> c) & 1u) y = xo[c];
                 const long q = nq + c;
                 if (EPI == EPI_APPLY) {
-                    a.out[q] = y;
+                    a.out[q] = a.dinv ? y * di[c] : y;
                 } else if (EPI == EPI_RESID) {
                     a.out[q] = bo[c] - y;
                 } else if (EPI == EPI_CHEB && DIAG_FLY) {

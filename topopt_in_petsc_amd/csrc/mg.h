@@ -121,7 +121,10 @@ __global__ __launch_bounds__(BLK) void k_dot2(const double *__restrict__ a1, con
 // Lanczos helpers (owned range)
 template <int DOF>
 __global__ __launch_bounds__(BLK) void k_lanczos_init(Geom g, double *__restrict__ v, double *__restrict__ dis,
-                                                      const double *__restrict__ dinv) {
+                                                      const double *__restrict__ dinv, double *__restrict__ coef, int ncoef) {
+    // the run's coefficient table starts from zero (a memset node in the replayed chain cost ~50 us before its first kernel)
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < ncoef; i += BLK) coef[i] = 0.0;
     const long plane = g.plane();
     const long t = blockIdx.x * (long)BLK + threadIdx.x;
     if (t >= g.owned_nodes()) return;
@@ -134,9 +137,15 @@ __global__ __launch_bounds__(BLK) void k_lanczos_init(Geom g, double *__restrict
     }
 }
 // partials[q*nb + b] = sum over block b of V_q . w   (grid = (nb, nv); V_q = V + q*stride)
+// Round 6: with `mticket` the last workgroup of vector q to arrive adds q's partial sums itself, in k_reduce_multi's order
+// (bitwise the same value, one dependent launch less per Gram-Schmidt pass).  Counters as in reduce_tail (common.h), one set
+// of 8 shards + top per vector, MT_STRIDE words apart (a cache line of their own each); they rest at 0.
+constexpr int MT_STRIDE = 64;             // unsigned words between two counters (256 B)
+constexpr int MT_WORDS = 9 * MT_STRIDE;   // per vector
 __global__ __launch_bounds__(BLK) void k_multi_dot(const double *__restrict__ V, long stride, int nv,
                                                    const double *__restrict__ w, long off, long n,
-                                                   double *__restrict__ partials) {
+                                                   double *__restrict__ partials, unsigned *mticket,
+                                                   double *__restrict__ out) {
     const int q = blockIdx.y;
     const double *__restrict__ vq = V + (long)q * stride;
     // 4 independent chains: with one workgroup per vector (small levels) the loop is latency bound
@@ -151,7 +160,34 @@ __global__ __launch_bounds__(BLK) void k_multi_dot(const double *__restrict__ V,
     }
     for (; i < n; i += st) s0 = fma(vq[off + i], w[off + i], s0);
     double s = block_sum((s0 + s1) + (s2 + s3));
-    if (threadIdx.x == 0) partials[(long)q * gridDim.x + blockIdx.x] = s;
+    const int nb = gridDim.x, b = blockIdx.x;
+    if (!mticket) {
+        if (threadIdx.x == 0) partials[(long)q * nb + b] = s;
+        return;
+    }
+    __shared__ int s_last;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&partials[(long)q * nb + b], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int sh = b & 7;
+        const unsigned in_shard = (unsigned)((nb + 7 - sh) >> 3);
+        unsigned *base = mticket + (size_t)q * MT_WORDS, *mine_t = base + sh * MT_STRIDE, *top_t = base + 8 * MT_STRIDE;
+        int last = 0;
+        if (__hip_atomic_fetch_add(mine_t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1) {
+            __hip_atomic_store(mine_t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned shards = (unsigned)(nb < 8 ? nb : 8);
+            last = __hip_atomic_fetch_add(top_t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards - 1;
+            if (last) __hip_atomic_store(top_t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    double t = 0.0;
+    for (int bb = threadIdx.x; bb < nb; bb += BLK)
+        t += __hip_atomic_load(&partials[(long)q * nb + bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = block_sum(t);
+    if (threadIdx.x == 0) out[q] = t;
 }
 // out[q] = sum_b partials[q*nb + b]; one workgroup per value (grid = nv)
 __global__ __launch_bounds__(BLK) void k_reduce_multi(const double *__restrict__ partials, int nb, int nv,
@@ -163,15 +199,25 @@ __global__ __launch_bounds__(BLK) void k_reduce_multi(const double *__restrict__
     if (threadIdx.x == 0) out[q] = s;
 }
 // w -= sum_q h[q] V_q ; acc[q] += h[q]  (device-resident coefficients)
+// NORM (round 6): also |w|^2 of the updated vector (the beta of the Lanczos step) -> nrm_out, finished by the last workgroup
+// (reduce_tail) or, without a ticket, left as gridDim.x partial sums for k_reduce_multi.
+template <bool NORM>
 __global__ __launch_bounds__(BLK) void k_multi_axpy(const double *__restrict__ V, long stride, int nv,
                                                     const double *__restrict__ h, double *__restrict__ w, long off,
-                                                    long n, const double *__restrict__ hprev, double *__restrict__ alpha) {
+                                                    long n, const double *__restrict__ hprev, double *__restrict__ alpha,
+                                                    double *__restrict__ nrm_part, unsigned *ticket, double *__restrict__ nrm_out) {
     // Lanczos, second Gram-Schmidt pass: alpha[j] = h1[j] + h2[j] with j = nv - 1
     if (hprev && blockIdx.x == 0 && threadIdx.x == 0) alpha[nv - 1] = hprev[nv - 1] + h[nv - 1];
+    double nrm = 0.0;
     for (long i = blockIdx.x * (long)BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
         double acc = w[off + i];
         for (int q = 0; q < nv; q++) acc = fma(-h[q], V[(long)q * stride + off + i], acc);
         w[off + i] = acc;
+        if (NORM) nrm = fma(acc, acc, nrm);
+    }
+    if (NORM) {
+        const double v[1] = {block_sum(nrm)};
+        reduce_tail<1>(v, nrm_part, gridDim.x, blockIdx.x, ticket, nrm_out);
     }
 }
 // alpha[j] = h1[j] + h2[j]
@@ -371,6 +417,7 @@ struct MGSolver {
                 hipStream_t s;
                 int l;
             };
+            bool chain_on_main = false;
             std::vector<Replay> replay;
             // coarsest level first: with the exact coarse solve its chain (factorisation) is the longest one
             // (with the factorisation the other levels' chains share ONE stream: the device has four hardware queues, and
@@ -381,7 +428,17 @@ struct MGSolver {
                 // between it and the coarsest one on the owner's spare stream (or on the same one if there is none)
                 hipStream_t ls;
                 if (direct && l != nlv - 1) {
-                    if (l != first_level && side_stream) {
+                    // round 6: the levels beyond first_level + 1 run on the solver's own stream -- it has nothing else to do
+                    // until the chains are in (its queue was the idle fourth one), and two levels' chains one after the other on
+                    // the spare stream had become the longest path of the set-up once the chains lost their reduction launches
+                    static const int on_main = getenv("TP_LANCZOS_ON_MAIN") ? atoi(getenv("TP_LANCZOS_ON_MAIN")) : 1;
+                    if (l > first_level + 1 && side_stream && on_main == 1) {
+                        ls = main;
+                        chain_on_main = true;
+                    } else if (l > first_level + 1 && side_stream && on_main == 2) {
+                        if (!lan_stream[l]) TP_HIP(hipStreamCreateWithFlags(&lan_stream[l], hipStreamNonBlocking));
+                        ls = lan_stream[l];
+                    } else if (l != first_level && side_stream) {
                         ls = side_stream;
                     } else {
                         if (!lan_stream[first_level]) TP_HIP(hipStreamCreateWithFlags(&lan_stream[first_level], hipStreamNonBlocking));
@@ -454,6 +511,7 @@ struct MGSolver {
             for (int l = first_level; l < nlv; l++)
                 if (lan_stream[l] && !(defer && l == nlv - 1)) (void)hipStreamSynchronize(lan_stream[l]);
             if (side_stream) (void)hipStreamSynchronize(side_stream);
+            if (chain_on_main) (void)hipStreamSynchronize(main);
             cd_pending = cd_deferred_last = defer;
             if (rc) return rc;
             for (int l = first_level; l < nlv; l++) {
@@ -577,6 +635,8 @@ struct MGSolver {
             (void)hipFree(b.V);
             (void)hipFree(b.coef);
             (void)hipFree(b.part);
+            (void)hipFree(b.ticket);
+            (void)hipFree(b.mticket);
             (void)hipHostFree(b.hc);
             b = LanBuf();
         }
@@ -601,6 +661,7 @@ struct MGSolver {
     // host copy of the coefficients; the runs of different levels are independent and may share the device
     struct LanBuf {
         double *V = nullptr, *coef = nullptr, *part = nullptr, *hc = nullptr;
+        unsigned *ticket = nullptr, *mticket = nullptr;  // arrival counters of the chain's in-kernel reductions (its own: the chains of the levels run side by side)
         size_t cap = 0;
         int m = 0;
     };
@@ -1613,28 +1674,41 @@ struct MGSolver {
             B.cap = 0;
             TP_HIP(hipMalloc((void **)&B.V, sizeof(double) * need));
             B.cap = need;
+            // zeroed once: the chain reads and writes the owned range of every basis vector only
+            TP_HIP(hipMemsetAsync(B.V, 0, sizeof(double) * need, s));
         }
         if (!B.coef) TP_HIP(hipMalloc((void **)&B.coef, sizeof(double) * 520));
         if (!B.part) TP_HIP(hipMalloc((void **)&B.part, sizeof(double) * 256 * 130));
         if (!B.hc) TP_HIP(hipHostMalloc((void **)&B.hc, sizeof(double) * 520));
+        // Round 6: the reductions of the chain end inside the kernels that produce them (TP_LANCZOS_TAILS=0: second launches, as
+        // before) -- per step 3 launches of k_reduce_multi less, |w|^2 from the second Gram-Schmidt subtraction instead of a dot
+        // product of its own, and on the level-1 operator the D^-1/2 scaling in its epilogue: 12 -> 6 dependent launches per step
+        // on level 1, 10 -> 6 on the stencil levels, 7 -> 6 where one workgroup per vector does the dot products.
+        static const bool tails = !(getenv("TP_LANCZOS_TAILS") && atoi(getenv("TP_LANCZOS_TAILS")) == 0) && !getenv("TP_NO_REDUCE_TAIL");
+        if (tails && !B.ticket) {
+            TP_HIP(hipMalloc((void **)&B.ticket, sizeof(unsigned) * TICKET_WORDS));
+            TP_HIP(hipMalloc((void **)&B.mticket, sizeof(unsigned) * (size_t)MT_WORDS * 130));
+            TP_HIP(hipMemsetAsync(B.ticket, 0, sizeof(unsigned) * TICKET_WORDS, s));
+            TP_HIP(hipMemsetAsync(B.mticket, 0, sizeof(unsigned) * (size_t)MT_WORDS * 130, s));
+        }
         double *V = B.V, *coef = B.coef, *part = B.part;
+        unsigned *mt = tails ? B.mticket : nullptr, *tk = tails ? B.ticket : nullptr;
         auto multi_dot = [&](const double *A, int nv, const double *wv, double *out) -> int {
-            TP_LAUNCH(k_multi_dot, dim3(nb, nv), dim3(BLK), 0, s, A, nd, nv, wv, off, n, nb == 1 ? out : part);
-            if (nb > 1) TP_LAUNCH(k_reduce_multi, dim3(nv), dim3(BLK), 0, s, part, nb, nv, out);
+            TP_LAUNCH(k_multi_dot, dim3(nb, nv), dim3(BLK), 0, s, A, nd, nv, wv, off, n, nb == 1 ? out : part, nb == 1 ? nullptr : mt, out);
+            if (nb > 1 && !mt) TP_LAUNCH(k_reduce_multi, dim3(nv), dim3(BLK), 0, s, part, nb, nv, out);
             return TP_OK;
         };
-        TP_HIP(hipMemsetAsync(V, 0, sizeof(double) * (size_t)nd * (size_t)(steps + 1), s));
-        TP_HIP(hipMemsetAsync(coef, 0, sizeof(double) * 520, s));
         // coef: h1[129] h2[129] alpha[128] beta[128] bb[1]
         double *h1 = coef, *h2 = coef + 129, *al = coef + 258, *be = coef + 386, *bb = coef + 514;
         double *w = L.d, *t = L.r, *dis = L.b;  // scratch that smooth() never swaps: stable addresses for the graph
-        TP_LAUNCH((k_lanczos_init<DOF>), dim3(gn), dim3(BLK), 0, s, L.g, V, dis, L.dinv);
+        TP_LAUNCH((k_lanczos_init<DOF>), dim3(gn), dim3(BLK), 0, s, L.g, V, dis, L.dinv, coef, 520);
         TP_TRY(multi_dot(V, 1, V, bb));
         TP_TRY(allreduce_dev(bb, 1, L.no_comm));
         TP_LAUNCH(k_lanczos_next, dim3(grid_for(n)), dim3(BLK), 0, s, V, bb, 0, be, V, off, n, dis, t);  // normalise v0
         // w = D^-1/2 A D^-1/2 v_j: the first scaling is written by k_lanczos_next together with v_j, the second one
-        // by the operator's epilogue where the level is a stored stencil (NodeArgs::dinv of EPI_APPLY)
-        const bool scaled_apply = L.kind == LV_DIA;
+        // by the operator's epilogue where the level is a stored stencil or the level-1 pattern (NodeArgs::dinv of EPI_APPLY)
+        const bool scaled_apply = L.kind == LV_DIA || (DOF == 3 && L.kind == LV_MACRO && tails);
+        const int ga = grid_for(n);
         for (int j = 0; j < steps; j++) {
             if (scaled_apply) {
                 TP_TRY(halo(l, t));
@@ -1651,15 +1725,18 @@ struct MGSolver {
                 double *h = pass ? h2 : h1;
                 TP_TRY(multi_dot(V, j + 1, w, h));
                 TP_TRY(allreduce_dev(h, j + 1, L.no_comm));
-                // the second pass also records alpha[j] = h1[j] + h2[j]
-                TP_LAUNCH(k_multi_axpy, dim3(grid_for(n)), dim3(BLK), 0, s, V, nd, j + 1, h, w, off, n,
-                                   pass ? h1 : nullptr, al);
+                // the second pass also records alpha[j] = h1[j] + h2[j] -- and, with the tails, |w|^2 of what it leaves
+                if (pass && tails)
+                    TP_LAUNCH(k_multi_axpy<true>, dim3(ga), dim3(BLK), 0, s, V, nd, j + 1, h, w, off, n, h1, al, part, tk, bb);
+                else
+                    TP_LAUNCH(k_multi_axpy<false>, dim3(ga), dim3(BLK), 0, s, V, nd, j + 1, h, w, off, n,
+                              pass ? h1 : nullptr, al, nullptr, nullptr, nullptr);
             }
-            TP_TRY(multi_dot(w, 1, w, bb));
+            if (!tails) TP_TRY(multi_dot(w, 1, w, bb));
             TP_TRY(allreduce_dev(bb, 1, L.no_comm));
             TP_LAUNCH(k_lanczos_next, dim3(grid_for(n)), dim3(BLK), 0, s, w, bb, j, be, V + (size_t)(j + 1) * nd,
                                off, n, dis, t);
-            grid->launches += (nb == 1 ? 8 : 11) - (scaled_apply ? 1 : 0);
+            grid->launches += tails ? 6 : ((nb == 1 ? 8 : 11) - (scaled_apply ? 1 : 0));
         }
         B.m = steps;
         TP_HIP(hipMemcpyAsync(B.hc, coef, sizeof(double) * 520, hipMemcpyDeviceToHost, s));
@@ -1728,19 +1805,23 @@ struct MGSolver {
         // first use: allocate outside the capture (a warm-up run), then capture the identical chain
         int rc = lanczos_enqueue(l, steps);
         if (rc) return rc;
-        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        // the legacy default stream cannot capture: the chain is recorded on the spare stream and replayed where it belongs
+        hipStream_t cs = (s == nullptr && side_stream) ? side_stream : s;
+        if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) {
             (void)hipGetLastError();
             lan_graph_state[l] = -1;
             return TP_OK;  // the warm-up run above already did the work
         }
         const long l0 = grid->launches;
         const double b0 = grid->alg_bytes, f0 = grid->flops;
+        grid->stream = cs;
         rc = lanczos_enqueue(l, steps);
+        grid->stream = s;
         grid->launches = l0;  // the captured chain was not executed
         grid->alg_bytes = b0;
         grid->flops = f0;
         hipGraph_t g = nullptr;
-        const hipError_t e1 = hipStreamEndCapture(s, &g);
+        const hipError_t e1 = hipStreamEndCapture(cs, &g);
         if (rc || e1 != hipSuccess || !g || hipGraphInstantiate(&lan_graph[l], g, nullptr, nullptr, 0) != hipSuccess) {
             (void)hipGetLastError();
             if (g) (void)hipGraphDestroy(g);

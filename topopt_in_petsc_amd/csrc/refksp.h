@@ -129,7 +129,7 @@ struct RefKsp {
         for (int c0 = 0; c0 < nv; c0 += CH) {
             const int cnt = nv - c0 < CH ? nv - c0 : CH;
             TP_LAUNCH(k_multi_dot, dim3(nb, cnt), dim3(BLK), 0, grid->stream, B.chunk[c0 / CH], B.nd, cnt, w, off, n,
-                      nb == 1 ? coef + c0 : part);
+                      nb == 1 ? coef + c0 : part, nullptr, nullptr);
             if (nb > 1) TP_LAUNCH(k_reduce_multi, dim3(cnt), dim3(BLK), 0, grid->stream, part, nb, cnt, coef + c0);
             grid->launches += nb > 1 ? 2 : 1;
         }
@@ -142,8 +142,8 @@ struct RefKsp {
         const long off = L.own_off(), n = L.own_n();
         for (int c0 = 0; c0 < nv; c0 += CH) {
             const int cnt = nv - c0 < CH ? nv - c0 : CH;
-            TP_LAUNCH(k_multi_axpy, dim3(grid_for(n)), dim3(BLK), 0, grid->stream, B.chunk[c0 / CH], B.nd, cnt, coef + c0, w, off,
-                      n, nullptr, nullptr);
+            TP_LAUNCH(k_multi_axpy<false>, dim3(grid_for(n)), dim3(BLK), 0, grid->stream, B.chunk[c0 / CH], B.nd, cnt, coef + c0, w, off,
+                      n, nullptr, nullptr, nullptr, nullptr, nullptr);
             count_launch(grid);
         }
         return TP_OK;
@@ -161,7 +161,7 @@ struct RefKsp {
         Level<DOF> &L = mg->lv[l];
         const long off = L.own_off(), n = L.own_n();
         const int nb = n <= 65536 ? 1 : grid_for(n, 256);
-        TP_LAUNCH(k_multi_dot, dim3(nb, 1), dim3(BLK), 0, grid->stream, w, L.ndof(), 1, w, off, n, nb == 1 ? coef + SLOT_NORM : part);
+        TP_LAUNCH(k_multi_dot, dim3(nb, 1), dim3(BLK), 0, grid->stream, w, L.ndof(), 1, w, off, n, nb == 1 ? coef + SLOT_NORM : part, nullptr, nullptr);
         if (nb > 1) TP_LAUNCH(k_reduce_multi, dim3(1), dim3(BLK), 0, grid->stream, part, nb, 1, coef + SLOT_NORM);
         grid->launches += nb > 1 ? 2 : 1;
         TP_TRY(mg->allreduce_dev(coef + SLOT_NORM, 1, L.no_comm));
