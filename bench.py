@@ -562,6 +562,7 @@ def main():
         # 7.4 s, 64 spread over the cores 5.1 s per design iteration).  The baseline is the BEST of a short list, chosen on
         # the sample mesh in a process each (OpenMP placement is fixed at start-up); the list and the choice go into the line.
         threads_tried = []
+        runner_up = None
         if "TP_CPU_THREADS" not in os.environ and env.get("OMP_NUM_THREADS") in (None, "1"):
             try:
                 usable = len(os.sched_getaffinity(0))
@@ -594,7 +595,6 @@ def main():
                 finally:
                     if os.path.exists(probe_json):
                         os.unlink(probe_json)
-            runner_up = None
             if threads_tried:
                 ranked = sorted(threads_tried, key=lambda r: r["sample_seconds"])
                 best = ranked[0]

@@ -412,7 +412,9 @@ __global__ __launch_bounds__(BLK) void k_prolong_add(Geom gc, Geom gf, const dou
     for (int r = 0; r < DOF; r++) s[r] = 0.0;
     // (Round 6, measured and dropped: the same gather branch-free -- always 8 coarse triples, the absent ones with weight 0, the
     // fine triple requested with them: bit-equal, 34.1 us against 30.6 in the step for the 1 -> 0 launch: the launch is bound by
-    // its read-modify-write of the fine vector out of a cold cache, not by the latency of its gathers.)
+    // its read-modify-write of the fine vector out of a cold cache, not by the latency of its gathers.  Nor by the strided
+    // triples: a thread per DOUBLE of a fine plane -- contiguous 512-byte runs per wave, three times the threads and gather
+    // instructions -- measured +0.25 ms per design iteration, ~50 us per launch.)
     for (int kk = 0; kk <= mk; kk++)
         for (int jj = 0; jj <= mj; jj++)
             for (int ii = 0; ii <= mi; ii++) {
