@@ -112,6 +112,7 @@ for l in range(1 if os.environ.get("TP_NO_MACRO") else 2, nlv):
     le.smooth(l, b, x, 4, False)
     res["cheb1_%%d" %% l] = x.cpu().numpy()
     res["lam%%d" %% l] = np.asarray([le.level_lambda(l)])
+res["lam_level1"] = np.asarray([le.level_lambda(1)])
 r = torch.from_numpy(rng.standard_normal(3 * (ex + 1) * (ey + 1) * (ez + 1))).cuda()
 res["pc"] = le.precond(r).cpu().numpy()
 its = le.KSPSolve(hist_cap=300)
@@ -145,6 +146,38 @@ def test_stencil_kernel_per_node_equals_per_row_bitwise(tmp_path, mesh, nlv, ext
     assert sorted(a.files) == sorted(b.files) and any(k.startswith("apply") for k in a.files)
     for k in a.files:
         assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("mesh,nlv", [((96, 96, 96), 5), ((128, 96, 64), 4)])
+def test_spectra_chains_with_in_kernel_reductions_against_the_plain_chains(tmp_path, mesh, nlv):
+    """Round 6: the Lanczos chains of the set-up end their dot products inside k_multi_dot (same order as k_reduce_multi: the
+    same bits), take beta from the second Gram-Schmidt subtraction (another summation order than a dot product of its own)
+    and scale inside the level-1 operator ((y + c) d became y d + c d at the Dirichlet corrections); TP_LANCZOS_TAILS=0 keeps
+    the chain of round 5, TP_LANCZOS_ON_MAIN=0 its streams.  The estimates agree to rounding -- far inside what the
+    residual-history parity needs -- and the solve takes the same iterations."""
+    res = {}
+    for tag, env in (("tails", {}), ("plain", {"TP_LANCZOS_TAILS": "0", "TP_LANCZOS_ON_MAIN": "0"})):
+        out = str(tmp_path / (tag + ".npz"))
+        e = dict(os.environ)
+        for k in ("TP_LANCZOS_TAILS", "TP_LANCZOS_ON_MAIN", "TP_NO_REDUCE_TAIL"):
+            e.pop(k, None)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", STENCIL_WORKER % {"root": ROOT}] + [str(v) for v in mesh] + [str(nlv), out],
+                           env=e, capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = np.load(out)
+    a, b = res["tails"], res["plain"]
+    lams = [k for k in a.files if k.startswith("lam")]
+    assert lams
+    for k in lams:
+        assert abs(a[k][0] - b[k][0]) <= 1e-12 * abs(b[k][0]), (k, a[k][0], b[k][0])
+    assert int(a["its"][0]) == int(b["its"][0])
+    n = int(a["its"][0])
+    assert np.abs(a["hist"][:n + 1] - b["hist"][:n + 1]).max() <= 1e-10 * np.abs(b["hist"][:n + 1]).max()
+    assert np.abs(a["U"] - b["U"]).max() <= 1e-9 * np.abs(b["U"]).max()
+    for k in a.files:   # the operators themselves do not depend on the chains
+        if k.startswith("apply"):
+            assert np.array_equal(a[k], b[k]), k
 
 
 def test_large_level_node_stencil_with_mirrored_reads_against_the_plain_form(tmp_path):
