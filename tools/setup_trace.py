@@ -1,4 +1,4 @@
-"""Timeline of the set-up part of ONE design iteration (k_matfree_diag .. first k_cheb_first) of a rocprofv3 --kernel-trace
+"""Timeline of the set-up part of ONE design iteration (k_simp .. first k_cheb_first) of a rocprofv3 --kernel-trace
 database, per stream: where the spectra chains of the levels sit and which one the solve waits for.
 usage: setup_trace.py file.db"""
 import sqlite3, sys, collections
@@ -6,7 +6,7 @@ con = sqlite3.connect(sys.argv[1])
 cols = [r[1] for r in con.execute("pragma table_info(kernels)")]
 key = "stream_id" if "stream_id" in cols else ("queue_id" if "queue_id" in cols else None)
 rows = con.execute("select name, start, end%s from kernels order by start" % (", " + key if key else "")).fetchall()
-starts = [i for i, r in enumerate(rows) if r[0].startswith("void k_matfree_diag")]
+starts = [i for i, r in enumerate(rows) if r[0].startswith("k_simp")] or [i for i, r in enumerate(rows) if r[0].startswith("void k_matfree_diag")]
 firsts = [i for i, r in enumerate(rows) if r[0].startswith("k_cheb_first")]
 i0 = [i for i in starts if i < firsts[-1]][-1]
 i1 = next(i for i in firsts if i > i0)

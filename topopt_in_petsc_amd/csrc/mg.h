@@ -406,7 +406,7 @@ struct MGSolver {
         const bool direct = coarse_direct_ok();
         const bool early = cd_early && direct;  // factorisation enqueued by the owner already (its event is recorded)
         cd_early = false;
-        if (!early) cd.factored = false;
+        if (!early) cd.factored = false, cd_inverse_owed = false;
         if (!grid->has_comm && !serial && nlv - first_level >= 2) {
             hipStream_t main = grid->stream;
             if (!lan_fork) TP_HIP(hipEventCreateWithFlags(&lan_fork, hipEventDisableTiming));
@@ -484,6 +484,7 @@ struct MGSolver {
                             if (hipGraphLaunch(lan_graph[r.l], r.s) != hipSuccess || hipEventRecord(lan_done[r.l], r.s) != hipSuccess) trc[q] = TP_ERR_HIP;
                         }
                     });
+                if (early) rc = enqueue_owed_inverse();  // (while the helper threads sit in hipGraphLaunch)
                 for (std::thread &t : th) t.join();
                 for (size_t q = 0; q < streams.size(); q++)
                     if (trc[q] != TP_OK) {   // a failed replay: drop the graphs, enqueue the chains the plain way
@@ -499,6 +500,7 @@ struct MGSolver {
                         }
                     }
             }
+            if (early && rc == TP_OK) rc = enqueue_owed_inverse();  // (no replay this time: behind the directly enqueued chains)
             // Round 5: the factorisation is NOT joined here.  Nothing on the host depends on it (no Ritz values to read), and
             // the solve does not touch the factor before the first V-cycle reaches the coarsest level -- ~0.35 ms of
             // fine-level and level-1..3 work into the solve.  The solver's stream waits for the chain's event right before the
@@ -524,6 +526,7 @@ struct MGSolver {
             }
             return TP_OK;
         }
+        if (early) TP_TRY(enqueue_owed_inverse());
         for (int l = first_level; l < nlv; l++) {
             const bool rep = replicate && l >= rep0;   // the level's estimate comes from its replicated copy: same operator, same
             const int r = rep ? rix(l) : l;             // hashed start vector, no communication
@@ -1144,6 +1147,19 @@ struct MGSolver {
     } cd;
     int cd_level() const { return replicate ? rix(nlv - 1) : nlv - 1; }
     bool cd_early = false;              // this assembly's factorisation is already under way (coarse_direct_early)
+    bool cd_inverse_owed = false;       // ... and its triangular inverse is still to be enqueued behind it (estimate_spectra)
+    int enqueue_owed_inverse() {
+        if (!cd_inverse_owed) return TP_OK;
+        cd_inverse_owed = false;
+        const int l = nlv - 1;
+        hipStream_t main = grid->stream;
+        grid->stream = lan_stream[l];
+        const int rc = coarse_direct_factor(2);
+        grid->stream = main;
+        if (rc) return rc;
+        TP_HIP(hipEventRecord(lan_done[l], lan_stream[l]));
+        return TP_OK;
+    }
     hipStream_t side_stream = nullptr;  // owner's spare stream (idle during estimate_spectra): a second one for the chains
     // Called by the owner as soon as the coarsest level's stencil is enqueued (before the other levels are finished): the
     // factorisation goes to the coarsest level's stream right away.  One rank only (the replicated copy of a multi-rank
@@ -1159,11 +1175,16 @@ struct MGSolver {
         if (!lan_done[l]) TP_HIP(hipEventCreateWithFlags(&lan_done[l], hipEventDisableTiming));
         TP_HIP(hipEventRecord(lan_fork, main));
         TP_HIP(hipStreamWaitEvent(lan_stream[l], lan_fork, 0));
+        // Only the fill and the factorisation itself now: the inverse's 17 launches follow from estimate_spectra, once the
+        // rest of the assembly and the spectra chains are enqueued -- they are not needed for 1.4 ms, and enqueueing them here
+        // kept the solver's stream idle for their host time in the middle of the assembly (round 6).
+        static const bool split_enq = !(getenv("TP_CD_SPLIT_ENQUEUE") && atoi(getenv("TP_CD_SPLIT_ENQUEUE")) == 0);
         grid->stream = lan_stream[l];
-        const int rc = coarse_direct_factor();
+        const int rc = coarse_direct_factor(split_enq ? 1 : 3);
         grid->stream = main;
         if (rc) return rc;
-        TP_HIP(hipEventRecord(lan_done[l], lan_stream[l]));
+        cd_inverse_owed = split_enq;
+        if (!split_enq) TP_HIP(hipEventRecord(lan_done[l], lan_stream[l]));
         cd_early = true;
         *started = true;
         return TP_OK;
@@ -1192,7 +1213,8 @@ struct MGSolver {
         cd.level = -1;
     }
     // factor + invert on grid->stream (the caller puts it on a stream of its own beside the spectra chains)
-    int coarse_direct_factor() {
+    // parts: 1 = band fill + factorisation, 2 = the triangular inverse behind it, 3 = both
+    int coarse_direct_factor(int parts = 3) {
         const int l = cd_level();
         Level<DOF> &L = lv[l];
         hipStream_t s = grid->stream;
@@ -1215,10 +1237,11 @@ struct MGSolver {
             cd.level = l;
         }
         cd.g = g;
+        const int P = g.KB + 1;
+        if (parts & 1) {
         TP_HIP(hipMemsetAsync(cd.Lb, 0, sizeof(double) * (size_t)g.nblk * (g.KB + 1) * CD_NB * CD_NB, s));
         DiaOp<DOF> o{L.S, L.ndof(), L.g};
         TP_LAUNCH((k_cd_fill<DOF>), dim3((g.np + CD_T - 1) / CD_T), dim3(CD_T), 0, s, o, g, cd.Lb);
-        const int P = g.KB + 1;
         static const int stages = getenv("TP_CD_STAGES") ? atoi(getenv("TP_CD_STAGES")) : 3;  // (timing aid: 1 fill, 2 + factor, 3 all)
         static const bool prof_on = getenv("TP_CD_PROF") != nullptr;  // (timing aid: ticks per phase, printed per factorisation)
         long long *prof = nullptr;
@@ -1239,7 +1262,10 @@ struct MGSolver {
                         h[r * 8 + 0] * 1e3 / rate, h[r * 8 + 1] * 1e3 / rate, h[r * 8 + 2] * 1e3 / rate, h[r * 8 + 3] * 1e3 / rate, h[r * 8 + 4] * 1e3 / rate,
                         h[r * 8 + 5] * 1e3 / rate, h[r * 8 + 7] * 1e3 / rate);
         }
-        if (stages >= 3) {
+        }
+        if (!(parts & 2)) return TP_OK;
+        static const int stages2 = getenv("TP_CD_STAGES") ? atoi(getenv("TP_CD_STAGES")) : 3;
+        if (stages2 >= 3) {
             TP_LAUNCH(k_cd_diag_inv, dim3(g.nblk), dim3(WAVE), 0, s, cd.Ld, cd.Linv);
             static const bool dc = getenv("TP_CD_INVERT_COLUMNS") == nullptr;  // (1: round 3's block-column substitution)
             if (dc) {
@@ -1303,7 +1329,7 @@ struct MGSolver {
     void xcd_reset_controls() {
         for (XcdRunCtrl *b : {run_ctl, lan_ctl, cd.ctl})
             if (b) (void)hipMemsetAsync(b, 0, sizeof(XcdRunCtrl), grid->stream);
-        cd_early = false;
+        cd_early = cd_inverse_owed = false;
         cd.factored = false;
     }
     // after an assembly that failed half way: no chain of a side stream may still be running when the next one starts
@@ -1311,7 +1337,7 @@ struct MGSolver {
         for (int i = 0; i < LV_SLOTS; i++)
             if (lan_stream[i]) (void)hipStreamSynchronize(lan_stream[i]);
         if (side_stream) (void)hipStreamSynchronize(side_stream);
-        cd_early = false;
+        cd_early = cd_inverse_owed = false;
         cd_pending = false;
     }
     unsigned long long run_base = 0;        // arrivals of all runs so far

@@ -998,7 +998,7 @@ extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, dou
     TP_TRY(exchange_segments(g, e->d_E, nullptr, nullptr, e->d_E + nel, 2 * lay, 1, 2 * lay));
     // a previous assembly that failed half way must not leave its state behind (a stale "factorisation under way" event,
     // a sticky give-up flag)
-    mg.cd_early = false;
+    mg.cd_early = mg.cd_inverse_owed = false;
     e->assembled = false;
     TP_TRY(mg.join_pending_factor());  // a factorisation no solve has waited for must not be overtaken by the new coarse stencil
     int rc = elasticity_setup_from_E(e);
