@@ -6,7 +6,7 @@
 //   * slab_comm_try_rccl() then hands the exchange to RCCL inside the library (tp_grid_use_rccl, topopt_amd.h): rank 0
 //     makes the unique id, the mailboxes carry it to the others, the library checks the path collectively and falls
 //     back to these hooks if any rank cannot use it.
-// It is also the reduction layer of the multi-process PETSc-named surface (host/petsc_shim.cc: MPI_Allreduce & co.).
+// It is also the reduction layer of the multi-process PETSc-named surface (host/shim/sys.cc: MPI_Allreduce & co.).
 // What an MPI host would write instead: the same three hooks with MPI_Sendrecv / MPI_Allreduce / MPI_Allgather on
 // host-staged or GPU-aware buffers.
 #ifndef TOPOPT_SLAB_COMM_H

@@ -1,6 +1,6 @@
 /* petsc.h (compat) -- the subset of the PETSc 3.11 C API that TopOpt_in_PETSc's hot path is written against
  * (the calls of LinearElasticity.cc, Filter.cc and PDEFilter.cc), implemented on the MI355X
- * library (libtopopt_petsc_shim.so, host/petsc_shim.cc -> libtopopt_amd.so).
+ * library (libtopopt_petsc_shim.so, host/shim/ -> libtopopt_amd.so).
  *
  * Put  -I include/petsc_compat  where a PETSc build would put  -I $PETSC_DIR/include : ALL EIGHT sources of the
  * reference (main.cc, TopOpt.cc, MMA.cc, MPIIO.cc and the three hot-path classes) compile UNCHANGED against this

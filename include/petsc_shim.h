@@ -1,6 +1,6 @@
 /* petsc_shim.h -- the one extension of libtopopt_petsc_shim.so beyond the PETSc names (used by host/ksp_probe.cc and
  * tests/test_cpp_host.py): what a configured KSP resolves to.  The PETSc-named surface itself lives in
- * include/petsc_compat/petsc.h (the header the reference's own sources compile against, host/petsc_shim.cc behind it). */
+ * include/petsc_compat/petsc.h (the header the reference's own sources compile against, host/shim/ behind it). */
 #ifndef TOPOPT_PETSC_SHIM_H
 #define TOPOPT_PETSC_SHIM_H
 #include "petsc_compat/petsc.h"

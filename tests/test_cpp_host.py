@@ -137,7 +137,7 @@ def test_cpp_driver_slab_ranks_match_one_rank(filt):
             assert len(a) == len(b) and a == pytest.approx(b, rel=2e-5, abs=2e-6), (n, a, b)
 
 
-# ---- PETSc-named surface (include/petsc_compat/petsc.h, host/petsc_shim.cc) ---------------------------------------------
+# ---- PETSc-named surface (include/petsc_compat/petsc.h, host/shim/) ---------------------------------------------
 def _shim_symbols():
     hdr = open(os.path.join(ROOT, "include", "petsc_compat", "petsc.h")).read()
     return sorted(set(re.findall(r"^PetscErrorCode\s+(\w+)\(", hdr, flags=re.M)))
