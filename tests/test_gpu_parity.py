@@ -283,6 +283,47 @@ def test_conv_filter_default_radius_c2_bits(tmp_path):
     assert np.abs(res["tiled"]["xt"]).max() > 0
 
 
+@pytest.mark.parametrize("mesh,rfac", [((128, 128, 128), 2.56), ((128, 64, 64), 2.56), ((97, 50, 43), 2.56), ((128, 128, 128), 1.5)])
+def test_conv_filter_several_outputs_along_z_bits(tmp_path, mesh, rfac):
+    """Round 6: at ElemConn 1 and 2 a thread of the tiled cone filter sums two or four outputs along z (k_conv_filter_zmulti:
+    a staged value serves every output whose window holds its plane -- 2.5 x fewer LDS reads); every output is still one fma
+    chain over (dk, dj, di) ascending: the bits of the one-output tile kernel (TP_FILTER_ZMULTI=0) and of the direct loop
+    (TP_NO_FILTER_TILE=1), on ragged meshes too, for both forced widths and the size-based choice."""
+    import subprocess, sys
+    worker = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import topopt_in_petsc_amd as tp\n"
+        "tp.load_library()\n"
+        "ex, ey, ez, rfac = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5])\n"
+        "grid = tp.Grid(ex + 1, ey + 1, ez + 1, 1.0 / ey)\n"
+        "f = tp.Filter(grid, 1, rfac / ey)\n"
+        "assert f.ElemConn in (1, 2)\n"
+        "x = grid.synth_density(12345)\n"
+        "xt, xp = grid.elem_vec(), grid.elem_vec()\n"
+        "f.FilterProject(x, xt, xp)\n"
+        "df = torch.sin(torch.arange(x.numel(), dtype=torch.float64, device='cuda'))\n"
+        "f.Gradients(x, xt, df, [])\n"
+        "np.savez(sys.argv[1], xt=xt.cpu().numpy(), df=df.cpu().numpy(), hs=f.Hs().cpu().numpy())\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env in (("auto", {}), ("z4", {"TP_FILTER_ZMULTI": "4"}), ("z2", {"TP_FILTER_ZMULTI": "2"}), ("one", {"TP_FILTER_ZMULTI": "0"}),
+                     ("direct", {"TP_NO_FILTER_TILE": "1"})):
+        e = dict(os.environ)
+        e.pop("TP_NO_FILTER_TILE", None)
+        e.pop("TP_FILTER_ZMULTI", None)
+        e.update(env)
+        out = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", worker, out] + [str(v) for v in mesh] + [str(rfac)], env=e, capture_output=True, text=True,
+                           timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = np.load(out)
+    assert np.abs(res["direct"]["xt"]).max() > 0
+    for tag in ("auto", "z4", "z2", "one"):
+        for k in ("xt", "df", "hs"):
+            assert np.array_equal(res[tag][k].view(np.int64), res["direct"][k].view(np.int64)), (tag, k)
+
+
 @pytest.mark.parametrize("rfac", [1.5, 2.56, 3.2])
 def test_conv_filter(tp, orc, rfac):
     ex, ey, ez = 12, 8, 8

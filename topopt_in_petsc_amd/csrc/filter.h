@@ -67,6 +67,80 @@ __global__ __launch_bounds__(256) void k_conv_filter_tiled(int ex, int ey, int e
     if (d2) s = s / d2[t];
     out[t] = s;
 }
+// Round 6, small radii (ElemConn 1, 2; counters: the one-output form above is LDS-issue bound -- one ds_read per fma): NO outputs
+// per thread along z.  A staged value serves up to NO outputs (those whose window holds its plane), so a thread reads
+// (NO + 2C)(2C+1)^2 values for NO outputs instead of NO (2C+1)^3 -- 2.5 x fewer at C = 2, NO = 4 -- at unit lane stride in x (the
+// four-outputs-along-x form conflicts in the LDS banks at these radii, below).  Every output is still ONE fma chain over
+// (dk, dj, di) ascending with exact zeros outside the domain: the bits of k_conv_filter.  The weights are sign-symmetric bit for
+// bit ((di dx)^2 ...), so the (C+1)^3 values of one octant are read once into scalar registers.
+template <int C, int NO>
+__global__ __launch_bounds__(256) void k_conv_filter_zmulti(int ex, int ey, int ez_own, int e0z, int ez_glob,
+                                                            const double *__restrict__ xg, const double *__restrict__ wtab,
+                                                            double *__restrict__ out, const double *__restrict__ d1,
+                                                            const double *__restrict__ d2) {
+    constexpr int TX = 32, TY = 4, TZT = 2, TZ = TZT * NO, W1 = 2 * C + 1, SX = TX + 2 * C, SY = TY + 2 * C, SZ = TZ + 2 * C;
+    __shared__ double s_x[SZ * SY * SX];
+    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY, z0 = blockIdx.z * TZ;
+    for (int f = threadIdx.x; f < SZ * SY * SX; f += 256) {
+        const int sx = f % SX, sy = (f / SX) % SY, sz = f / (SX * SY);
+        const int gi = x0 - C + sx, gj = y0 - C + sy, kl = z0 - C + sz;  // kl: layer relative to the own range
+        const bool ok = gi >= 0 && gi < ex && gj >= 0 && gj < ey && kl + e0z >= 0 && kl + e0z < ez_glob && kl < ez_own + C;
+        s_x[f] = ok ? xg[(long)gi + (long)ex * (gj + (long)ey * (kl + C))] : 0.0;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x % TX, ty = (threadIdx.x / TX) % TY, tzt = threadIdx.x / (TX * TY);
+    const int i = x0 + tx, j = y0 + ty, k0 = z0 + NO * tzt;
+    if (i >= ex || j >= ey || k0 >= ez_own) return;
+    double wq[C + 1][C + 1][C + 1];
+#pragma unroll
+    for (int a = 0; a <= C; a++)
+#pragma unroll
+        for (int b = 0; b <= C; b++)
+#pragma unroll
+            for (int c = 0; c <= C; c++) wq[a][b][c] = wtab[((C + a) * W1 + (C + b)) * W1 + (C + c)];
+    double acc[NO];
+#pragma unroll
+    for (int o = 0; o < NO; o++) acc[o] = 0.0;
+    // Straight-line code, scheduled row by row: left alone the compiler sinks the sums of the later outputs behind the last row
+    // with every staged value live (370 VGPRs at C = 2, NO = 4: one wave per SIMD, 78 us against the one-output form's 49).  The
+    // pins keep a row's fma of every output in the row's slot; the NEXT row is requested before the current one is consumed.
+    constexpr int R = (NO + 2 * C) * W1;
+    const double *__restrict__ base = s_x + ((NO * tzt) * SY + ty) * SX + tx;
+    double v[W1], vn[W1];
+#pragma unroll
+    for (int di = 0; di < W1; di++) v[di] = base[di];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int p = r / W1, dj = r % W1;
+        if (r + 1 < R) {
+#pragma unroll
+            for (int di = 0; di < W1; di++) vn[di] = base[(((r + 1) / W1) * SY + ((r + 1) % W1)) * SX + di];
+        }
+#pragma unroll
+        for (int di = 0; di < W1; di++)
+#pragma unroll
+            for (int o = 0; o < NO; o++) {
+                const int dk = p - o;
+                if (dk >= 0 && dk < W1)
+                    acc[o] = fma(wq[dk < C ? C - dk : dk - C][dj < C ? C - dj : dj - C][di < C ? C - di : di - C], v[di], acc[o]);
+            }
+#pragma unroll
+        for (int o = 0; o < NO; o++) asm volatile("" : "+v"(acc[o]));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int di = 0; di < W1; di++) v[di] = vn[di];
+    }
+#pragma unroll
+    for (int o = 0; o < NO; o++) {
+        const int k = k0 + o;
+        if (k >= ez_own) break;
+        const long t = (long)i + (long)ex * (j + (long)ey * k);
+        double sres = acc[o];
+        if (d1) sres = sres / d1[t];
+        if (d2) sres = sres / d2[t];
+        out[t] = sres;
+    }
+}
 // Large radii (ElemConn 4 .. 8: the reference's own default rmin = 0.08 on the BASELINE meshes, TopOpt.cc:121 --
 // 5 on 128x64x64 (1331 taps), 8 at 128^3 (4913)): the same tile idea with FOUR outputs per thread along x.  A thread
 // loads a row of 4 + 2C staged values once and uses each of them for up to four outputs (sliding window): 3.2x fewer
@@ -303,8 +377,24 @@ static int filter_conv(tp_filter *f, double *out, const double *d1, const double
     // Round 6 (counters: the one-output form is LDS-issue bound, one ds_read per fma): the four-outputs-per-thread form was
     // measured for the small radii too, bit-equal -- ElemConn 3 (343 taps): 105.5 -> 69.8 us at 128^3, taken; ElemConn 2 (125
     // taps, the bench's 2.56 h): 96 us against 50 (its 32-byte lane stride of the staged rows conflicts in the LDS banks, and a
-    // quarter of the threads), fully unrolled no better: the one-output form stays for ElemConn 1 and 2
-    if (!no_tile && c == 1)
+    // quarter of the threads), fully unrolled no better.  Several outputs per thread along Z instead keep the unit lane stride:
+    // k_conv_filter_zmulti serves ElemConn 1 and 2 on all but the small meshes
+    // outputs per thread along z at ElemConn 1, 2 (k_conv_filter_zmulti, bit-equal): by the number of workgroups the one-output
+    // form would launch -- 128^3: 49.6 -> 36.1 us with four (two: 39.6), 128x64x64: 18.2 -> 15.6 with two (four: 16.4),
+    // 48x24x24: 8.0 as it is (8.4 / 10.7); TP_FILTER_ZMULTI=0 / 2 / 4 forces one
+    static const int zm_env = getenv("TP_FILTER_ZMULTI") ? atoi(getenv("TP_FILTER_ZMULTI")) : -1;
+    const long wgs1 = (long)tg.x * tg.y * tg.z;
+    const int zm = zm_env >= 0 ? zm_env : (wgs1 >= 8192 ? 4 : (wgs1 >= 1024 ? 2 : 0));
+#define TP_CONV_ZMULTI(CC, NO)                                                                                                     \
+    TP_LAUNCH((k_conv_filter_zmulti<CC, NO>), dim3((g->ex + 31) / 32, (g->ey + 3) / 4, (g->ez_own + 2 * NO - 1) / (2 * NO)), dim3(256), 0, \
+              g->stream, g->ex, g->ey, g->ez_own, g->rank * g->ez_own, g->ez_glob, f->xg, f->wtab, out, d1, d2)
+    if (!no_tile && c == 2 && zm == 4)
+        TP_CONV_ZMULTI(2, 4);
+    else if (!no_tile && c == 2 && zm == 2)
+        TP_CONV_ZMULTI(2, 2);
+    else if (!no_tile && c == 1 && zm >= 2)
+        TP_CONV_ZMULTI(1, 4);  // (128^3: 25.9 -> 22.2 us)
+    else if (!no_tile && c == 1)
         TP_CONV_TILED(1);
     else if (!no_tile && c == 2)
         TP_CONV_TILED(2);
@@ -321,6 +411,7 @@ static int filter_conv(tp_filter *f, double *out, const double *d1, const double
     else if (!no_tile && c == 8)
         TP_CONV_WIDE(8, 4, 2);
 #undef TP_CONV_WIDE
+#undef TP_CONV_ZMULTI
 #define TP_CONV_ZRING(CC)                                                                                                             \
     TP_LAUNCH((k_conv_filter_zring<CC>), dim3((g->ex + 31) / 32, (g->ey + 15) / 16, (g->ez_own + 3) / 4), dim3(256), 0, g->stream, \
               g->ex, g->ey, g->ez_own, g->rank * g->ez_own, g->ez_glob, f->xg, f->wtab, out, d1, d2)
