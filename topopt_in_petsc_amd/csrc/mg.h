@@ -406,6 +406,12 @@ struct MGSolver {
         const bool direct = coarse_direct_ok();
         const bool early = cd_early && direct;  // factorisation enqueued by the owner already (its event is recorded)
         cd_early = false;
+        struct ReadyReset {  // the level events belong to this assembly only
+            bool *f;
+            ~ReadyReset() {
+                for (int i = 0; i < LV_SLOTS; i++) f[i] = false;
+            }
+        } ready_reset{lv_ready_set};
         if (!early) cd.factored = false, cd_inverse_owed = false;
         if (!grid->has_comm && !serial && nlv - first_level >= 2) {
             hipStream_t main = grid->stream;
@@ -449,7 +455,7 @@ struct MGSolver {
                     ls = lan_stream[l];
                 }
                 if (!lan_done[l]) TP_HIP(hipEventCreateWithFlags(&lan_done[l], hipEventDisableTiming));
-                TP_HIP(hipStreamWaitEvent(ls, lan_fork, 0));
+                TP_HIP(hipStreamWaitEvent(ls, (lv_ready_set[l] && l != nlv - 1) ? lv_ready[l] : lan_fork, 0));
                 const int steps = (l == nlv - 1 && l > 0) ? NLANCZOS_COARSE : opt.nlanczos;
                 // A captured chain is replayed from a helper thread (round 4): hipGraphLaunch of a ~100-node chain keeps
                 // the calling thread for 0.6-1.3 ms (rocprofv3 --hip-trace), so three replays issued one after the other
@@ -655,6 +661,11 @@ struct MGSolver {
         if (lan_fork) (void)hipEventDestroy(lan_fork);
         lan_fork = nullptr;
         for (int i = 0; i < LV_SLOTS; i++) {
+            if (lv_ready[i]) (void)hipEventDestroy(lv_ready[i]);
+            lv_ready[i] = nullptr;
+            lv_ready_set[i] = false;
+        }
+        for (int i = 0; i < LV_SLOTS; i++) {
             if (pend_ev[i]) (void)hipEventDestroy(pend_ev[i]);
             pend_ev[i] = nullptr;
             pend[i].ptr = nullptr;
@@ -677,6 +688,19 @@ struct MGSolver {
     int lan_graph_state[LV_SLOTS] = {};  // 0: not tried, 1: valid, -1: capture failed -> direct launches
     hipStream_t lan_stream[LV_SLOTS] = {};
     hipEvent_t lan_fork = nullptr, lan_done[LV_SLOTS] = {};
+    // Round 6: the owner may say when a level's operator is complete (mark_level_ready, recorded on the solver's stream in the
+    // middle of the assembly); that level's spectrum chain then waits for this event instead of for the end of the whole
+    // assembly -- level 1's chain needs two small kernels, not the stencils of the levels below it.  Valid for one assembly.
+    hipEvent_t lv_ready[LV_SLOTS] = {};
+    bool lv_ready_set[LV_SLOTS] = {};
+    int mark_level_ready(int l) {
+        static const bool off = getenv("TP_NO_LEVEL_EVENTS") != nullptr;
+        if (off || grid->has_comm || l < 0 || l >= LV_SLOTS) return TP_OK;
+        if (!lv_ready[l]) TP_HIP(hipEventCreateWithFlags(&lv_ready[l], hipEventDisableTiming));
+        TP_HIP(hipEventRecord(lv_ready[l], grid->stream));
+        lv_ready_set[l] = true;
+        return TP_OK;
+    }
 
     // ---- operator application with one of the epilogues -------------------
     // out_halo: the ghost planes of a.out will be read next (another operator application, a grid transfer).  On the

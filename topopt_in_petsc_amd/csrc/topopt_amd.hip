@@ -999,6 +999,7 @@ extern "C" int tp_elasticity_assemble(tp_elasticity *e, const double *xPhys, dou
     // a previous assembly that failed half way must not leave its state behind (a stale "factorisation under way" event,
     // a sticky give-up flag)
     mg.cd_early = mg.cd_inverse_owed = false;
+    for (bool &b : mg.lv_ready_set) b = false;
     e->assembled = false;
     TP_TRY(mg.join_pending_factor());  // a factorisation no solve has waited for must not be overtaken by the new coarse stencil
     int rc = elasticity_setup_from_E(e);
@@ -1153,7 +1154,10 @@ static int elasticity_setup_from_E(tp_elasticity *e) {
             TP_TRY(mg.coarse_direct_early(&early));
         }
         TP_TRY(mg.setup_matfree_level(0, e->KE));
-        for (int l = 1; l < mg.nlv - (mg.nlv > 2 ? 1 : 0); l++) TP_TRY(finish_level(l));
+        for (int l = 1; l < mg.nlv - (mg.nlv > 2 ? 1 : 0); l++) {
+            TP_TRY(finish_level(l));
+            TP_TRY(mg.mark_level_ready(l));  // (its spectrum chain may start from here, mg.h)
+        }
     } else {
         TP_TRY(mg.setup_matfree_level(0, e->KE));
         for (int l = 1; l < mg.nlv; l++) {
